@@ -1,0 +1,93 @@
+"""ctypes binding of libscipnp.so (C ABI declared in include/scipnp.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing or a symbol is absent this module raises at import of the first op; if no MI355X is
+visible every op raises before touching memory.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libscipnp.so')
+
+_f = C.POINTER(C.c_float)
+_d = C.POINTER(C.c_double)
+_i32 = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_int = C.c_int
+_flt = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/scipnp.h declares
+SIGNATURES = {
+    'scipnp_version': (C.c_char_p, []),
+    'scipnp_last_error': (C.c_char_p, []),
+    'scipnp_arch': (C.c_char_p, []),
+    'scipnp_A': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_At': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_phisum': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_bayer_split': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_bayer_merge': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_proj_twostage': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _vp]),
+    'scipnp_proj_onestage': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _vp]),
+    'scipnp_mosaic_to_state': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_state_to_mosaic': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_y_to_meas': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_rgb_to_cube': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_cube_to_rgb': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_pm_setup': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_pm_project': (_int, [_vp] * 6 + [_int, _int, _int, _int, _flt, _flt, _vp]),
+    'scipnp_tv_workspace_bytes': (_sz, [_int, _int, _int, _int]),
+    'scipnp_tv_chambolle': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _flt, _flt, _int, _vp, _sz, _vp, _vp]),
+    'scipnp_pm_dual_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _flt, _int, _int, _int,
+                                     C.POINTER(_int), _vp]),
+    'scipnp_pm_pre_denoise': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
+    'scipnp_pm_post_denoise': (_int, [_vp] * 10 + [_int, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_sse_partials': (_int, [_vp, _vp, _sz, _vp, C.POINTER(_int), _vp]),
+    'scipnp_conv3x3_packed_floats': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_weights': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
+}
+
+_lib = None
+
+
+class ScipnpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libscipnp.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScipnpError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C adaptivepnp_sci_amd/csrc`).  There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ScipnpError(f'libscipnp.so lacks symbol {name}; rebuild the library') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().scipnp_last_error().decode()
+        if rc in (-1, -2, -4):
+            raise ValueError(f'{what}: {msg}')
+        raise ScipnpError(f'{what}: {msg} (code {rc})')
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise ScipnpError('no MI355X/ROCm device visible: the scipnp hot path runs only on the GPU '
+                          '(no CPU fallback by design)')

@@ -1,0 +1,79 @@
+// Shared helpers for the scipnp HIP sources (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/scipnp.h"
+
+namespace scipnp {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return code;
+}
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SCIPNP_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return SCIPNP_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define SCIPNP_REQUIRE(cond, ...) \
+    do { if (!(cond)) return ::scipnp::fail(SCIPNP_EINVAL, __VA_ARGS__); } while (0)
+#define SCIPNP_ALIGNED(p) \
+    do { if (!::scipnp::aligned16(p)) return ::scipnp::fail(SCIPNP_EALIGN, #p " is not 16-byte aligned"); } while (0)
+
+constexpr int WAVE = 64;
+
+// Sum of nB addends in the order PyTorch's CPU reduction uses for `torch.sum(dim)` over a short
+// strided dim (verified against torch 2.10 for 1 <= nB <= 24): four accumulators over the full
+// groups of four (element i -> accumulator i%4), the remainder appended to accumulator 0, then
+// ((a0+a1)+a2)+a3.  Keeps the projection bit-identical to the reference's A_() (utilspy.py:33).
+template <int MAXB, typename F>
+__device__ __forceinline__ float torch_order_sum(int nB, F term) {
+    // fully unrolled over MAXB (a multiple of 4, or < 4) with predicates so that `term(i)` only ever
+    // sees compile-time indices: register arrays stay in registers (no scratch).
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int n4 = nB & ~3;
+#pragma unroll
+    for (int i = 0; i + 3 < MAXB; i += 4) {
+        if (i < n4) {
+            a0 = a0 + term(i);
+            a1 = a1 + term(i + 1);
+            a2 = a2 + term(i + 2);
+            a3 = a3 + term(i + 3);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i)
+        if (i >= n4 && i < nB) a0 = a0 + term(i);
+    return ((a0 + a1) + a2) + a3;
+}
+
+// block-wide sum of one double per thread (block size a multiple of 64, <= 1024; `tid` is the
+// linear thread id); result valid in thread 0.  Fixed tree + fixed wave order: deterministic.
+__device__ __forceinline__ double block_sum_double(double v, double* lds /* >= 16 doubles */, int tid, int nthreads) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (tid == 0) {
+        const int nw = (nthreads + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += lds[i];
+    }
+    __syncthreads();
+    return r;
+}
+
+}  // namespace scipnp

@@ -1,0 +1,271 @@
+// 3x3 convolution (stride 1, zero pad 1) as an implicit GEMM on the CDNA4 matrix cores with fp32
+// operands: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate -- the only MFMA precision
+// that meets the 1e-5 per-iterate parity bar of the PnP loop; bf16/fp16 operands fail it by 2-3
+// orders of magnitude).
+//
+// Data layout ("c8"): activations [n][C/8][h][w][8] -- 8-channel groups innermost.  With
+//   A = weights  [co (32 rows)][k]      lane l holds A[l&31][l>>5]
+//   B = pixels   [k][px (32 cols)]      lane l holds B[l>>5][l&31]
+// and k running over the channels of one group, one ds_read_b128 per lane yields four MFMA k-steps
+// for both operands (lane half h reads channels 4h..4h+3), and the 32x32 accumulator of a lane
+// holds, for each of its four row groups g, the four consecutive output channels 8g+4h..8g+4h+3 of
+// its pixel: the epilogue is one 16-byte store per lane and group, 1 KiB contiguous per wave --
+// i.e. the output is written directly in the c8 layout the next layer reads.
+//
+// Work decomposition: workgroup = 4 waves = output tile 8 rows x 32 columns x (32*COB) channels;
+// wave w owns rows 2w, 2w+1 (2 pixel blocks x COB channel blocks = 2*COB accumulators).  K loop =
+// channel groups of the input; per group the 10x34x8 input halo tile and the 9 x (32*COB) x 8 weight
+// slab go HBM/L2 -> registers -> LDS (double-buffered: the loads for group g+1 are issued before the
+// 216 MFMAs of group g and written to the other buffer after them; one barrier per group).
+// The kernel is MFMA-bound by construction: per group and wave 9*4*2*COB MFMAs of 64 cycles against
+// 5 ds_read_b128 per tap.
+#include "common.hpp"
+
+namespace scipnp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CV_TH = 8, CV_TW = 32;
+constexpr int CV_TWP = CV_TW + 2, CV_THP = CV_TH + 2;
+constexpr int CV_IN_FLOATS = CV_THP * CV_TWP * 8;      // 2720
+constexpr int CV_IN_VEC = CV_IN_FLOATS / 4;            // 680 float4
+constexpr int CV_THREADS = 256;
+constexpr int CV_IN_ITERS = (CV_IN_VEC + CV_THREADS - 1) / CV_THREADS;  // 3
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int COB>
+struct ConvCfg {
+    static constexpr int COUTP = 32 * COB;
+    static constexpr int W_FLOATS = 9 * COUTP * 8;
+    static constexpr int W_VEC = W_FLOATS / 4;
+    static constexpr int W_ITERS = (W_VEC + CV_THREADS - 1) / CV_THREADS;
+    static constexpr int STAGE = CV_IN_FLOATS + W_FLOATS;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
+};
+
+template <int COB>
+__global__ void __launch_bounds__(CV_THREADS, (COB <= 3 ? 2 : 1))
+conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk, float* __restrict__ out,
+                  const float* __restrict__ residual, int CGin, int CGout, int CoutP_total, int nsplit,
+                  int H, int W, int flags) {
+    using Cfg = ConvCfg<COB>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
+    const int n = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+    const size_t HW = (size_t)H * W;
+    const float* in_n = in + (size_t)n * CGin * HW * 8;
+    const float* w_split = wpk + (size_t)split * Cfg::COUTP * 8;
+
+    f32x4 st_in[CV_IN_ITERS];
+    f32x4 st_w[Cfg::W_ITERS];
+
+    auto issue_loads = [&](int cig) {
+        const float* src = in_n + (size_t)cig * HW * 8;
+#pragma unroll
+        for (int k = 0; k < CV_IN_ITERS; ++k) {
+            const int e = tid + k * CV_THREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < CV_IN_VEC) {
+                const int pix = e >> 1, half = e & 1;
+                const int r = pix / CV_TWP, c = pix - r * CV_TWP;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v = *(const f32x4*)(src + ((size_t)gy * W + gx) * 8 + 4 * half);
+            }
+            st_in[k] = v;
+        }
+        const float* wsrc = w_split + (size_t)cig * 9 * CoutP_total * 8;
+#pragma unroll
+        for (int k = 0; k < Cfg::W_ITERS; ++k) {
+            const int e = tid + k * CV_THREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < Cfg::W_VEC) {
+                const int tap = e / (Cfg::COUTP * 2), rem = e - tap * (Cfg::COUTP * 2);
+                v = *(const f32x4*)(wsrc + ((size_t)tap * CoutP_total * 2 + rem) * 4);
+            }
+            st_w[k] = v;
+        }
+    };
+    auto write_lds = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < CV_IN_ITERS; ++k) {
+            const int e = tid + k * CV_THREADS;
+            if (e < CV_IN_VEC) *(f32x4*)(buf + 4 * e) = st_in[k];
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::W_ITERS; ++k) {
+            const int e = tid + k * CV_THREADS;
+            if (e < Cfg::W_VEC) *(f32x4*)(buf + CV_IN_FLOATS + 4 * e) = st_w[k];
+        }
+    };
+
+    f32x16 acc[2][COB];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
+
+    issue_loads(0);
+    write_lds(smem);
+    __syncthreads();
+
+    // per-lane LDS offsets (floats)
+    const int b_off = ((2 * wv) * CV_TWP + li) * 8 + 4 * lh;   // + (pb+ky)*TWP*8 + kx*8
+    const int a_off = CV_IN_FLOATS + li * 8 + 4 * lh;           // + (tap*COUTP + cb*32)*8
+
+    for (int cig = 0; cig < CGin; ++cig) {
+        const float* buf = smem + (cig & 1) * Cfg::STAGE;
+        const bool more = (cig + 1 < CGin);
+        if (more) issue_loads(cig + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            f32x4 bf[2], af[COB];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+                bf[pb] = *(const f32x4*)(buf + b_off + ((pb + ky) * CV_TWP + kx) * 8);
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+                af[cb] = *(const f32x4*)(buf + a_off + (tap * Cfg::COUTP + cb * 32) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int cb = 0; cb < COB; ++cb)
+                        acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][j], bf[pb][j], acc[pb][cb], 0, 0, 0);
+        }
+        if (more) write_lds(smem + ((cig + 1) & 1) * Cfg::STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (+ residual) (+ ReLU), 16-byte stores straight into the c8 layout
+    const float* bias = wpk + (size_t)CGin * 9 * CoutP_total * 8;
+    const bool relu = flags & 1, add_res = (flags & 2) && residual;
+    const int x = x0 + li;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int y = y0 + 2 * wv + pb;
+        if (y < H && x < W) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cog = (split * COB + cb) * 4 + g;
+                    if (cog < CGout) {
+                        const f32x4 bs = *(const f32x4*)(bias + cog * 8 + 4 * lh);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[pb][cb][4 * g + e] + bs[e];
+                        const size_t o = (((size_t)n * CGout + cog) * HW + (size_t)y * W + x) * 8 + 4 * lh;
+                        if (add_res) {
+                            const f32x4 rs = *(const f32x4*)(residual + o);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] + rs[e];
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        *(f32x4*)(out + o) = v;
+                    }
+                }
+        }
+    }
+}
+
+template <int COB>
+static int launch_conv(const float* in, const float* wpk, float* out, const float* residual, int n, int Cin,
+                       int Cout, int h, int w, int flags, hipStream_t st) {
+    using Cfg = ConvCfg<COB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8_kernel<COB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3, %zu B LDS): %s", Cfg::LDS_BYTES,
+                                         hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int CoutP = round_up(Cout, 32);
+    const int nsplit = CoutP / Cfg::COUTP;
+    const dim3 grid((w + CV_TW - 1) / CV_TW, (h + CV_TH - 1) / CV_TH, n * nsplit);
+    hipLaunchKernelGGL((conv3x3_c8_kernel<COB>), grid, dim3(CV_THREADS), Cfg::LDS_BYTES, st, in, wpk, out, residual,
+                       Cin / 8, Cout / 8, CoutP, nsplit, h, w, flags);
+    return launch_status("conv3x3_c8_kernel");
+}
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+size_t scipnp_conv3x3_packed_floats(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
+    const int CoutP = round_up(Cout, 32);
+    return (size_t)(Cin / 8) * 9 * CoutP * 8 + CoutP;
+}
+
+int scipnp_pack_conv3x3_weights(const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
+                                int Cin_real, int Cout_real, int Cin, int Cout, float* packed) {
+    SCIPNP_REQUIRE(w && packed, "null pointer");
+    SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
+                   "bad channel counts Cin_real=%d Cout_real=%d Cin=%d Cout=%d", Cin_real, Cout_real, Cin, Cout);
+    const int CoutP = round_up(Cout, 32);
+    const size_t nw = (size_t)(Cin / 8) * 9 * CoutP * 8;
+    for (size_t i = 0; i < nw + CoutP; ++i) packed[i] = 0.f;
+    for (int co = 0; co < Cout_real; ++co) {
+        const float sc = bn_scale ? bn_scale[co] : 1.f;
+        for (int ci = 0; ci < Cin_real; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                const float v = w[((size_t)co * Cin_real + ci) * 9 + tap];
+                packed[(((size_t)(ci / 8) * 9 + tap) * CoutP + co) * 8 + (ci % 8)] = bn_scale ? v * sc : v;
+            }
+        float bv = bias ? bias[co] : 0.f;
+        if (bn_scale) bv = bv * sc;
+        if (bn_shift) bv = bv + bn_shift[co];
+        packed[nw + co] = bv;
+    }
+    return SCIPNP_OK;
+}
+
+int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const float* residual, int n, int Cin,
+                      int Cout, int h, int w, int flags, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && packed_w && out, "null pointer");
+    SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0,
+                   "bad shape n=%d Cin=%d Cout=%d h=%d w=%d (channels must be multiples of 8)", n, Cin, Cout, h, w);
+    SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(packed_w); SCIPNP_ALIGNED(out);
+    if (residual) SCIPNP_ALIGNED(residual);
+    const int CoutP = round_up(Cout, 32);
+    SCIPNP_REQUIRE((long long)n * (CoutP / 32) <= 65535, "grid too large");
+    hipStream_t st = (hipStream_t)s;
+    if (CoutP % 96 == 0) return launch_conv<3>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+    if (CoutP % 128 == 0) return launch_conv<4>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+    if (CoutP % 64 == 0) return launch_conv<2>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+    return launch_conv<1>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+}
+
+int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,
+                          float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8 && packed && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
+    float* buf[2] = {scratch0, scratch1};
+    int rc = scipnp_conv3x3_c8(in_c8, packed[0], buf[0], nullptr, B, 16, nc, M, N, 1, s);
+    if (rc) return rc;
+    int cur = 0;
+    for (int l = 1; l < nb - 1; ++l) {
+        rc = scipnp_conv3x3_c8(buf[cur], packed[l], buf[cur ^ 1], nullptr, B, nc, nc, M, N, 1, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return scipnp_conv3x3_c8(buf[cur], packed[nb - 1], out_c8, nullptr, B, nc, 16, M, N, 0, s);
+}
+
+}  // extern "C"

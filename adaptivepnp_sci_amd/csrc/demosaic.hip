@@ -1,0 +1,229 @@
+// Pre- and post-denoiser fusions on the plane-major state.
+//
+// pre : mosaic = x + inv_rho*b  ->  Malvar-2004 demosaic (reflect-101 border of the torch port)
+//       ->  x_rgb, x_rgb - w/tau  ->  planar and/or pixel-unshuffled c8 denoiser input.
+// post: denoised RGB (planar, or FFDNet tail in c8 before pixel-shuffle) -> theta at the CFA sites,
+//       clip, dual updates b and w, optional SSE partials.
+// One thread = one Bayer quad (2x2 mosaic pixels) of one frame; consecutive lanes = consecutive n,
+// so every plane access is a coalesced row segment.  Built with -ffp-contract=off; the 5x5
+// correlations use explicit fmaf chains in row-major tap order.
+#include "common.hpp"
+
+namespace scipnp {
+
+// 5x5 tap tables, already divided by 8 (reference malvar2004.py:174-208).  Row-major, ky then kx.
+__device__ constexpr float K_G[25] = {0, 0, -0.125f, 0, 0, 0, 0, 0.25f, 0, 0, -0.125f, 0.25f, 0.5f, 0.25f, -0.125f,
+                                       0, 0, 0.25f, 0, 0, 0, 0, -0.125f, 0, 0};
+__device__ constexpr float K_ROW[25] = {0, 0, 0.0625f, 0, 0, 0, -0.125f, 0, -0.125f, 0, -0.125f, 0.5f, 0.625f, 0.5f, -0.125f,
+                                         0, -0.125f, 0, -0.125f, 0, 0, 0, 0.0625f, 0, 0};
+__device__ constexpr float K_DIAG[25] = {0, 0, -0.1875f, 0, 0, 0, 0.25f, 0, 0.25f, 0, -0.1875f, 0, 0.75f, 0, -0.1875f,
+                                          0, 0.25f, 0, 0.25f, 0, 0, 0, -0.1875f, 0, 0};
+
+// v is the 6x6 mosaic window whose element [2][2] is the quad's (dy=0,dx=0) pixel
+template <int OY, int OX, bool TRANSPOSE>
+__device__ __forceinline__ float corr5(const float (&v)[6][6], const float (&k)[25]) {
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float tap = TRANSPOSE ? k[kx * 5 + ky] : k[ky * 5 + kx];
+            if (tap != 0.f) acc = fmaf(tap, v[OY + ky][OX + kx], acc);
+        }
+    return acc;
+}
+
+// reflect-101 index of mosaic row/col `r` (may be -2..-1 or H..H+1) expressed in plane space:
+// parity is preserved, so plane dy stays and only the plane row changes.
+__device__ __forceinline__ int reflect_plane(int mm, int d, int M) {
+    // mosaic index r = 2*mm + d
+    int r = 2 * mm + d;
+    const int H = 2 * M;
+    if (r < 0) r = -r;
+    if (r >= H) r = 2 * (H - 1) - r;
+    return r >> 1;  // r keeps parity d
+}
+
+__global__ void __launch_bounds__(256)
+pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                      const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
+                      float* __restrict__ net_in, int M, int N, int B, float inv_rho, float inv_tau,
+                      float sigma) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    const int t = blockIdx.z;
+    if (n >= N) return;
+    const size_t plane = (size_t)M * N;
+    const float* xt = x + (size_t)t * 4 * plane;
+    const float* bt = b ? b + (size_t)t * 4 * plane : nullptr;
+    float v[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d_y = i & 1;                 // window row i <-> mosaic row 2m-2+i: parity = i&1
+        const int mm = reflect_plane(m - 1 + (i >> 1), d_y, M);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int d_x = j & 1;
+            const int nn = reflect_plane(n - 1 + (j >> 1), d_x, N);
+            const size_t o = (size_t)(d_y * 2 + d_x) * plane + (size_t)mm * N + nn;
+            v[i][j] = bt ? (xt[o] + inv_rho * bt[o]) : xt[o];
+        }
+    }
+    // rgb[c][dy][dx]
+    float rgb[3][2][2];
+    // R site (0,0)
+    rgb[0][0][0] = v[2][2];
+    rgb[1][0][0] = corr5<0, 0, false>(v, K_G);
+    rgb[2][0][0] = corr5<0, 0, false>(v, K_DIAG);
+    // G1 site (0,1): red row, blue column
+    rgb[0][0][1] = corr5<0, 1, false>(v, K_ROW);
+    rgb[1][0][1] = v[2][3];
+    rgb[2][0][1] = corr5<0, 1, true>(v, K_ROW);
+    // G2 site (1,0): blue row, red column
+    rgb[0][1][0] = corr5<1, 0, true>(v, K_ROW);
+    rgb[1][1][0] = v[3][2];
+    rgb[2][1][0] = corr5<1, 0, false>(v, K_ROW);
+    // B site (1,1)
+    rgb[0][1][1] = corr5<1, 1, false>(v, K_DIAG);
+    rgb[1][1][1] = corr5<1, 1, false>(v, K_G);
+    rgb[2][1][1] = v[3][3];
+
+    const int W = 2 * N;
+    const size_t HW = 4 * plane;
+    float in[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const size_t o = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
+            *(float2*)(x_rgb + o) = make_float2(rgb[c][dy][0], rgb[c][dy][1]);
+            float2 wv = make_float2(0.f, 0.f);
+            if (w) wv = *(const float2*)(w + o);
+            in[c][dy][0] = w ? (rgb[c][dy][0] - inv_tau * wv.x) : rgb[c][dy][0];
+            in[c][dy][1] = w ? (rgb[c][dy][1] - inv_tau * wv.y) : rgb[c][dy][1];
+            if (rgb_w) *(float2*)(rgb_w + o) = make_float2(in[c][dy][0], in[c][dy][1]);
+        }
+    if (net_in) {
+        // c8 layout [t][2][M][N][8]; channel = c*4 + dy*2 + dx; 12 = sigma; 13..15 = 0
+        float4* dst0 = (float4*)(net_in + (((size_t)t * 2 + 0) * plane + (size_t)m * N + n) * 8);
+        float4* dst1 = (float4*)(net_in + (((size_t)t * 2 + 1) * plane + (size_t)m * N + n) * 8);
+        dst0[0] = make_float4(in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1]);
+        dst0[1] = make_float4(in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]);
+        dst1[0] = make_float4(in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1]);
+        dst1[1] = make_float4(sigma, 0.f, 0.f, 0.f);
+    }
+}
+
+constexpr int POST_THREADS = 256;
+
+__global__ void __launch_bounds__(POST_THREADS)
+pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restrict__ out_c8,
+                       float* __restrict__ out_store, float* __restrict__ x,
+                       const float* __restrict__ x_rgb, float* __restrict__ theta, float* __restrict__ b,
+                       float* __restrict__ w, const float* __restrict__ orig, double* sse_part,
+                       int first_iter_alias, int M, int N, int B) {
+    __shared__ double red[16];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    const int t = blockIdx.z;
+    double acc = 0.0;
+    if (n < N) {
+        const size_t plane = (size_t)M * N;
+        const int W = 2 * N;
+        const size_t HW = 4 * plane;
+        float o[3][2][2];
+        if (out_c8) {
+            const float4* s0 = (const float4*)(out_c8 + (((size_t)t * 2 + 0) * plane + (size_t)m * N + n) * 8);
+            const float4* s1 = (const float4*)(out_c8 + (((size_t)t * 2 + 1) * plane + (size_t)m * N + n) * 8);
+            const float4 r = s0[0], g = s0[1], bl = s1[0];
+            o[0][0][0] = r.x; o[0][0][1] = r.y; o[0][1][0] = r.z; o[0][1][1] = r.w;
+            o[1][0][0] = g.x; o[1][0][1] = g.y; o[1][1][0] = g.z; o[1][1][1] = g.w;
+            o[2][0][0] = bl.x; o[2][0][1] = bl.y; o[2][1][0] = bl.z; o[2][1][1] = bl.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const float2 q = *(const float2*)(out_rgb + ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n);
+                    o[c][dy][0] = q.x; o[c][dy][1] = q.y;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const size_t off = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
+                if (out_store) *(float2*)(out_store + off) = make_float2(o[c][dy][0], o[c][dy][1]);
+                if (w) {
+                    const float2 xr = *(const float2*)(x_rgb + off);
+                    float2 wv = *(float2*)(w + off);
+                    wv.x = wv.x + (xr.x - o[c][dy][0]);
+                    wv.y = wv.y + (xr.y - o[c][dy][1]);
+                    *(float2*)(w + off) = wv;
+                }
+            }
+        // CFA sites: R (0,0), G1 (0,1), G2 (1,0), B (1,1)   -- dvp...:206-209
+        const float raw[4] = {o[0][0][0], o[1][0][1], o[1][1][0], o[2][1][1]};
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const size_t off = ((size_t)t * 4 + ib) * plane + (size_t)m * N + n;
+            const float th = fminf(fmaxf(raw[ib], 0.f), 1.f);
+            float xe;
+            if (first_iter_alias) { xe = raw[ib]; x[off] = xe; }   // x IS theta in the reference's first iteration
+            else xe = x[off];
+            b[off] = b[off] + (xe - th);
+            theta[off] = th;
+            if (sse_part) {
+                const float e = orig[off] - th;
+                acc += (double)(e * e);
+            }
+        }
+    }
+    if (sse_part) {
+        const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+        if (threadIdx.x == 0)
+            sse_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+int scipnp_pm_pre_denoise(const float* x, const float* b, const float* w, float* x_rgb, float* rgb_w,
+                          float* net_in_c8, int M, int N, int B, float inv_rho, float inv_tau, float sigma,
+                          scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && x_rgb, "null pointer");
+    SCIPNP_REQUIRE(M >= 2 && N >= 2 && B > 0 && B <= 65535 && M <= 65535, "bad shape M=%d N=%d B=%d", M, N, B);
+    SCIPNP_ALIGNED(x_rgb);
+    if (w) SCIPNP_ALIGNED(w);
+    if (rgb_w) SCIPNP_ALIGNED(rgb_w);
+    if (net_in_c8) SCIPNP_ALIGNED(net_in_c8);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, x_rgb, rgb_w,
+                       net_in_c8, M, N, B, inv_rho, inv_tau, sigma);
+    return launch_status("pm_pre_denoise_kernel");
+}
+
+int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out_rgb_store, float* x,
+                           const float* x_rgb, float* theta, float* b, float* w, const float* orig,
+                           double* sse_part, int first_iter_alias, int M, int N, int B, int* nblocks,
+                           scipnp_stream_t s) {
+    SCIPNP_REQUIRE((out_rgb != nullptr) != (out_c8 != nullptr), "exactly one of out_rgb / out_c8 must be given");
+    SCIPNP_REQUIRE(x && theta && b, "null pointer");
+    SCIPNP_REQUIRE((w == nullptr) || (x_rgb != nullptr), "w update needs x_rgb");
+    SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
+    SCIPNP_REQUIRE(M >= 1 && N >= 1 && B > 0 && B <= 65535 && M <= 65535, "bad shape");
+    if (out_c8) SCIPNP_ALIGNED(out_c8);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    if (nblocks) *nblocks = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(pm_post_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, out_rgb, out_c8,
+                       out_rgb_store, x, x_rgb, theta, b, w, orig, sse_part, first_iter_alias, M, N, B);
+    return launch_status("pm_post_denoise_kernel");
+}
+
+}  // extern "C"

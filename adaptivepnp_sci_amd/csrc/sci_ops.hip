@@ -1,0 +1,512 @@
+// SCI forward / transpose operators, Euclidean projections, Bayer layout conversions, dual
+// updates and the SSE reduction.  All HBM-bound streaming kernels: one pass, 16-byte lanes where
+// the layout allows, no intermediate tensors.  Built with -ffp-contract=off so that every
+// multiply and add rounds separately, exactly like the reference's op-by-op PyTorch expressions.
+#include "common.hpp"
+
+namespace scipnp {
+
+// ===================================================================== reference layout (M,N,B,4)
+// One thread owns the four Bayer planes of one (quad, frame): a float4.  The B frames of a quad are
+// B consecutive lanes, so for B = 8 a quad is one 128-byte line and Sigma_t is a wavefront shuffle.
+
+template <int LOGB>
+__device__ __forceinline__ float4 frame_sum_shuffle(float4 v, int lane) {
+    // every lane of a quad's group receives the torch-order sum over the group's B frames
+    constexpr int B = 1 << LOGB;
+    const int base = lane & ~(B - 1);
+    float4 r;
+    float* rp = &r.x;
+    const float* vp = &v.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mine = vp[c];
+        rp[c] = torch_order_sum<B>(B, [&](int i) { return __shfl(mine, base + i, WAVE); });
+    }
+    return r;
+}
+
+template <int LOGB, int MODE>  // MODE 0 two-stage, 1 one-stage, 2 = A only, 3 = At only, 4 = Phi_sum
+__global__ void __launch_bounds__(256)
+ref_layout_kernel(const float4* __restrict__ theta, const float4* __restrict__ bb,
+                  const float4* __restrict__ Phi, const float4* __restrict__ y,
+                  const float4* __restrict__ Phisum, float4* xout, float4* yout,
+                  long long nquad, float c0, float c1) {
+    constexpr int B = 1 << LOGB;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // = quad*B + t
+    const long long total = nquad * B;
+    const bool live = gid < total;
+    const long long idx = live ? gid : (total - 1);  // keep whole waves converged for the shuffles
+    const long long quad = idx >> LOGB;
+    const int lane = threadIdx.x & 63;
+    const float4 ph = Phi[idx];
+    if (MODE == 4) {
+        float4 s = frame_sum_shuffle<LOGB>(ph, lane);
+        s.x = (s.x == 0.f) ? 1.f : s.x;
+        s.y = (s.y == 0.f) ? 1.f : s.y;
+        s.z = (s.z == 0.f) ? 1.f : s.z;
+        s.w = (s.w == 0.f) ? 1.f : s.w;
+        if (live && (idx & (B - 1)) == 0) yout[quad] = s;
+        return;
+    }
+    if (MODE == 3) {
+        const float4 yy = y[quad];
+        if (live) xout[idx] = make_float4(yy.x * ph.x, yy.y * ph.y, yy.z * ph.z, yy.w * ph.w);
+        return;
+    }
+    const float4 th = theta[idx];
+    if (MODE == 2) {
+        float4 pr = make_float4(th.x * ph.x, th.y * ph.y, th.z * ph.z, th.w * ph.w);
+        float4 s = frame_sum_shuffle<LOGB>(pr, lane);
+        if (live && (idx & (B - 1)) == 0) yout[quad] = s;
+        return;
+    }
+    const float4 bv = bb[idx];
+    float4 p;
+    if (MODE == 0) {
+        p = make_float4(th.x - c0 * bv.x, th.y - c0 * bv.y, th.z - c0 * bv.z, th.w - c0 * bv.w);
+    } else {
+        p = make_float4(th.x + bv.x, th.y + bv.y, th.z + bv.z, th.w + bv.w);
+    }
+    float4 pr = make_float4(p.x * ph.x, p.y * ph.y, p.z * ph.z, p.w * ph.w);
+    const float4 yb = frame_sum_shuffle<LOGB>(pr, lane);
+    const float4 yy = y[quad];
+    const float4 ps = Phisum[quad];
+    float4 r;
+    if (MODE == 0) {
+        r = make_float4((yy.x - yb.x) / (c1 + ps.x), (yy.y - yb.y) / (c1 + ps.y),
+                        (yy.z - yb.z) / (c1 + ps.z), (yy.w - yb.w) / (c1 + ps.w));
+        r = make_float4(p.x + ph.x * r.x, p.y + ph.y * r.y, p.z + ph.z * r.z, p.w + ph.w * r.w);
+    } else {
+        r = make_float4((yy.x - yb.x) / (ps.x + c1), (yy.y - yb.y) / (ps.y + c1),
+                        (yy.z - yb.z) / (ps.z + c1), (yy.w - yb.w) / (ps.w + c1));
+        r = make_float4(p.x + c0 * (r.x * ph.x), p.y + c0 * (r.y * ph.y),
+                        p.z + c0 * (r.z * ph.z), p.w + c0 * (r.w * ph.w));
+    }
+    if (live) xout[idx] = r;
+}
+
+template <int MODE>
+static int launch_ref_layout(const float* theta, const float* b, const float* Phi, const float* y,
+                             const float* Phisum, float* xout, float* yout, int M, int N, int B,
+                             float c0, float c1, hipStream_t st) {
+    SCIPNP_REQUIRE(M > 0 && N > 0, "M,N must be positive (got %d,%d)", M, N);
+    SCIPNP_REQUIRE(B == 1 || B == 2 || B == 4 || B == 8 || B == 16,
+                   "reference-layout kernels need B in {1,2,4,8,16} (got %d); use the plane-major entry", B);
+    const long long nquad = (long long)M * N;
+    const long long total = nquad * B;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+#define SCIPNP_GO(LB)                                                                              \
+    hipLaunchKernelGGL((ref_layout_kernel<LB, MODE>), dim3(blocks), dim3(threads), 0, st,           \
+                       (const float4*)theta, (const float4*)b, (const float4*)Phi, (const float4*)y, \
+                       (const float4*)Phisum, (float4*)xout, (float4*)yout, nquad, c0, c1)
+    switch (B) {
+        case 1: SCIPNP_GO(0); break;
+        case 2: SCIPNP_GO(1); break;
+        case 4: SCIPNP_GO(2); break;
+        case 8: SCIPNP_GO(3); break;
+        default: SCIPNP_GO(4); break;
+    }
+#undef SCIPNP_GO
+    return launch_status("ref_layout_kernel");
+}
+
+// mosaic (H,W,B) <-> planes (M,N,B,4): thread = (quad, frame); the B frames of a mosaic pixel are
+// contiguous, so each of the four plane values is a 4*B-byte coalesced run per quad.
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+bayer_reorder_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int N, int B) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)M * N * B;
+    if (gid >= total) return;
+    const int t = (int)(gid % B);
+    const long long quad = gid / B;
+    const int n = (int)(quad % N), m = (int)(quad / N);
+    const long long W = 2LL * N;
+    const long long r0 = ((2LL * m) * W + 2LL * n) * B + t;
+    const long long r1 = r0 + W * B;
+    float4* pl = (float4*)(SPLIT ? dst : const_cast<float*>(src));
+    if (SPLIT) {
+        pl[gid] = make_float4(src[r0], src[r0 + B], src[r1], src[r1 + B]);
+    } else {
+        const float4 v = pl[gid];
+        dst[r0] = v.x; dst[r0 + B] = v.y; dst[r1] = v.z; dst[r1 + B] = v.w;
+    }
+}
+
+// ===================================================================== plane-major conversions
+// state[t][ib][m][n] <-> mosaic[(2m+dy)][(2n+dx)][t].  Tiled through LDS so that both sides move
+// whole lines: a block handles one mosaic row pair (2 rows) x 32 quads x all B frames.
+constexpr int CONV_TQ = 32;
+
+template <bool TO_STATE>
+__global__ void __launch_bounds__(256)
+state_mosaic_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int N, int B) {
+    extern __shared__ float tile[];  // [2 rows][CONV_TQ*2 px][B+1]
+    const int m = blockIdx.y;
+    const int n0 = blockIdx.x * CONV_TQ;
+    const int nq = min(CONV_TQ, N - n0);
+    const int W = 2 * N;
+    const int pitch = B + 1;
+    const int per_row = 2 * nq * B;  // floats of one mosaic row segment
+    const size_t plane = (size_t)M * N;
+    if (TO_STATE) {
+        for (int i = threadIdx.x; i < 2 * per_row; i += blockDim.x) {
+            const int dy = i / per_row, j = i % per_row;
+            const int px = j / B, t = j % B;
+            tile[(dy * 2 * CONV_TQ + px) * pitch + t] =
+                src[((size_t)(2 * m + dy) * W + 2 * n0) * B + j];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < B * 4 * nq; i += blockDim.x) {
+            const int q = i % nq, ib = (i / nq) & 3, t = i / (4 * nq);
+            const int dy = ib >> 1, dx = ib & 1;
+            dst[((size_t)t * 4 + ib) * plane + (size_t)m * N + n0 + q] =
+                tile[(dy * 2 * CONV_TQ + 2 * q + dx) * pitch + t];
+        }
+    } else {
+        for (int i = threadIdx.x; i < B * 4 * nq; i += blockDim.x) {
+            const int q = i % nq, ib = (i / nq) & 3, t = i / (4 * nq);
+            const int dy = ib >> 1, dx = ib & 1;
+            tile[(dy * 2 * CONV_TQ + 2 * q + dx) * pitch + t] =
+                src[((size_t)t * 4 + ib) * plane + (size_t)m * N + n0 + q];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * per_row; i += blockDim.x) {
+            const int dy = i / per_row, j = i % per_row;
+            const int px = j / B, t = j % B;
+            dst[((size_t)(2 * m + dy) * W + 2 * n0) * B + j] = tile[(dy * 2 * CONV_TQ + px) * pitch + t];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+y_to_meas_kernel(const float* __restrict__ y, float* __restrict__ meas, int M, int N) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = 4LL * M * N;
+    if (gid >= total) return;
+    const int n = (int)(gid % N);
+    const int m = (int)((gid / N) % M);
+    const int ib = (int)(gid / ((long long)M * N));
+    meas[gid] = y[(size_t)(2 * m + (ib >> 1)) * (2 * N) + 2 * n + (ib & 1)];
+}
+
+// planar rgb [B][3][H][W] <-> cube (H,W,3,B): block = one image row x 64 columns, through LDS
+template <bool TO_CUBE>
+__global__ void __launch_bounds__(256)
+rgb_cube_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int B) {
+    extern __shared__ float tile[];  // [64 px][3*B + 1]
+    const int r = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int nc = min(64, W - c0);
+    const int CB = 3 * B, pitch = CB + 1;
+    const size_t HW = (size_t)H * W;
+    if (TO_CUBE) {
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
+            const int px = i % nc, ch_t = i / nc;  // ch_t = t*3 + c in the planar source order
+            const int t = ch_t / 3, c = ch_t % 3;
+            tile[px * pitch + c * B + t] = src[(size_t)ch_t * HW + (size_t)r * W + c0 + px];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x)
+            dst[((size_t)r * W + c0) * CB + i] = tile[(i / CB) * pitch + (i % CB)];
+    } else {
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x)
+            tile[(i / CB) * pitch + (i % CB)] = src[((size_t)r * W + c0) * CB + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
+            const int px = i % nc, ch_t = i / nc;
+            const int t = ch_t / 3, c = ch_t % 3;
+            dst[(size_t)ch_t * HW + (size_t)r * W + c0 + px] = tile[px * pitch + c * B + t];
+        }
+    }
+}
+
+// ===================================================================== plane-major projection
+// state[t][q], q in [0, Q = 4MN); meas[q].  One thread = VEC consecutive pixels, all B frames in
+// registers (MAXB template) -> theta, b, Phi are each read exactly once, x written once:
+// 16 B per (pixel,frame) + 8 B per pixel of measurement = the algorithmic minimum.
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC, int MAXB, int MODE>  // MODE 0 two-stage, 1 one-stage, 2 setup (Phi_sum, x0 = y*Phi)
+__global__ void __launch_bounds__(256)
+pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
+                  const float* __restrict__ Phi, const float* __restrict__ y,
+                  const float* Phisum_in, float* Phisum_out, float* xout,
+                  long long Q, int B, float c0, float c1) {
+    using V = typename VecT<VEC>::type;
+    const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (q >= Q) return;
+    float p[MAXB][VEC], ph[MAXB][VEC];
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        if (t < B) {
+            const size_t o = (size_t)t * Q + q;
+            V phv = *(const V*)(Phi + o);
+            const float* php = (const float*)&phv;
+            if (MODE == 2) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { ph[t][v] = php[v]; p[t][v] = php[v]; }
+            } else {
+                V thv = *(const V*)(theta + o);
+                V bv = *(const V*)(bb + o);
+                const float* thp = (const float*)&thv;
+                const float* bp = (const float*)&bv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    ph[t][v] = php[v];
+                    p[t][v] = (MODE == 0) ? (thp[v] - c0 * bp[v]) : (thp[v] + bp[v]);
+                }
+            }
+        }
+    }
+    V yv = *(const V*)(y + q);
+    const float* yp = (const float*)&yv;
+    float r[VEC];
+    if (MODE == 2) {
+        V so;
+        float* sp = (float*)&so;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float s = torch_order_sum<MAXB>(B, [&](int i) { return ph[i][v]; });
+            s = (s == 0.f) ? 1.f : s;
+            sp[v] = s;
+            r[v] = yp[v];
+        }
+        *(V*)(Phisum_out + q) = so;
+        if (xout == nullptr) return;
+    } else {
+        V sv = *(const V*)(Phisum_in + q);
+        const float* sp = (const float*)&sv;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float yb = torch_order_sum<MAXB>(B, [&](int i) { return p[i][v] * ph[i][v]; });
+            r[v] = (MODE == 0) ? (yp[v] - yb) / (c1 + sp[v]) : (yp[v] - yb) / (sp[v] + c1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        if (t < B) {
+            V ov;
+            float* op = (float*)&ov;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (MODE == 0) op[v] = p[t][v] + ph[t][v] * r[v];
+                else if (MODE == 1) op[v] = p[t][v] + c0 * (r[v] * ph[t][v]);
+                else op[v] = r[v] * ph[t][v];
+            }
+            *(V*)(xout + (size_t)t * Q + q) = ov;
+        }
+    }
+}
+
+template <int MODE>
+static int launch_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
+                             const float* Phisum_in, float* Phisum_out, float* x, int M, int N, int B,
+                             float c0, float c1, hipStream_t st) {
+    SCIPNP_REQUIRE(M > 0 && N > 0 && B > 0 && B <= 32, "bad shape M=%d N=%d B=%d (B <= 32)", M, N, B);
+    const long long Q = 4LL * M * N;
+    const bool vec = (Q % 4 == 0) && aligned16(Phi) && aligned16(y) && aligned16(x) &&
+                     (MODE == 2 ? aligned16(Phisum_out) : (aligned16(theta) && aligned16(b) && aligned16(Phisum_in)));
+    const int threads = 256;
+#define SCIPNP_GO(VEC, MAXB)                                                                        \
+    hipLaunchKernelGGL((pm_project_kernel<VEC, MAXB, MODE>),                                         \
+                       dim3((unsigned)((Q / VEC + threads - 1) / threads)), dim3(threads), 0, st,    \
+                       theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1)
+    if (vec && B <= 8) SCIPNP_GO(4, 8);
+    else if (vec && B <= 16) SCIPNP_GO(4, 16);
+    else if (B <= 8) SCIPNP_GO(1, 8);
+    else SCIPNP_GO(1, 32);
+#undef SCIPNP_GO
+    return launch_status("pm_project_kernel");
+}
+
+// ===================================================================== dual update (+ SSE partials)
+constexpr int RED_THREADS = 256;
+constexpr int RED_PER_THREAD = 8;
+
+__global__ void __launch_bounds__(RED_THREADS)
+pm_dual_update_kernel(const float* __restrict__ theta_raw, const float* __restrict__ x,
+                      float* theta, float* b, const float* __restrict__ orig, double* sse_part,
+                      int which, float sign, long long total) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    const long long base = (long long)blockIdx.x * (RED_THREADS * RED_PER_THREAD);
+#pragma unroll
+    for (int k = 0; k < RED_PER_THREAD; ++k) {
+        const long long i = base + (long long)k * RED_THREADS + threadIdx.x;
+        if (i < total) {
+            const float raw = theta_raw[i];
+            const float xv = x[i];
+            const float th = fminf(fmaxf(raw, 0.f), 1.f);
+            const float d = xv - th;
+            b[i] = (sign > 0.f) ? (b[i] + d) : (b[i] - d);
+            theta[i] = th;
+            if (sse_part) {
+                const float e = orig[i] - (which == 0 ? th : xv);
+                acc += (double)(e * e);
+            }
+        }
+    }
+    if (sse_part) {
+        const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+        if (threadIdx.x == 0) sse_part[blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(RED_THREADS)
+sse_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, double* part) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    const size_t base = (size_t)blockIdx.x * (RED_THREADS * RED_PER_THREAD);
+#pragma unroll
+    for (int k = 0; k < RED_PER_THREAD; ++k) {
+        const size_t i = base + (size_t)k * RED_THREADS + threadIdx.x;
+        if (i < n) {
+            const float e = a[i] - b[i];
+            acc += (double)(e * e);
+        }
+    }
+    const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+int scipnp_A(const float* x, const float* Phi, float* y, int M, int N, int B, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && Phi && y, "null pointer");
+    SCIPNP_ALIGNED(x); SCIPNP_ALIGNED(Phi); SCIPNP_ALIGNED(y);
+    return launch_ref_layout<2>(x, nullptr, Phi, nullptr, nullptr, nullptr, y, M, N, B, 0.f, 0.f, (hipStream_t)s);
+}
+
+int scipnp_At(const float* y, const float* Phi, float* x, int M, int N, int B, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && Phi && y, "null pointer");
+    SCIPNP_ALIGNED(x); SCIPNP_ALIGNED(Phi); SCIPNP_ALIGNED(y);
+    return launch_ref_layout<3>(nullptr, nullptr, Phi, y, nullptr, x, nullptr, M, N, B, 0.f, 0.f, (hipStream_t)s);
+}
+
+int scipnp_phisum(const float* Phi, float* Phisum, int M, int N, int B, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(Phi && Phisum, "null pointer");
+    SCIPNP_ALIGNED(Phi); SCIPNP_ALIGNED(Phisum);
+    return launch_ref_layout<4>(nullptr, nullptr, Phi, nullptr, nullptr, nullptr, Phisum, M, N, B, 0.f, 0.f, (hipStream_t)s);
+}
+
+int scipnp_proj_twostage(const float* theta, const float* b, const float* Phi, const float* y,
+                         const float* Phisum, float* x, int M, int N, int B, float inv_rho,
+                         float alpha_rho, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(theta && b && Phi && y && Phisum && x, "null pointer");
+    SCIPNP_ALIGNED(theta); SCIPNP_ALIGNED(b); SCIPNP_ALIGNED(Phi); SCIPNP_ALIGNED(y); SCIPNP_ALIGNED(Phisum); SCIPNP_ALIGNED(x);
+    return launch_ref_layout<0>(theta, b, Phi, y, Phisum, x, nullptr, M, N, B, inv_rho, alpha_rho, (hipStream_t)s);
+}
+
+int scipnp_proj_onestage(const float* theta, const float* b, const float* Phi, const float* y,
+                         const float* Phisum, float* x, int M, int N, int B, float lambda, float gamma,
+                         scipnp_stream_t s) {
+    SCIPNP_REQUIRE(theta && b && Phi && y && Phisum && x, "null pointer");
+    SCIPNP_ALIGNED(theta); SCIPNP_ALIGNED(b); SCIPNP_ALIGNED(Phi); SCIPNP_ALIGNED(y); SCIPNP_ALIGNED(Phisum); SCIPNP_ALIGNED(x);
+    return launch_ref_layout<1>(theta, b, Phi, y, Phisum, x, nullptr, M, N, B, lambda, gamma, (hipStream_t)s);
+}
+
+static int bayer_reorder(const float* src, float* dst, int M, int N, int B, bool split, hipStream_t st) {
+    SCIPNP_REQUIRE(src && dst && M > 0 && N > 0 && B > 0, "bad arguments");
+    SCIPNP_ALIGNED(split ? dst : src);
+    const long long total = (long long)M * N * B;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (split) hipLaunchKernelGGL(bayer_reorder_kernel<true>, dim3(blocks), dim3(256), 0, st, src, dst, M, N, B);
+    else hipLaunchKernelGGL(bayer_reorder_kernel<false>, dim3(blocks), dim3(256), 0, st, src, dst, M, N, B);
+    return launch_status("bayer_reorder_kernel");
+}
+
+int scipnp_bayer_split(const float* mosaic, float* planes, int M, int N, int B, scipnp_stream_t s) {
+    return bayer_reorder(mosaic, planes, M, N, B, true, (hipStream_t)s);
+}
+int scipnp_bayer_merge(const float* planes, float* mosaic, int M, int N, int B, scipnp_stream_t s) {
+    return bayer_reorder(planes, mosaic, M, N, B, false, (hipStream_t)s);
+}
+
+static int state_mosaic(const float* src, float* dst, int M, int N, int B, bool to_state, hipStream_t st) {
+    SCIPNP_REQUIRE(src && dst && M > 0 && N > 0 && B > 0 && B <= 64, "bad arguments (B <= 64)");
+    const dim3 grid((N + CONV_TQ - 1) / CONV_TQ, M);
+    const size_t lds = (size_t)2 * 2 * CONV_TQ * (B + 1) * sizeof(float);
+    if (to_state) hipLaunchKernelGGL(state_mosaic_kernel<true>, grid, dim3(256), lds, st, src, dst, M, N, B);
+    else hipLaunchKernelGGL(state_mosaic_kernel<false>, grid, dim3(256), lds, st, src, dst, M, N, B);
+    return launch_status("state_mosaic_kernel");
+}
+
+int scipnp_mosaic_to_state(const float* mosaic, float* state, int M, int N, int B, scipnp_stream_t s) {
+    return state_mosaic(mosaic, state, M, N, B, true, (hipStream_t)s);
+}
+int scipnp_state_to_mosaic(const float* state, float* mosaic, int M, int N, int B, scipnp_stream_t s) {
+    return state_mosaic(state, mosaic, M, N, B, false, (hipStream_t)s);
+}
+
+int scipnp_y_to_meas(const float* y, float* meas, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(y && meas && M > 0 && N > 0, "bad arguments");
+    const long long total = 4LL * M * N;
+    hipLaunchKernelGGL(y_to_meas_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, meas, M, N);
+    return launch_status("y_to_meas_kernel");
+}
+
+static int rgb_cube(const float* src, float* dst, int H, int W, int B, bool to_cube, hipStream_t st) {
+    SCIPNP_REQUIRE(src && dst && H > 0 && W > 0 && B > 0 && B <= 64, "bad arguments (B <= 64)");
+    const dim3 grid((W + 63) / 64, H);
+    const size_t lds = (size_t)64 * (3 * B + 1) * sizeof(float);
+    if (to_cube) hipLaunchKernelGGL(rgb_cube_kernel<true>, grid, dim3(256), lds, st, src, dst, H, W, B);
+    else hipLaunchKernelGGL(rgb_cube_kernel<false>, grid, dim3(256), lds, st, src, dst, H, W, B);
+    return launch_status("rgb_cube_kernel");
+}
+int scipnp_rgb_to_cube(const float* rgb, float* cube, int H, int W, int B, scipnp_stream_t s) {
+    return rgb_cube(rgb, cube, H, W, B, true, (hipStream_t)s);
+}
+int scipnp_cube_to_rgb(const float* cube, float* rgb, int H, int W, int B, scipnp_stream_t s) {
+    return rgb_cube(cube, rgb, H, W, B, false, (hipStream_t)s);
+}
+
+int scipnp_pm_setup(const float* Phi, const float* y, float* Phisum, float* x0, int M, int N, int B,
+                    scipnp_stream_t s) {
+    SCIPNP_REQUIRE(Phi && y && Phisum, "null pointer");
+    return launch_pm_project<2>(nullptr, nullptr, Phi, y, nullptr, Phisum, x0, M, N, B, 0.f, 0.f, (hipStream_t)s);
+}
+
+int scipnp_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
+                      const float* Phisum, float* x, int M, int N, int B, int mode, float c0, float c1,
+                      scipnp_stream_t s) {
+    SCIPNP_REQUIRE(theta && b && Phi && y && Phisum && x, "null pointer");
+    SCIPNP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (two-stage) or 1 (one-stage)");
+    if (mode == 0) return launch_pm_project<0>(theta, b, Phi, y, Phisum, nullptr, x, M, N, B, c0, c1, (hipStream_t)s);
+    return launch_pm_project<1>(theta, b, Phi, y, Phisum, nullptr, x, M, N, B, c0, c1, (hipStream_t)s);
+}
+
+int scipnp_pm_dual_update(const float* theta_raw, const float* x, float* theta, float* b,
+                          const float* orig, double* sse_part, int which, float sign, int M, int N, int B,
+                          int* nblocks, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(theta_raw && x && theta && b, "null pointer");
+    SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
+    const long long total = 4LL * M * N * B;
+    const int per = RED_THREADS * RED_PER_THREAD;
+    const unsigned blocks = (unsigned)((total + per - 1) / per);
+    if (nblocks) *nblocks = (int)blocks;
+    hipLaunchKernelGGL(pm_dual_update_kernel, dim3(blocks), dim3(RED_THREADS), 0, (hipStream_t)s, theta_raw, x,
+                       theta, b, orig, sse_part, which, sign, total);
+    return launch_status("pm_dual_update_kernel");
+}
+
+int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, int* nblocks,
+                        scipnp_stream_t s) {
+    SCIPNP_REQUIRE(a && b && nblocks, "null pointer");
+    const size_t per = (size_t)RED_THREADS * RED_PER_THREAD;
+    const unsigned blocks = (unsigned)((n + per - 1) / per);
+    *nblocks = (int)blocks;
+    if (part == nullptr) return SCIPNP_OK;  // size query
+    hipLaunchKernelGGL(sse_kernel, dim3(blocks), dim3(RED_THREADS), 0, (hipStream_t)s, a, b, n, part);
+    return launch_status("sse_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// Chambolle total-variation prior on C independent M x N channels (plane-major: every channel is
+// one contiguous image).  Replaces the reference's per-iteration device->host copy, single-thread
+// NumPy `skimage.restoration.denoise_tv_chambolle(..., n_iter_max=5, multichannel=True)` and
+// host->device copy (dvp_linear_inv_2_stage_ADMM_tensor_online.py:153-160, :403-407).
+//
+// One launch per inner iteration i (the data-dependent stop needs the global energy E_i of each
+// channel).  Kernel i first reduces the fp64 block partials that kernel i-1 left for its channel,
+// evaluates skimage's stop test for iteration i-1 exactly as the NumPy-1.x code does (two float32
+// array sums combined in double, see oracle/tv_chambolle.py) and returns if the channel has
+// stopped -- theta then already holds the `out` of the stopping iteration.  Every block of a
+// channel computes the same decision from the same numbers in the same order: deterministic, no
+// atomics, no host round trip.
+//
+// Arithmetic follows skimage operation by operation in float32 (-ffp-contract=off):
+//   d   = -(p0+p1) (+ p0[r-1,c] for r>0) (+ p1[r,c-1] for c>0);   out = v + d        (i > 0)
+//   g0  = out[r+1,c]-out[r,c] (0 on the last row),  g1 likewise;  nrm = sqrt(g0*g0+g1*g1)
+//   p  <- (p - 0.25 g) / (1 + nrm * (0.25/weight))
+#include "common.hpp"
+
+namespace scipnp {
+
+constexpr int TV_TS = 32;        // tile edge
+constexpr int TV_TY = 8;         // block = 32 x 8 threads, 4 rows per thread
+constexpr int TV_RPT = TV_TS / TV_TY;
+
+struct TvWorkspace {
+    float* p[2];        // ping-pong dual field: [2][C][M][N] each (component-major)
+    double* partial;    // [n_iter][C][nblk][2]   (sum d^2, sum nrm)
+    double* energy;     // [n_iter][C]
+    int* stopped;       // [n_iter][C]
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t tv_layout(int M, int N, int C, int n_iter, void* base, TvWorkspace* ws) {
+    const size_t img = (size_t)C * M * N;
+    const int nblk = ((M + TV_TS - 1) / TV_TS) * ((N + TV_TS - 1) / TV_TS);
+    size_t off = 0;
+    char* b = (char*)base;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return b ? b + o : nullptr; };
+    float* p0 = (float*)take(2 * img * sizeof(float));
+    float* p1 = (float*)take(2 * img * sizeof(float));
+    double* part = (double*)take((size_t)n_iter * C * nblk * 2 * sizeof(double));
+    double* en = (double*)take((size_t)n_iter * C * sizeof(double));
+    int* st = (int*)take((size_t)n_iter * C * sizeof(int));
+    if (ws) { ws->p[0] = p0; ws->p[1] = p1; ws->partial = part; ws->energy = en; ws->stopped = st; }
+    return off;
+}
+
+__device__ __forceinline__ float tv_input(const float* __restrict__ x, const float* __restrict__ b, float coef,
+                                          size_t o) {
+    return b ? (x[o] + coef * b[o]) : x[o];
+}
+
+// `out` of the current iteration at (r,c) from the previous dual field (global memory, cache-served)
+// (x, b, p0, p1 already point at this channel's image)
+template <bool FIRST>
+__device__ __forceinline__ float tv_out_at(const float* __restrict__ x, const float* __restrict__ b, float coef,
+                                           const float* __restrict__ p0, const float* __restrict__ p1,
+                                           int r, int c, int N, float* d_out) {
+    const size_t o = (size_t)r * N + c;
+    const float v = tv_input(x, b, coef, o);
+    if (FIRST) { *d_out = 0.f; return v; }
+    float d = -(p0[o] + p1[o]);
+    if (r > 0) d = d + p0[o - N];
+    if (c > 0) d = d + p1[o - 1];
+    *d_out = d;
+    return v + d;
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(TV_TS* TV_TY)
+tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta,
+               TvWorkspace ws, int it, int M, int N, int C, double weight, float tau_over_w, double eps,
+               int32_t* stop_iter) {
+    __shared__ float s_out[TV_TS + 1][TV_TS + 1];
+    __shared__ double red[16];
+    __shared__ int s_stop;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TV_TS + tx;
+    const int c = blockIdx.z;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    const int nblk = ntx * nty;
+    const int blk = blockIdx.y * ntx + blockIdx.x;
+    const size_t img = (size_t)M * N;
+    const size_t chan = (size_t)c * img;
+
+    if (!FIRST) {
+        // ---- evaluate iteration it-1 for this channel (skimage's stop test), identically in every block
+        const double* part = ws.partial + ((size_t)(it - 1) * C + c) * nblk * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = tid; k < nblk; k += TV_TS * TV_TY) { s1 += part[2 * k]; s2 += part[2 * k + 1]; }
+        s1 = block_sum_double(s1, red, tid, TV_TS * TV_TY);
+        s2 = block_sum_double(s2, red, tid, TV_TS * TV_TY);
+        if (tid == 0) {
+            // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
+            double E = (double)(float)s1;
+            E += weight * (double)(float)s2;           // `weight` is the Python double of the reference: see host
+            E /= (double)img;
+            int stopped = 0;
+            if (it - 1 >= 1) {
+                const int was = ws.stopped[(size_t)(it - 2) * C + c];
+                const double E0 = ws.energy[c];
+                const double Eprev = ws.energy[(size_t)(it - 2) * C + c];
+                stopped = was || (fabs(Eprev - E) < eps * E0);
+                if (stopped && !was && stop_iter && blk == 0) stop_iter[c] = it - 1;
+            }
+            if (blk == 0) {
+                ws.energy[(size_t)(it - 1) * C + c] = E;
+                ws.stopped[(size_t)(it - 1) * C + c] = stopped;
+            }
+            s_stop = stopped;
+        }
+        __syncthreads();
+        if (s_stop) return;
+    } else if (stop_iter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        stop_iter[c] = -1;  // patched to n_iter_max-1 by the host wrapper's last launch (see below)
+    }
+
+    const float* p0 = ws.p[(it + 1) & 1] + chan;          // written by iteration it-1
+    const float* p1 = p0 + (size_t)C * img;
+    float* q0 = ws.p[it & 1] + chan;
+    float* q1 = q0 + (size_t)C * img;
+    const int r0 = blockIdx.y * TV_TS, c0 = blockIdx.x * TV_TS;
+    const int col = c0 + tx;
+    const float* xc = x + chan;
+    const float* bc = b ? b + chan : nullptr;
+
+    float dloc[TV_RPT];
+#pragma unroll
+    for (int k = 0; k < TV_RPT; ++k) {
+        const int lr = ty * TV_RPT + k, r = r0 + lr;
+        dloc[k] = 0.f;
+        if (r < M && col < N)
+            s_out[lr][tx] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, col, N, &dloc[k]);
+    }
+    // right halo column (tx == 0 threads of each row group) and bottom halo row (ty == 0 row)
+    float dummy;
+    if (tx < TV_RPT) {
+        const int lr = ty * TV_RPT + tx, r = r0 + lr, cc = c0 + TV_TS;
+        if (r < M && cc < N) s_out[lr][TV_TS] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, cc, N, &dummy);
+    }
+    if (ty == TV_TY - 1) {
+        const int r = r0 + TV_TS;
+        if (r < M && col < N) s_out[TV_TS][tx] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, col, N, &dummy);
+    }
+    __syncthreads();
+
+    double acc1 = 0.0, acc2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < TV_RPT; ++k) {
+        const int lr = ty * TV_RPT + k, r = r0 + lr;
+        if (r < M && col < N) {
+            const size_t o = (size_t)r * N + col;
+            const float out = s_out[lr][tx];
+            const float g0 = (r < M - 1) ? (s_out[lr + 1][tx] - out) : 0.f;
+            const float g1 = (col < N - 1) ? (s_out[lr][tx + 1] - out) : 0.f;
+            float nrm = sqrtf(g0 * g0 + g1 * g1);
+            acc1 += (double)(dloc[k] * dloc[k]);
+            acc2 += (double)nrm;
+            nrm = nrm * tau_over_w;
+            nrm = nrm + 1.f;
+            const float pp0 = FIRST ? 0.f : p0[o];
+            const float pp1 = FIRST ? 0.f : p1[o];
+            q0[o] = (pp0 - 0.25f * g0) / nrm;
+            q1[o] = (pp1 - 0.25f * g1) / nrm;
+            theta[chan + o] = out;
+        }
+    }
+    acc1 = block_sum_double(acc1, red, tid, TV_TS * TV_TY);
+    acc2 = block_sum_double(acc2, red, tid, TV_TS * TV_TY);
+    if (tid == 0) {
+        double* part = ws.partial + (((size_t)it * C + c) * nblk + blk) * 2;
+        part[0] = acc1;
+        part[1] = acc2;
+    }
+}
+
+__global__ void tv_fill_stop_kernel(int32_t* stop_iter, int C, int last) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C && stop_iter[c] < 0) stop_iter[c] = last;
+}
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+size_t scipnp_tv_workspace_bytes(int M, int N, int C, int n_iter_max) {
+    if (M <= 0 || N <= 0 || C <= 0 || n_iter_max <= 0) return 0;
+    return tv_layout(M, N, C, n_iter_max, nullptr, nullptr);
+}
+
+int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta, int M, int N, int C,
+                        float weight, float eps, int n_iter_max, void* workspace, size_t workspace_bytes,
+                        int32_t* stop_iter, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && theta && workspace, "null pointer");
+    SCIPNP_REQUIRE(M > 0 && N > 0 && C > 0 && C <= 65535 && n_iter_max > 0, "bad shape M=%d N=%d C=%d n_iter_max=%d", M, N, C, n_iter_max);
+    SCIPNP_REQUIRE(weight > 0.f, "weight must be positive");
+    SCIPNP_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
+    TvWorkspace ws;
+    const size_t need = tv_layout(M, N, C, n_iter_max, workspace, &ws);
+    if (workspace_bytes < need) return fail(SCIPNP_EWORKSPACE, "TV workspace too small: %zu < %zu", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)s;
+    const dim3 block(TV_TS, TV_TY);
+    const dim3 grid((N + TV_TS - 1) / TV_TS, (M + TV_TS - 1) / TV_TS, C);
+    // weight and eps are Python floats (doubles) in the reference and promote its float32 sums to
+    // double; they reach this ABI as float32, so recover the double through the shortest decimal
+    // that round-trips (0.1f -> 0.1, 2e-4f -> 2e-4).
+    auto as_double = [](float f) {
+        for (int prec = 1; prec <= 9; ++prec) {
+            char buf[40];
+            double d = 0.0;
+            snprintf(buf, sizeof buf, "%.*g", prec, (double)f);
+            sscanf(buf, "%lf", &d);
+            if ((float)d == f) return d;
+        }
+        return (double)f;
+    };
+    const double eps_d = as_double(eps);
+    const double weight_d = as_double(weight);
+    const float tau_over_w = (float)(0.25 / weight_d);
+    for (int it = 0; it < n_iter_max; ++it) {
+        if (it == 0)
+            hipLaunchKernelGGL(tv_iter_kernel<true>, grid, block, 0, st, x, b, coef, theta, ws, it, M, N, C, weight_d,
+                               tau_over_w, eps_d, stop_iter);
+        else
+            hipLaunchKernelGGL(tv_iter_kernel<false>, grid, block, 0, st, x, b, coef, theta, ws, it, M, N, C, weight_d,
+                               tau_over_w, eps_d, stop_iter);
+    }
+    if (stop_iter)
+        hipLaunchKernelGGL(tv_fill_stop_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stop_iter, C, n_iter_max - 1);
+    return launch_status("tv_iter_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+"""Denoiser plug-ins with the reference's call signatures, running on the HIP kernels.
+
+ffdnet_rgb_denoise_full_tensor      <- packages/ffdnet/test_ffdnet_ipol.py:240-359
+fastdvdnet_denoiser_full_tensor_v2  <- packages/fastdvdnet/test_fastdvdnet.py:325-500
+
+Both take / return the reference's (H, W, 3, B) colour cube as a CUDA(ROCm) tensor.  The solver
+itself does not go through these wrappers (it keeps everything plane-major and fuses the layout
+changes into its pre/post kernels); they exist so that code written against the reference's
+plug-in API keeps working.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .nets import FFDNetEngine
+
+_ENGINES = {}
+
+
+def _engine_for(model, B, M, N, device):
+    key = (id(model), B, M, N, str(device))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        if len(_ENGINES) > 8:
+            _ENGINES.clear()
+        eng = _ENGINES[key] = FFDNetEngine(model, B, M, N, device)
+    else:
+        eng.refresh(model)
+    return eng
+
+
+def _unshuffle_to_c8(x, sigma):
+    """(n,3,H,W) -> c8 [n][2][H/2][W/2][8] with channel c*4+dy*2+dx, ch 12 = sigma, 13..15 = 0
+    (reference network_ffdnet.py:54-64; layout plumbing only, the arithmetic is in the HIP convs)."""
+    n, c, H, W = x.shape
+    x = F.pad(x, (0, W % 2, 0, H % 2), mode='replicate')
+    h, w = x.shape[-2] // 2, x.shape[-1] // 2
+    u = x.reshape(n, c, h, 2, w, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, c * 4, h, w)
+    extra = torch.zeros(n, 4, h, w, device=x.device, dtype=x.dtype)
+    extra[:, 0] = sigma
+    return ops.to_c8(torch.cat([u, extra], 1)), h, w
+
+
+def ffdnet_forward_nchw(model, x, sigma):
+    """FFDNet forward on n frames: x (n,3,H,W) CUDA float32 -> (n,3,H,W)."""
+    n, _, H, W = x.shape
+    in_c8, h, w = _unshuffle_to_c8(x.float().contiguous(), sigma)
+    eng = _engine_for(model, n, h, w, x.device)
+    out = ops.from_c8(eng.forward(in_c8), 12)
+    return F.pixel_shuffle(out, 2)[..., :H, :W].contiguous()
+
+
+def ffdnet_rgb_denoise_full_tensor(x, yall, Phiall, sigma, model, useGPU=True, lr_=0.000001, updata_=False,
+                                   update_per_iter=4, device=0):
+    """x (H,W,3,B) CUDA tensor -> denoised (H,W,3,B); with `updata_` first runs the online
+    measurement-loss finetune and returns (out, model) like the reference."""
+    if updata_:
+        from .finetune import ffdnet_online_finetune
+        rgb = ops.cube_to_rgb(x.float().contiguous())
+        ffdnet_online_finetune(model, rgb, yall, Phiall, sigma, lr_, update_per_iter, planes_layout='reference')
+        out = ffdnet_forward_nchw(model, rgb, sigma)
+        return ops.rgb_to_cube(out), model
+    rgb = ops.cube_to_rgb(x.float().contiguous())
+    return ops.rgb_to_cube(ffdnet_forward_nchw(model, rgb, sigma))

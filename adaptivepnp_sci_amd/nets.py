@@ -1,0 +1,90 @@
+"""Denoiser networks of the plug-and-play prior, as the engine sees them.
+
+`FFDNet` / `FastDVDnet` are parameter containers that are state-dict-key compatible with the
+reference's checkpoints (models/network_ffdnet.py:27-69: keys `model.{0,2,..}.{weight,bias}`;
+packages/fastdvdnet/models.py:146-253: keys `temp{1,2}.<block>.convblock.*`), so that a user can
+`load_state_dict` the reference's .pth files, or hand the reference's own nn.Module to the solver.
+Their `forward` runs on the HIP kernels only (no PyTorch convolution, no CPU path).
+
+`FFDNetEngine` packs a module's weights for scipnp_conv3x3_c8 (c8 layout, channel groups of 8) and
+owns the scratch activations of one forward pass over B frames.
+"""
+import ctypes as C
+import re
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class FFDNet(nn.Module):
+    """KAIR FFDNet container (in_nc*4+1 -> nc -> ... -> out_nc*4, nb conv3x3 layers)."""
+
+    def __init__(self, in_nc=3, out_nc=3, nc=96, nb=12, act_mode='R'):
+        super().__init__()
+        if act_mode != 'R':
+            raise ValueError("only act_mode='R' (conv+ReLU, no BatchNorm) is supported, as the reference uses")
+        self.in_nc, self.out_nc, self.nc, self.nb = in_nc, out_nc, nc, nb
+        layers = [nn.Conv2d(in_nc * 4 + 1, nc, 3, 1, 1, bias=True), nn.ReLU(inplace=True)]
+        for _ in range(nb - 2):
+            layers += [nn.Conv2d(nc, nc, 3, 1, 1, bias=True), nn.ReLU(inplace=True)]
+        layers += [nn.Conv2d(nc, out_nc * 4, 3, 1, 1, bias=True)]
+        self.model = nn.Sequential(*layers)
+        self._engine = None
+
+    def forward(self, x, sigma):
+        """x (n,3,H,W) CUDA tensor, sigma (1,1,1,1) or float -> (n,3,H,W); HIP kernels only."""
+        from .denoisers import ffdnet_forward_nchw
+        return ffdnet_forward_nchw(self, x, float(sigma.reshape(-1)[0]) if torch.is_tensor(sigma) else float(sigma))
+
+
+def ffdnet_layers(model):
+    """[(weight, bias)] of the conv stack of a (reference- or scipnp-) FFDNet module, in order."""
+    sd = model.state_dict()
+    keys = sorted((int(m.group(1)), k) for k in sd for m in [re.fullmatch(r'(?:module\.)?model\.(\d+)\.weight', k)] if m)
+    if not keys:
+        raise ValueError('model does not look like an FFDNet (no `model.<i>.weight` keys)')
+    out = []
+    for _, k in keys:
+        out.append((sd[k], sd[k.replace('weight', 'bias')]))
+    return out
+
+
+class FFDNetEngine:
+    """Packed weights + scratch for B frames of M x N (half-resolution) activations."""
+
+    def __init__(self, model, B, M, N, device):
+        self.device = device
+        self.B, self.M, self.N = B, M, N
+        self.refresh(model)
+        nc = self.nc
+        self.scratch = [torch.empty(B * nc * M * N, dtype=torch.float32, device=device) for _ in range(2)]
+        self.in_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
+        self.out_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
+
+    def refresh(self, model):
+        """(Re)pack the weights; call after every optimizer step of the online finetune."""
+        layers = ffdnet_layers(model)
+        self.nb = len(layers)
+        self.nc = layers[0][0].shape[0]
+        if layers[0][0].shape[1] != 13 or layers[-1][0].shape[0] != 12 or self.nc % 8:
+            raise ValueError('FFDNetEngine supports the colour network (13 -> nc -> 12 channels, nc % 8 == 0)')
+        self.packed = []
+        for i, (w, b) in enumerate(layers):
+            cin = 16 if i == 0 else self.nc
+            cout = 16 if i == self.nb - 1 else self.nc
+            self.packed.append(ops.pack_conv3x3(w, b, Cin=cin, Cout=cout, device=self.device))
+        self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
+
+    def forward(self, in_c8=None, out_c8=None):
+        in_c8 = self.in_c8 if in_c8 is None else in_c8
+        out_c8 = self.out_c8 if out_c8 is None else out_c8
+        lib = _lib.load()
+        _lib.require_gpu()
+        rc = lib.scipnp_ffdnet_forward(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), self._ptrs,
+                                       self.nb, self.nc, C.c_void_p(self.scratch[0].data_ptr()),
+                                       C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, 'scipnp_ffdnet_forward')
+        return out_c8

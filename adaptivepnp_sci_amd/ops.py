@@ -1,0 +1,267 @@
+"""Thin Python wrappers over the C ABI (include/scipnp.h).  PyTorch-ROCm is used only as the
+device allocator and stream provider: every function takes CUDA(ROCm) float32 tensors, checks
+them, and passes raw device pointers plus the current HIP stream to libscipnp.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, name='tensor', dtype=F32):
+    if t is None:
+        return C.c_void_p(0)
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.ScipnpError(f'{name} must be a CUDA/ROCm tensor (the hot path has no CPU fallback)')
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}')
+    return C.c_void_p(t.data_ptr())
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.require_gpu()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+# ------------------------------------------------------------------ reference-layout operators
+def A_(x, Phi):
+    """y = sum_t x*Phi on planes (M,N,B,4) -> (M,N,4); reference utilspy.py:28-33."""
+    M, N, B, _ = Phi.shape
+    y = torch.empty(M, N, 4, device=Phi.device, dtype=F32)
+    _call('scipnp_A', _p(x, 'x'), _p(Phi, 'Phi'), _p(y), M, N, B, _stream())
+    return y
+
+
+def At_(y, Phi):
+    """x = y*Phi broadcast over frames; reference utilspy.py:35-44."""
+    M, N, B, _ = Phi.shape
+    x = torch.empty_like(Phi)
+    _call('scipnp_At', _p(y, 'y'), _p(Phi, 'Phi'), _p(x), M, N, B, _stream())
+    return x
+
+
+def phisum(Phi):
+    M, N, B, _ = Phi.shape
+    out = torch.empty(M, N, 4, device=Phi.device, dtype=F32)
+    _call('scipnp_phisum', _p(Phi, 'Phi'), _p(out), M, N, B, _stream())
+    return out
+
+
+def bayer_split(mosaic):
+    H, W, B = mosaic.shape
+    out = torch.empty(H // 2, W // 2, B, 4, device=mosaic.device, dtype=F32)
+    _call('scipnp_bayer_split', _p(mosaic, 'mosaic'), _p(out), H // 2, W // 2, B, _stream())
+    return out
+
+
+def bayer_merge(planes):
+    M, N, B, _ = planes.shape
+    out = torch.empty(2 * M, 2 * N, B, device=planes.device, dtype=F32)
+    _call('scipnp_bayer_merge', _p(planes, 'planes'), _p(out), M, N, B, _stream())
+    return out
+
+
+def proj_twostage(theta, b, Phi, y, Phisum, inv_rho, alpha_rho, out=None):
+    M, N, B, _ = Phi.shape
+    out = torch.empty_like(theta) if out is None else out
+    _call('scipnp_proj_twostage', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
+          _p(out, 'out'), M, N, B, float(np.float32(inv_rho)), float(np.float32(alpha_rho)), _stream())
+    return out
+
+
+def proj_onestage(theta, b, Phi, y, Phisum, lam, gamma, out=None):
+    M, N, B, _ = Phi.shape
+    out = torch.empty_like(theta) if out is None else out
+    _call('scipnp_proj_onestage', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
+          _p(out, 'out'), M, N, B, float(np.float32(lam)), float(np.float32(gamma)), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ layout conversions
+def mosaic_to_state(mosaic):
+    H, W, B = mosaic.shape
+    out = torch.empty(B, 4, H // 2, W // 2, device=mosaic.device, dtype=F32)
+    _call('scipnp_mosaic_to_state', _p(mosaic, 'mosaic'), _p(out), H // 2, W // 2, B, _stream())
+    return out
+
+
+def state_to_mosaic(state):
+    B, _, M, N = state.shape
+    out = torch.empty(2 * M, 2 * N, B, device=state.device, dtype=F32)
+    _call('scipnp_state_to_mosaic', _p(state, 'state'), _p(out), M, N, B, _stream())
+    return out
+
+
+def y_to_meas(y):
+    H, W = y.shape
+    out = torch.empty(4, H // 2, W // 2, device=y.device, dtype=F32)
+    _call('scipnp_y_to_meas', _p(y, 'y'), _p(out), H // 2, W // 2, _stream())
+    return out
+
+
+def rgb_to_cube(rgb):
+    B, _, H, W = rgb.shape
+    out = torch.empty(H, W, 3, B, device=rgb.device, dtype=F32)
+    _call('scipnp_rgb_to_cube', _p(rgb, 'rgb'), _p(out), H, W, B, _stream())
+    return out
+
+
+def cube_to_rgb(cube):
+    H, W, _, B = cube.shape
+    out = torch.empty(B, 3, H, W, device=cube.device, dtype=F32)
+    _call('scipnp_cube_to_rgb', _p(cube, 'cube'), _p(out), H, W, B, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ plane-major engine
+def pm_setup(Phi, y, want_x0=True):
+    B, _, M, N = Phi.shape
+    Phisum = torch.empty(4, M, N, device=Phi.device, dtype=F32)
+    x0 = torch.empty_like(Phi) if want_x0 else None
+    _call('scipnp_pm_setup', _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum), _p(x0), M, N, B, _stream())
+    return Phisum, x0
+
+
+def pm_project(theta, b, Phi, y, Phisum, mode, c0, c1, out):
+    B, _, M, N = Phi.shape
+    _call('scipnp_pm_project', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
+          _p(out, 'out'), M, N, B, int(mode), float(np.float32(c0)), float(np.float32(c1)), _stream())
+    return out
+
+
+class TvPlan:
+    """Workspace for the Chambolle TV prior on C channels of M x N (allocated once per solve)."""
+
+    def __init__(self, M, N, C_, n_iter_max, device):
+        self.M, self.N, self.C, self.n_iter_max = M, N, C_, n_iter_max
+        nbytes = _lib.load().scipnp_tv_workspace_bytes(M, N, C_, n_iter_max)
+        self.nbytes = nbytes
+        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        off = (-self.ws.data_ptr()) % 256
+        self.ptr = self.ws.data_ptr() + off
+        self.stop_iter = torch.empty(C_, dtype=torch.int32, device=device)
+
+
+def tv_chambolle(x, b, coef, theta, plan, weight=0.1, eps=2e-4):
+    """theta = TV(x + coef*b) channel by channel; x, b, theta: (C, M, N) views of plane-major state."""
+    _call('scipnp_tv_chambolle', _p(x, 'x'), _p(b, 'b'), float(np.float32(coef)), _p(theta, 'theta'),
+          plan.M, plan.N, plan.C, float(np.float32(weight)), float(np.float32(eps)), plan.n_iter_max,
+          C.c_void_p(plan.ptr), plan.nbytes, _p(plan.stop_iter, 'stop_iter', torch.int32), _stream())
+    return theta
+
+
+def pm_dual_update(theta_raw, x, theta, b, sign, orig=None, sse_part=None, which=0):
+    B, _, M, N = x.shape
+    nb = C.c_int(0)
+    _call('scipnp_pm_dual_update', _p(theta_raw, 'theta_raw'), _p(x, 'x'), _p(theta, 'theta'), _p(b, 'b'),
+          _p(orig, 'orig'), _p(sse_part, 'sse_part', torch.float64), int(which), float(sign), M, N, B,
+          C.byref(nb), _stream())
+    return nb.value
+
+
+def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma):
+    B, _, M, N = x.shape
+    _call('scipnp_pm_pre_denoise', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(x_rgb, 'x_rgb'), _p(rgb_w, 'rgb_w'),
+          _p(net_in_c8, 'net_in_c8'), M, N, B, float(np.float32(inv_rho)), float(np.float32(inv_tau)),
+          float(np.float32(sigma)), _stream())
+
+
+def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first_iter_alias, orig=None,
+                    sse_part=None):
+    B, _, M, N = x.shape
+    nb = C.c_int(0)
+    _call('scipnp_pm_post_denoise', _p(out_rgb, 'out_rgb'), _p(out_c8, 'out_c8'), _p(out_rgb_store, 'out_rgb_store'),
+          _p(x, 'x'), _p(x_rgb, 'x_rgb'), _p(theta, 'theta'), _p(b, 'b'), _p(w, 'w'), _p(orig, 'orig'),
+          _p(sse_part, 'sse_part', torch.float64), int(bool(first_iter_alias)), M, N, B, C.byref(nb), _stream())
+    if sse_part is not None and nb.value != sse_part.numel():
+        raise _lib.ScipnpError(f'SSE partial count mismatch: kernel wrote {nb.value}, buffer has {sse_part.numel()}')
+    return nb.value
+
+
+def sse_nblocks(n):
+    nb = C.c_int(0)
+    lib = _lib.load()
+    _lib.check(lib.scipnp_sse_partials(C.c_void_p(1), C.c_void_p(1), n, C.c_void_p(0), C.byref(nb), C.c_void_p(0)),
+               'scipnp_sse_partials')
+    return nb.value
+
+
+def sse_partials(a, b, part):
+    nb = C.c_int(0)
+    _call('scipnp_sse_partials', _p(a, 'a'), _p(b, 'b'), a.numel(), _p(part, 'part', torch.float64), C.byref(nb),
+          _stream())
+    return part
+
+
+def post_nblocks(M, N, B):
+    """number of SSE partials scipnp_pm_post_denoise writes (its launch grid; mirrored from demosaic.hip)"""
+    threads = 256 if N >= 256 else (128 if N >= 128 else 64)
+    return ((N + threads - 1) // threads) * M * B
+
+
+def sse(a, b):
+    """sum((a-b)^2) with float32 differences and float64 accumulation (skimage PSNR's MSE numerator)."""
+    n = a.numel()
+    part = torch.empty(sse_nblocks(n), dtype=torch.float64, device=a.device)
+    nb = C.c_int(0)
+    _call('scipnp_sse_partials', _p(a, 'a'), _p(b, 'b'), n, _p(part, 'part', torch.float64), C.byref(nb), _stream())
+    return float(part.sum().item())
+
+
+# ------------------------------------------------------------------ convolutions
+def pack_conv3x3(weight, bias=None, bn_scale=None, bn_shift=None, Cin=None, Cout=None, device=None):
+    """OIHW float32 weights (CPU or GPU tensor) -> packed device buffer for scipnp_conv3x3_c8."""
+    w = weight.detach().to('cpu', F32).contiguous()
+    co, ci = w.shape[0], w.shape[1]
+    Cin = Cin or (ci + 7) // 8 * 8
+    Cout = Cout or (co + 7) // 8 * 8
+    lib = _lib.load()
+    n = lib.scipnp_conv3x3_packed_floats(Cin, Cout)
+    packed = torch.empty(n, dtype=F32)
+
+    def hp(t):
+        if t is None:
+            return C.c_void_p(0), None
+        t = t.detach().to('cpu', F32).contiguous()
+        return C.c_void_p(t.data_ptr()), t
+
+    bp, _b = hp(bias)
+    sp, _s = hp(bn_scale)
+    hp_, _h = hp(bn_shift)
+    _lib.check(lib.scipnp_pack_conv3x3_weights(C.c_void_p(w.data_ptr()), bp, sp, hp_, ci, co, Cin, Cout,
+                                               C.c_void_p(packed.data_ptr())), 'scipnp_pack_conv3x3_weights')
+    return packed.to(device) if device is not None else packed
+
+
+def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None):
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+    flags = (1 if relu else 0) | (2 if residual is not None else 0)
+    _call('scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'), _p(out, 'out'), _p(residual, 'residual'),
+          n, cg * 8, Cout, h, w, flags, _stream())
+    return out
+
+
+def to_c8(x):
+    """NCHW torch tensor -> c8 layout [n][C/8][h][w][8] (zero-padded channels); test/helper path."""
+    n, c, h, w = x.shape
+    cp = (c + 7) // 8 * 8
+    if cp != c:
+        x = torch.cat([x, torch.zeros(n, cp - c, h, w, device=x.device, dtype=x.dtype)], 1)
+    return x.reshape(n, cp // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_c8(x, c=None):
+    n, cg, h, w, _ = x.shape
+    y = x.permute(0, 1, 4, 2, 3).reshape(n, cg * 8, h, w)
+    return y[:, :c].contiguous() if c is not None else y.contiguous()

@@ -1,0 +1,170 @@
+/* scipnp.h -- C ABI of the MI355X-native adaptive PnP-ADMM engine for Bayer video snapshot
+ * compressive imaging (drop-in for the hot path of xyvirtualgroup/AdaptivePnP_SCI).
+ *
+ * Rules of the boundary
+ *   - plain C: raw DEVICE pointers, ints, floats and a stream handle; no torch / C++ types;
+ *   - the library never allocates, frees or synchronises: the caller owns every buffer (the Python
+ *     host passes PyTorch-ROCm allocations) and passes its HIP stream; every entry is asynchronous
+ *     on that stream and may be captured in a hipGraph;
+ *   - every entry returns 0 on success or a negative SCIPNP_E* code; scipnp_last_error() gives the
+ *     text (thread-local).
+ *   - all arrays are float32.  Two memory layouts appear:
+ *       "reference layout": what the reference's Python functions hold --
+ *           planes (M,N,B,4): quarter-resolution Bayer planes R,G1,G2,B in the LAST dim, frame next;
+ *           mosaic (H,W,B), y (H,W), rgb cube (H,W,3,B) with H = 2M, W = 2N;
+ *       "plane-major layout": what the engine keeps resident in HBM between iterations --
+ *           state  [B][4][M][N]   (one contiguous M x N image per frame and Bayer plane),
+ *           meas   [4][M][N]      (y and Phi_sum),
+ *           rgb    [B][3][H][W]   (planar full-resolution colour frames),
+ *           c8     [n][C/8][h][w][8]  (activations of the denoiser: 8-channel groups innermost).
+ *
+ * Each entry cites the reference code it replaces (paths relative to the reference repository).
+ */
+#ifndef SCIPNP_H
+#define SCIPNP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* scipnp_stream_t; /* a hipStream_t */
+
+#define SCIPNP_OK 0
+#define SCIPNP_EINVAL (-1)   /* bad shape / null pointer / unsupported size  */
+#define SCIPNP_EALIGN (-2)   /* pointer not 16-byte aligned                  */
+#define SCIPNP_EHIP (-3)     /* HIP runtime error at launch                  */
+#define SCIPNP_EWORKSPACE (-4) /* workspace too small                        */
+
+const char* scipnp_version(void);
+const char* scipnp_last_error(void);
+/* name of the GPU architecture the kernels were compiled for ("gfx950") */
+const char* scipnp_arch(void);
+
+/* ---------------------------------------------------------------- reference-layout operators
+ * These take exactly the tensors the reference's functions take, so a maintainer can bind them
+ * one-to-one.  planes = (M,N,B,4) contiguous, meas = (M,N,4). */
+
+/* y[m,n,ib] = sum_t x[m,n,t,ib]*Phi[m,n,t,ib]      -- utilspy.py:28-33  A_(x, Phi) on all 4 planes */
+int scipnp_A(const float* x, const float* Phi, float* y, int M, int N, int B, scipnp_stream_t s);
+/* x[m,n,t,ib] = y[m,n,ib]*Phi[m,n,t,ib]            -- utilspy.py:35-44  At_(y, Phi) */
+int scipnp_At(const float* y, const float* Phi, float* x, int M, int N, int B, scipnp_stream_t s);
+/* Phi_sum = sum_t Phi, zeros replaced by 1          -- dvp_linear_inv_2_stage_ADMM_tensor_online.py:72-75 */
+int scipnp_phisum(const float* Phi, float* Phisum, int M, int N, int B, scipnp_stream_t s);
+/* mosaic (H,W,B) <-> planes (M,N,B,4)               -- utils/utils_image.py:130-151, dvp...:66-69,170-172 */
+int scipnp_bayer_split(const float* mosaic, float* planes, int M, int N, int B, scipnp_stream_t s);
+int scipnp_bayer_merge(const float* planes, float* mosaic, int M, int N, int B, scipnp_stream_t s);
+/* two-stage ADMM Euclidean projection               -- dvp...:128-140
+ *   p = theta - inv_rho*b ;  x = p + Phi*((y - sum_t p*Phi)/(alpha_rho + Phisum))
+ * x may alias theta (the reference's first iteration does).  One quad (2x2 pixels x B frames) is one
+ * 128-byte line for B = 8; the frame reduction is a wavefront shuffle.  B must be 1,2,4,8 or 16. */
+int scipnp_proj_twostage(const float* theta, const float* b, const float* Phi, const float* y,
+                         const float* Phisum, float* x, int M, int N, int B,
+                         float inv_rho, float alpha_rho, scipnp_stream_t s);
+/* one-stage ("GAP form") projection                 -- dvp...:389-391
+ *   v = theta + b ;  x = v + lambda*Phi*((y - sum_t v*Phi)/(Phisum + gamma)) */
+int scipnp_proj_onestage(const float* theta, const float* b, const float* Phi, const float* y,
+                         const float* Phisum, float* x, int M, int N, int B,
+                         float lambda, float gamma, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------- layout conversion (entry / exit only) */
+/* mosaic (H,W,B) -> state [B][4][M][N] and back     -- replaces the strided copies dvp...:66-83, :312-315 */
+int scipnp_mosaic_to_state(const float* mosaic, float* state, int M, int N, int B, scipnp_stream_t s);
+int scipnp_state_to_mosaic(const float* state, float* mosaic, int M, int N, int B, scipnp_stream_t s);
+/* y (H,W) -> meas [4][M][N] */
+int scipnp_y_to_meas(const float* y, float* meas, int M, int N, scipnp_stream_t s);
+/* planar rgb [B][3][H][W] -> reference cube (H,W,3,B)   -- the (H,W,3,B) return value dvp...:324 */
+int scipnp_rgb_to_cube(const float* rgb, float* cube, int H, int W, int B, scipnp_stream_t s);
+/* reference cube (H,W,3,B) -> planar rgb [B][3][H][W] */
+int scipnp_cube_to_rgb(const float* cube, float* rgb, int H, int W, int B, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------- plane-major engine kernels */
+/* setup: Phisum[4][M][N] = sum_t Phi (0 -> 1); if x0 != NULL: x0 = y*Phi  -- dvp...:72-80 */
+int scipnp_pm_setup(const float* Phi, const float* y, float* Phisum, float* x0,
+                    int M, int N, int B, scipnp_stream_t s);
+/* projection on plane-major state; mode 0 = two-stage (c0 = inv_rho, c1 = alpha_rho),
+ * mode 1 = one-stage (c0 = lambda, c1 = gamma).  x may alias theta.        -- dvp...:128-140 / :389-391 */
+int scipnp_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
+                      const float* Phisum, float* x, int M, int N, int B, int mode,
+                      float c0, float c1, scipnp_stream_t s);
+
+/* Chambolle TV prior on C independent M x N channels (plane-major: channel = contiguous image)
+ *   theta = TV(x + coef*b)   [b may be NULL: theta = TV(x)]
+ * -- replaces the D2H + skimage.restoration.denoise_tv_chambolle(v, weight, n_iter_max=5,
+ *    multichannel=True) + H2D round trip at dvp...:153-160 and :403-407.  eps is skimage's default
+ *    2e-4.  Per-channel early stop is evaluated on device from fp64 block partials, in launch order
+ *    (deterministic).  stop_iter (int32[C], may be NULL) receives the iteration whose `out` was kept. */
+size_t scipnp_tv_workspace_bytes(int M, int N, int C, int n_iter_max);
+int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta,
+                        int M, int N, int C, float weight, float eps, int n_iter_max,
+                        void* workspace, size_t workspace_bytes, int32_t* stop_iter,
+                        scipnp_stream_t s);
+
+/* theta = clip(theta_raw,0,1); b = b + sign*(x - theta).  If sse_part != NULL and orig != NULL,
+ * also writes per-block partial sums of (orig - report)^2, report = theta (which=0) or x (which=1),
+ * to sse_part[0..nblocks) (double); returns the number of blocks through *nblocks.
+ * -- dvp...:265-267 (sign=+1) / :501-503 (sign=-1) and the per-iteration IQA :274-279 / :506-512. */
+int scipnp_pm_dual_update(const float* theta_raw, const float* x, float* theta, float* b,
+                          const float* orig, double* sse_part, int which, float sign,
+                          int M, int N, int B, int* nblocks, scipnp_stream_t s);
+
+/* pre-denoiser fusion: mosaic = x + inv_rho*b (never materialised), Malvar-2004 demosaic with the
+ * torch port's reflect-101 border, x_rgb [B][3][H][W] stored, net_in = x_rgb - inv_tau*w emitted
+ * (a) as planar rgb_w [B][3][H][W] if rgb_w != NULL and (b) 2x2 pixel-unshuffled + noise-level map
+ * into c8 layout [B][2][M][N][8] (channels 0..11 = c*4+dy*2+dx, 12 = sigma, 13..15 = 0) if
+ * net_in_c8 != NULL.  w may be NULL (treated as 0).
+ * -- dvp...:169-172 (merge), :186-191 + malvar2004.py:169-246 (demosaic), :198 (x_rgb - w/tau),
+ *    network_ffdnet.py:54-64 (unshuffle + sigma map). */
+int scipnp_pm_pre_denoise(const float* x, const float* b, const float* w, float* x_rgb,
+                          float* rgb_w, float* net_in_c8, int M, int N, int B,
+                          float inv_rho, float inv_tau, float sigma, scipnp_stream_t s);
+
+/* post-denoiser fusion: theta_raw = denoised RGB sampled at the CFA sites, theta = clip(theta_raw),
+ * b += x_eff - theta with x_eff = theta_raw when first_iter_alias (the reference's k = 0 tensor
+ * aliasing, SURVEY 3.2: x and theta are one tensor, so x is overwritten with theta_raw too) else x;
+ * w += x_rgb - out (skipped when w == NULL).  The denoised frames come either as planar rgb
+ * [B][3][H][W] (out_rgb) or as the FFDNet tail in c8 layout [B][2][M][N][8] before pixel-shuffle
+ * (out_c8; exactly one of the two non-NULL); if out_rgb_store != NULL the pixel-shuffled planar
+ * frames are also written there (needed for the returned colour cube).  SSE partials as above.
+ * -- dvp...:206-209 / :256-259, :265, :267, :271, :274-279 and network_ffdnet.py:66-68. */
+int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out_rgb_store,
+                           float* x, const float* x_rgb, float* theta, float* b, float* w,
+                           const float* orig, double* sse_part, int first_iter_alias,
+                           int M, int N, int B, int* nblocks, scipnp_stream_t s);
+
+/* sum of squared differences, per-block fp64 partials (deterministic two-level reduction; the
+ * host adds the nblocks doubles)  -- skimage peak_signal_noise_ratio at dvp...:279,:320 */
+int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, int* nblocks,
+                        scipnp_stream_t s);
+
+/* ---------------------------------------------------------------- denoiser: 3x3 convolutions on MFMA
+ * in/out in c8 layout [n][C/8][h][w][8]; weights pre-packed by scipnp_pack_conv3x3_weights.
+ * fp32 operands, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products, fmaf chain).
+ * Cin, Cout multiples of 8 (pad with zero channels); stride 1, zero padding 1.
+ * flags: bit0 = ReLU, bit1 = add `residual` (c8, same shape as out) before the activation.
+ * -- replaces nn.Conv2d(...,3,1,1)+ReLU at models/basicblock.py:61-98 as used by network_ffdnet.py:46-48
+ *    and the CvBlock/UpBlock/OutputCvBlock convs of packages/fastdvdnet/models.py:16-89. */
+size_t scipnp_conv3x3_packed_floats(int Cin, int Cout);
+/* w: [Cout_real][Cin_real][3][3] (PyTorch OIHW), bias: [Cout_real] or NULL; scale/shift fold an
+ * eval-mode BatchNorm (y = conv*scale[co] + shift[co]; NULL = identity).  HOST pointers in, HOST
+ * packed buffer out (the caller uploads it once per weight update). */
+int scipnp_pack_conv3x3_weights(const float* w, const float* bias, const float* bn_scale,
+                                const float* bn_shift, int Cin_real, int Cout_real, int Cin, int Cout,
+                                float* packed);
+int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const float* residual,
+                      int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+
+/* whole FFDNet-colour forward on B frames: 12 (nb) conv layers ping-ponging between two c8 scratch
+ * buffers of n*nc*h*w floats each.  in_c8: [B][2][M][N][8] from scipnp_pm_pre_denoise, out_c8:
+ * [B][2][M][N][8] (12 valid channels, pixel-shuffle is folded into scipnp_pm_post_denoise).
+ * packed: array of nb device pointers to packed layer weights.
+ * -- models/network_ffdnet.py:54-69 called per frame by packages/ffdnet/test_ffdnet_ipol.py:340-354 */
+int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,
+                          float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCIPNP_H */

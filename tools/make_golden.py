@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE ITSELF
+(/root/reference, imported read-only through tools/ref_shim.py; TV goes to the genuine
+scikit-image 0.18.3 of the py3.9 env) on seeded synthetic inputs, and -- in the same run -- assert
+that the oracle restatement (oracle/) reproduces every captured array.  Build-container only:
+`python tools/make_golden.py [group ...]`; the GPU box never sees /root/reference.
+
+Groups: ops, bayer, malvar, tv, tvadmm, ffdnet, ffdadmm, ffdtune, fastdvd, weights.
+"""
+import copy
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+import ref_shim  # noqa: E402
+
+R = ref_shim.import_solver()
+import utilspy as RU  # noqa: E402  (reference)
+import utils.utils_image as RI  # noqa: E402  (reference)
+from packages.colour_demosaicing.bayer.demosaicing.malvar2004 import (  # noqa: E402
+    demosaicing_CFA_Bayer_Malvar2004_tensor as ref_malvar)
+from models.network_ffdnet import FFDNet as RefFFDNet  # noqa: E402
+from packages.fastdvdnet.models import FastDVDnet as RefFastDVDnet  # noqa: E402
+
+from adaptivepnp_sci_amd import synth  # noqa: E402
+from oracle import denoisers as OD  # noqa: E402
+from oracle import malvar as OM  # noqa: E402
+from oracle import nets as ON  # noqa: E402
+from oracle import sci_ops as OO  # noqa: E402
+from oracle import solver as OS  # noqa: E402
+from oracle import tv_chambolle as OT  # noqa: E402
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check(name, mine, ref, tol=0.0):
+    r = rel(mine, ref)
+    flag = 'OK ' if r <= tol else 'BAD'
+    print(f'   [{flag}] oracle vs reference  {name}: rel-L2 = {r:.3e}')
+    assert r <= tol, name
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f'   wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def seed_all():
+    RU.worker_init_fn(0)  # reference seeding: numpy + torch = 42 (utilspy.py:22-25)
+
+
+class Capture:
+    """Hook on the reference solver's per-iteration PSNR call (dvp...:279 / :512): its 2nd argument
+    is the mosaic of the current iterate, once per iteration with shape (H,W,B)."""
+
+    def __init__(self):
+        self.iterates = []
+        self.orig = R.compare_psnr
+
+    def __enter__(self):
+        def hook(a, b, data_range=None):
+            if b.ndim == 3:
+                self.iterates.append(b.copy())
+            return self.orig(a, b, data_range=data_range)
+        R.compare_psnr = hook
+        return self
+
+    def __exit__(self, *a):
+        R.compare_psnr = self.orig
+
+
+def load_ref_ffdnet():
+    net = RefFFDNet(in_nc=3, out_nc=3, nc=96, nb=12, act_mode='R')
+    sd = torch.load(os.path.join(ref_shim.REF, 'model_zoo', 'ffdnet_color.pth'), map_location='cpu')
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    for p in net.parameters():
+        p.requires_grad = True
+    return net, sd
+
+
+def oracle_ffdnet(sd):
+    net = ON.OracleFFDNet()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    return net
+
+
+# ------------------------------------------------------------------ groups
+def g_weights():
+    _, sd = load_ref_ffdnet()
+    save('ffdnet_color_weights', **{k: v.numpy() for k, v in sd.items()})
+
+
+def g_ops():
+    for tag, (M, N, B) in {'8x8x8': (8, 8, 8), '32x32x8': (32, 32, 8), '12x20x5': (12, 20, 5)}.items():
+        rng = np.random.default_rng(11)
+        theta = torch.from_numpy(rng.uniform(-0.2, 1.2, (M, N, B, 4)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(0, 0.1, (M, N, B, 4)).astype(np.float32))
+        Phi = (rng.uniform(0, 1, (M, N, B, 4)) < 0.5).astype(np.float32)
+        Phi[0, :3] = 0  # pixels with Phi_sum == 0
+        Phi[1, 0] *= rng.uniform(0, 1, (B, 4)).astype(np.float32)  # non-binary mask values
+        Phi = torch.from_numpy(Phi)
+        y = torch.from_numpy(rng.uniform(0, B, (M, N, 4)).astype(np.float32))
+        Phisum = torch.zeros(M, N, 4)
+        A_out = torch.zeros(M, N, 4)
+        At_out = torch.zeros(M, N, B, 4)
+        x2 = torch.zeros(M, N, B, 4)
+        x1 = torch.zeros(M, N, B, 4)
+        x2r = torch.zeros(M, N, B, 4)
+        for ib in range(4):  # drive the reference's A_/At_ exactly as dvp...:72-73,:128-140,:389-391 do
+            s = torch.sum(Phi[..., ib], dim=2)
+            s[s == 0] = 1
+            Phisum[..., ib] = s
+            A_out[..., ib] = RU.A_(theta[..., ib], Phi[..., ib])
+            At_out[..., ib] = RU.At_(y[..., ib], Phi[..., ib])
+            for rho, alpha, dst in ((1, 1, x2), (0.55, 1, x2r)):
+                p = theta[..., ib] - (1 / rho) * b[..., ib]
+                yb = RU.A_(p, Phi[..., ib])
+                t = (y[..., ib] - yb) / (alpha * rho + Phisum[..., ib])
+                t = Phi[..., ib] * torch.repeat_interleave(t.unsqueeze(2), B, dim=2)
+                dst[..., ib] = p + t
+            yb = RU.A_(theta[..., ib] + b[..., ib], Phi[..., ib])
+            x1[..., ib] = theta[..., ib] + b[..., ib] + 1 * (RU.At_((y[..., ib] - yb) / (Phisum[..., ib] + 0.01), Phi[..., ib]))
+        check(f'proj2 {tag}', OO.project_two_stage(theta, b, Phi, y, Phisum, 1, 1), x2)
+        check(f'proj2 rho=.55 {tag}', OO.project_two_stage(theta, b, Phi, y, Phisum, 0.55, 1), x2r)
+        check(f'proj1 {tag}', OO.project_one_stage(theta, b, Phi, y, Phisum, 1, 0.01), x1)
+        save(f'ops_{tag}', theta=theta, b=b, Phi=Phi, y=y, Phisum=Phisum, A_theta=A_out, At_y=At_out,
+             x_two_stage=x2, x_two_stage_rho055=x2r, x_one_stage=x1)
+
+
+def g_bayer():
+    rng = np.random.default_rng(5)
+    mos = torch.from_numpy(rng.uniform(0, 1, (12, 20, 5)).astype(np.float32))
+    four = RI.oneCh2FourCh(mos)
+    back = RI.fourCh2OneCh(four)
+    three_a = RI.fourCh2ThreeCh(four)
+    three_b = RI.oneCh2ThreeCh(mos)
+    assert torch.equal(back, mos)
+    check('bayer_split', OO.bayer_split(mos), four)
+    check('bayer_merge', OO.bayer_merge(four), back)
+    check('four_to_three', OO.four_to_three_channel(four), three_a)
+    check('one_to_three', OO.one_to_three_channel(mos), three_b)
+    save('bayer_12x20x5', mosaic=mos, planes=four, three_from_four=three_a, three_from_one=three_b)
+
+
+def g_malvar():
+    out = {}
+    for tag, (H, W) in {'16x16': (16, 16), '64x64': (64, 64), '8x24': (8, 24)}.items():
+        rng = np.random.default_rng(7)
+        cfa = torch.from_numpy(rng.uniform(0, 1, (H, W)).astype(np.float32))
+        Rm, Gm, Bm = RI.masks_CFA_Bayer_tensor((H, W))
+        ref = ref_malvar(cfa, Rm, Gm, Bm)
+        check(f'malvar {tag}', OM.malvar_demosaic(cfa), ref)
+        out[f'cfa_{tag}'] = cfa
+        out[f'rgb_{tag}'] = ref
+    save('malvar', **out)
+
+
+def _tv_inputs():
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:64, 0:64]
+    chans = []
+    for c in range(32):
+        base = 0.5 + 0.3 * np.sin(xx / (5 + c)) * np.cos(yy / (7 + 0.5 * c))
+        noise = (1e-4, 0.02, 0.1, 0.3)[c % 4]
+        chans.append(base + noise * rng.standard_normal((64, 64)))
+    v = np.stack(chans, -1).astype(np.float32)
+    v[..., 5] = 0.25        # constant channel: E_0 = 0
+    # large-amplitude mask-like texture (what x0 = Phi*y looks like on a cold start, values up to B):
+    # these channels hit the |E_prev - E| < eps*E_0 stop inside the 5 allowed iterations
+    for c in (3, 7, 11, 15, 19, 23):
+        v[..., c] = ((2.0 + c) * rng.standard_normal((64, 64))).astype(np.float32)
+    v[..., 27] = (20.0 * ((xx + yy) % 2)).astype(np.float32)
+    v[..., 31] = (rng.uniform(0, 1, (64, 64)) < 0.5).astype(np.float32) * rng.uniform(0, 8, (64, 64)).astype(np.float32)
+    return v
+
+
+def g_tv():
+    v = _tv_inputs()
+    ref5 = ref_shim.SERVER.tv(v, 0.1, 5, True)
+    ref50 = ref_shim.SERVER.tv(v, 0.1, 50, True)
+    ref_w = ref_shim.SERVER.tv(v, 0.03, 5, True)
+    m5, s5, _ = OT.tv_chambolle_multichannel(v, 0.1, n_iter_max=5, return_info=True)
+    m50, s50, _ = OT.tv_chambolle_multichannel(v, 0.1, n_iter_max=50, return_info=True)
+    mw, sw, _ = OT.tv_chambolle_multichannel(v, 0.03, n_iter_max=5, return_info=True)
+    check('tv n=5', m5, ref5)
+    check('tv n=50', m50, ref50)
+    check('tv w=.03', mw, ref_w)
+    print('   stop iterations n=5 :', s5.tolist())
+    print('   stop iterations n=50:', s50.tolist())
+    assert (s5 < 4).any(), 'need early-stopping channels in the golden set'
+    save('tv_chambolle', v=v, out_w01_n5=ref5, stop_w01_n5=s5, out_w01_n50=ref50, stop_w01_n50=s50,
+         out_w003_n5=ref_w, stop_w003_n5=sw)
+
+
+def g_tvadmm():
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=0)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        xb, psnr_, ssim_, psnr_all = R.admm_denoise_bayer_demosaic_pre(
+            y, Phi, 1, 0.01, 'tv', [10], False, [0], x0_bayer=None, X_orig=orig, model=None,
+            show_iqa=True, logf=logf)
+    one = np.stack(cap.iterates)
+    o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [10], [0], X_orig=orig)
+    check('one-stage TV iterates', np.stack(o['x_iterates']), one)
+    check('one-stage TV psnr', np.array(o['psnr_all']), np.array(psnr_all))
+    seed_all()
+    with Capture() as cap:
+        xb2, psnr2_, ssim2_, psnr_all2 = R.twoStageAdmm_denoise_bayer(
+            y, Phi, 1, 0.01, 'tv', [10], False, [0], x0_bayer=None, X_orig=orig, show_iqa=True, logf=logf)
+    two = np.stack(cap.iterates)
+    o2 = OS.two_stage_admm(y, Phi, 'tv', [10], [0], X_orig=orig)
+    check('two-stage TV iterates', np.stack(o2['theta_iterates']), two)
+    save('tvadmm_64x64x8', y=y, Phi=Phi, orig=orig, one_stage_x=one, one_stage_psnr=psnr_all,
+         one_stage_final=xb, one_stage_psnr_frames=psnr_, one_stage_ssim_frames=ssim_,
+         two_stage_theta=two, two_stage_psnr=psnr_all2, two_stage_final=xb2,
+         two_stage_psnr_frames=psnr2_, two_stage_ssim_frames=ssim2_, log=np.array(logf.getvalue()))
+
+
+def g_ffdnet():
+    net, sd = load_ref_ffdnet()
+    onet = oracle_ffdnet(sd)
+    out = {}
+    rng = np.random.default_rng(9)
+    for tag, (H, W) in {'64x64': (64, 64), '128x128': (128, 128), '37x50': (37, 50)}.items():
+        x = torch.from_numpy(rng.uniform(0, 1, (1, 3, H, W)).astype(np.float32))
+        out[f'in_{tag}'] = x
+        for s in (6, 12, 25, 50):
+            sig = torch.full((1, 1, 1, 1), s / 255.)
+            with torch.no_grad():
+                ref = net(x, sig)
+                mine = onet(x, sig)
+            check(f'ffdnet {tag} sigma={s}', mine, ref)
+            out[f'out_{tag}_s{s}'] = ref
+    save('ffdnet_forward', **out)
+
+
+def _tv_warm(y, Phi, its=40):
+    o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [its], [0])
+    return o['x_bayer']
+
+
+def g_ffdadmm():
+    net, sd = load_ref_ffdnet()
+    # (a) cold start (x0 = Phi*y, values up to B): forces clipping at k = 0 -> exposes the alias rule
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=1)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2, 2], False, [50 / 255, 25 / 255],
+                                           x0_bayer=None, X_orig=orig, model_denoise=net, model_demosaic=None,
+                                           show_iqa=True, demosaic_method='malvar2004', logf=logf)
+    ref_it = np.stack(cap.iterates)
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2, 2], [50 / 255, 25 / 255], X_orig=orig,
+                          model_denoise=oracle_ffdnet(sd))
+    check('two-stage FFDNet cold iterates', np.stack(o['theta_iterates']), ref_it)
+    check('two-stage FFDNet cold rgb', o['rgb'], res[0])
+    save('ffdadmm_cold_64x64x8', y=y, Phi=Phi, orig=orig, theta=ref_it, rgb=res[0], final=res[1],
+         psnr_all=res[4], psnr_frames=res[2], ssim_frames=res[3])
+    # (b) driver schedule, TV warm start (two_stage_ADMM_Online_FFD_Warm.py:71-72,259-263)
+    y, Phi, orig = synth.make_problem(128, 128, 8, seed=2)
+    warm = _tv_warm(y, Phi)
+    sig, its = [25 / 255, 12 / 255, 6 / 255], [15, 6, 4]
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', its, False, sig,
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=net,
+                                           show_iqa=True, demosaic_method='malvar2004', logf=logf)
+    ref_it = np.stack(cap.iterates)
+    dio = []
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', its, sig, x0_bayer=warm, X_orig=orig,
+                          model_denoise=oracle_ffdnet(sd), denoiser_io=dio)
+    check('two-stage FFDNet warm iterates', np.stack(o['theta_iterates']), ref_it)
+    keep = [0, 1, 2, 14, 15, 16, 24]
+    save('ffdadmm_warm_128x128x8', y=y, Phi=Phi, orig=orig, warm=warm, keep=np.array(keep),
+         theta=ref_it[keep], psnr_all=res[4], final=res[1], rgb_final=res[0],
+         psnr_frames=res[2], ssim_frames=res[3])
+    # one-stage FFDNet branch (admm_denoise_bayer_demosaic_pre 'ffdnet_color', :439-468), short
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=3)
+    warm = _tv_warm(y, Phi, 20)
+    seed_all()
+    with Capture() as cap:
+        res1 = R.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'ffdnet_color', [3], False, [25 / 255],
+                                                 x0_bayer=torch.from_numpy(warm), X_orig=orig, model=net,
+                                                 show_iqa=True, logf=logf)
+    ref_it = np.stack(cap.iterates)
+    o1 = OS.one_stage_admm(y, Phi, 1, 0.01, 'ffdnet_color', [3], [25 / 255], x0_bayer=warm, X_orig=orig,
+                           model=oracle_ffdnet(sd))
+    check('one-stage FFDNet iterates', np.stack(o1['x_iterates']), ref_it)
+    save('ffdadmm_onestage_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, x=ref_it, rgb=res1[0], final=res1[1],
+         psnr_all=res1[4])
+
+
+def g_ffdtune():
+    """FFDNet online finetune (test_ffdnet_ipol.py:248-334): lr 2e-6, update_per_iter 2
+    (two_stage_ADMM_Online_FFD_Warm.py:74-76), gate fires at k = 2 with interval_iter=2."""
+    net, sd = load_ref_ffdnet()
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=4)
+    warm = _tv_warm(y, Phi, 20)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=net,
+                                           show_iqa=True, demosaic_method='malvar2004', lr_=2e-6,
+                                           inital_iter=1, interval_iter=2, logf=logf, update_=True,
+                                           update_per_iter=2)
+    ref_it = np.stack(cap.iterates)
+    new_sd = {k: v.detach().clone() for k, v in res[5].state_dict().items()}
+    trace = []
+    onet = oracle_ffdnet(sd)
+    for p in onet.parameters():
+        p.requires_grad = True
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [4], [25 / 255], x0_bayer=warm, X_orig=orig,
+                          model_denoise=onet, lr=2e-6, inital_iter=1, interval_iter=2, update=True,
+                          update_per_iter=2, finetune_trace=trace)
+    check('finetune iterates', np.stack(o['theta_iterates']), ref_it)
+    osd = o['model'].state_dict()
+    for k in new_sd:
+        check(f'finetuned {k}', osd[k], new_sd[k])
+    delta = {k.replace('.', '_') + '_delta': (new_sd[k] - sd[k]).numpy() for k in new_sd}
+    print('   oracle finetune losses:', trace)
+    save('ffdnet_finetune_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta=ref_it, rgb=res[0],
+         losses=np.array(trace), **delta)
+
+
+def _ref_fastdvd(seed):
+    onet = ON.synth_fastdvdnet_weights(seed)
+    rnet = RefFastDVDnet(num_input_frames=5)
+    rnet.load_state_dict(onet.state_dict(), strict=True)
+    return torch.nn.DataParallel(rnet), torch.nn.DataParallel(copy.deepcopy(onet)), onet.state_dict()
+
+
+def g_fastdvd():
+    rnet, onet, sd = _ref_fastdvd(0)
+    rnet.eval()
+    onet.eval()
+    rng = np.random.default_rng(13)
+    # forward on an (H,W,3,B) cube: circular-window edge frames 0,1,6,7 are included (B = 8)
+    v = torch.from_numpy(rng.uniform(0, 1, (32, 48, 3, 8)).astype(np.float32))
+    ref = R.fastdvdnet_denoiser_full_tensor_v2(v, 8 / 255, None, None, rnet, True, 1e-6)
+    mine = OD.fastdvdnet_pass(v, 8 / 255, None, None, onet, 1e-6)
+    check('fastdvd forward cube', mine, ref)
+    save('fastdvd_forward', v=v, out=ref, sigma=np.float32(8 / 255))
+    # solver, sigma = [8/255] (two_stage_ADMM_Online_FastDVD_Warm.py:68-75), short: 4 its, rho = 0.55
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=5)
+    warm = _tv_warm(y, Phi, 20)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [4], False, [8 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rnet,
+                                           show_iqa=True, demosaic_method='malvar2004', logf=logf)
+    ref_it = np.stack(cap.iterates)
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+    check('two-stage FastDVDnet iterates', np.stack(o['theta_iterates']), ref_it)
+    save('fastdvdadmm_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta=ref_it, rgb=res[0], final=res[1],
+         psnr_all=res[4])
+    # finetune: gate at k = 2, once (update_times = 1), lr 2e-6, 2 Adam steps; NumPy noise captured
+    rnet, onet, sd = _ref_fastdvd(0)
+    seed_all()
+    st = np.random.get_state()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [4], False, [8 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rnet,
+                                           show_iqa=True, demosaic_method='malvar2004', lr_=2e-6, inital_iter=1,
+                                           interval_iter=2, logf=logf, update_=True, update_per_iter=2,
+                                           update_times=1)
+    ref_it = np.stack(cap.iterates)
+    np.random.set_state(st)
+    noise = np.random.normal(0, 5 / 255, (8, 3, 64, 64))   # the draw the reference made (first use of the RNG)
+    np.random.set_state(st)
+    trace = []
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                          lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=2, update_times=1,
+                          finetune_trace=trace)
+    check('FastDVDnet finetune iterates', np.stack(o['theta_iterates']), ref_it)
+    rsd, osd = res[5].state_dict(), o['model'].state_dict()
+    worst = max(rel(osd[k], rsd[k]) for k in rsd)
+    print(f'   finetuned weights worst rel-L2 {worst:.3e}; losses {trace}')
+    assert worst == 0.0
+    dn = {k.replace('.', '_') + '_dnorm': float(torch.norm(rsd[k].float() - sd[k.replace('module.', '', 1)].float()))
+          for k in rsd if k.endswith('weight') and rsd[k].dim() == 4}
+    save('fastdvd_finetune_64x64x8', theta=ref_it, rgb=res[0], noise=noise.astype(np.float64),
+         losses=np.array(trace), **dn)
+
+
+GROUPS = dict(weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+              ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    todo = sys.argv[1:] or list(GROUPS)
+    for g in todo:
+        print(f'== {g}')
+        GROUPS[g]()
+    print('all requested groups generated and oracle-checked')
