@@ -45,7 +45,9 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
 };
 
-template <int COB>
+// TAG only changes the kernel's symbol name (0 = body/tail layers, 1 = network head layer with its
+// short K) so that per-kernel profiler statistics of the body layers are not diluted by the head.
+template <int COB, int TAG>
 __global__ void __launch_bounds__(CV_THREADS, (COB <= 3 ? 2 : 1))
 conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk, float* __restrict__ out,
                   const float* __restrict__ residual, int CGin, int CGout, int CoutP_total, int nsplit,
@@ -181,13 +183,13 @@ conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk, f
     }
 }
 
-template <int COB>
+template <int COB, int TAG = 0>
 static int launch_conv(const float* in, const float* wpk, float* out, const float* residual, int n, int Cin,
                        int Cout, int h, int w, int flags, hipStream_t st) {
     using Cfg = ConvCfg<COB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8_kernel<COB>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8_kernel<COB, TAG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3, %zu B LDS): %s", Cfg::LDS_BYTES,
                                          hipGetErrorString(e));
@@ -196,7 +198,7 @@ static int launch_conv(const float* in, const float* wpk, float* out, const floa
     const int CoutP = round_up(Cout, 32);
     const int nsplit = CoutP / Cfg::COUTP;
     const dim3 grid((w + CV_TW - 1) / CV_TW, (h + CV_TH - 1) / CV_TH, n * nsplit);
-    hipLaunchKernelGGL((conv3x3_c8_kernel<COB>), grid, dim3(CV_THREADS), Cfg::LDS_BYTES, st, in, wpk, out, residual,
+    hipLaunchKernelGGL((conv3x3_c8_kernel<COB, TAG>), grid, dim3(CV_THREADS), Cfg::LDS_BYTES, st, in, wpk, out, residual,
                        Cin / 8, Cout / 8, CoutP, nsplit, h, w, flags);
     return launch_status("conv3x3_c8_kernel");
 }
@@ -246,7 +248,10 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
     const int CoutP = round_up(Cout, 32);
     SCIPNP_REQUIRE((long long)n * (CoutP / 32) <= 65535, "grid too large");
     hipStream_t st = (hipStream_t)s;
-    if (CoutP % 96 == 0) return launch_conv<3>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+    if (CoutP % 96 == 0) {
+        if (flags & 0x100) return launch_conv<3, 1>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+        return launch_conv<3>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
+    }
     if (CoutP % 128 == 0) return launch_conv<4>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
     if (CoutP % 64 == 0) return launch_conv<2>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
     return launch_conv<1>(in, packed_w, out, residual, n, Cin, Cout, h, w, flags, st);
@@ -257,7 +262,7 @@ int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const*
     SCIPNP_REQUIRE(in_c8 && out_c8 && packed && scratch0 && scratch1, "null pointer");
     SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
     float* buf[2] = {scratch0, scratch1};
-    int rc = scipnp_conv3x3_c8(in_c8, packed[0], buf[0], nullptr, B, 16, nc, M, N, 1, s);
+    int rc = scipnp_conv3x3_c8(in_c8, packed[0], buf[0], nullptr, B, 16, nc, M, N, 1 | 0x100, s);
     if (rc) return rc;
     int cur = 0;
     for (int l = 1; l < nb - 1; ++l) {

@@ -77,7 +77,30 @@ class FFDNetEngine:
             self.packed.append(ops.pack_conv3x3(w, b, Cin=cin, Cout=cout, device=self.device))
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
 
-    def forward(self, in_c8=None, out_c8=None):
+    def forward(self, in_c8=None, out_c8=None, events=None):
+        """12 conv launches on the current stream (same sequence as the C entry scipnp_ffdnet_forward).
+        `events`, if a list, receives (start, end) torch.cuda.Event pairs bracketing the nb-2 body layers
+        (bench.py's live roofline measurement)."""
+        in_c8 = self.in_c8 if in_c8 is None else in_c8
+        out_c8 = self.out_c8 if out_c8 is None else out_c8
+        B, M, N, nc = self.B, self.M, self.N, self.nc
+        buf = [s.view(B, nc // 8, M, N, 8) for s in self.scratch]
+        ops.conv3x3_c8(in_c8, self.packed[0], nc, relu=True, out=buf[0], head=True)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        cur = 0
+        for l in range(1, self.nb - 1):
+            ops.conv3x3_c8(buf[cur], self.packed[l], nc, relu=True, out=buf[cur ^ 1])
+            cur ^= 1
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        ops.conv3x3_c8(buf[cur], self.packed[self.nb - 1], 16, relu=False, out=out_c8)
+        return out_c8
+
+    def forward_c_entry(self, in_c8=None, out_c8=None):
+        """Same pass through the single C entry point scipnp_ffdnet_forward (what a C/C++ host would call)."""
         in_c8 = self.in_c8 if in_c8 is None else in_c8
         out_c8 = self.out_c8 if out_c8 is None else out_c8
         lib = _lib.load()

@@ -242,11 +242,11 @@ def pack_conv3x3(weight, bias=None, bn_scale=None, bn_shift=None, Cin=None, Cout
     return packed.to(device) if device is not None else packed
 
 
-def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None):
+def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False):
     n, cg, h, w, _ = x.shape
     if out is None:
         out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
-    flags = (1 if relu else 0) | (2 if residual is not None else 0)
+    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (0x100 if head else 0)
     _call('scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'), _p(out, 'out'), _p(residual, 'residual'),
           n, cg * 8, Cout, h, w, flags, _stream())
     return out

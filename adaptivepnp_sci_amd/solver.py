@@ -10,14 +10,14 @@ device->host copy for TV (the reference goes through NumPy every iteration, :153
 for the per-iteration PSNR (:274-279): squared-error partials are reduced on device and read
 back once after the last iteration, when the log lines are emitted.
 
+`AdmmRun` is the stepper both entry points (and bench.py) drive: one `step()` = one ADMM iteration.
+
 Documented deviations from the reference:
   * `demosaic_method` other than 'malvar2004' raises ValueError (the reference silently feeds
     zeros to the denoiser, :187-191);
   * `logf=None` is accepted (no-op writer); arrays may be NumPy or CUDA tensors;
   * log lines are printed after the loop instead of during it (identical text).
 """
-import math
-
 import numpy as np
 import torch
 
@@ -27,11 +27,12 @@ from .nets import FFDNetEngine
 
 F32 = torch.float32
 
-
 # Test/diagnostic hook: callable(k, mosaic (H,W,B) CUDA tensor) invoked after every iteration with the
 # iterate the reference reports (theta for the two-stage solver, x for the one-stage one).  Costs one
 # extra layout kernel per iteration when set; None in production.
 ITERATE_HOOK = None
+
+DENOISERS = ('tv', 'ffdnet_color', 'fastdvd_color')
 
 
 class _NullLog:
@@ -55,36 +56,139 @@ def _as_lists(sigma, iter_max):
     return sigma, iter_max
 
 
-class _Problem:
-    """Device-resident plane-major problem state shared by both solvers (reference :48-95 / :335-381)."""
+class AdmmRun:
+    """Device-resident state of one reconstruction and its per-iteration kernel sequence.
 
-    def __init__(self, y_bayer, Phi_bayer, x0_bayer, X_orig):
+    two_stage=True  : p = theta - b/rho, denominator alpha*rho + Phi_sum, b += x - theta, w dual on the
+                      RGB cube, reports theta                                   (reference :121-305)
+    two_stage=False : v = theta + b, denominator Phi_sum + gamma, b -= x - theta, reports x (:385-536)
+    """
+
+    def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
+                 show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
+                 update_per_iter=1, update_times=-1, logf=None):
+        if denoiser not in DENOISERS:
+            raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         _lib.load()
         _lib.require_gpu()
         self.device = torch.device('cuda', torch.cuda.current_device())
+        self.denoiser, self.two_stage, self.model = denoiser, two_stage, model
+        self.logf = logf or _NullLog()
         Phi = _dev(Phi_bayer, self.device)
         y = _dev(y_bayer, self.device)
         if Phi.dim() != 3 or y.shape != Phi.shape[:2] or Phi.shape[0] % 2 or Phi.shape[1] % 2:
             raise ValueError(f'expected y (H,W) and Phi (H,W,B) with even H,W; got {tuple(y.shape)} {tuple(Phi.shape)}')
         self.H, self.W, self.B = Phi.shape
         self.M, self.N = self.H // 2, self.W // 2
+        B, M, N, H, W = self.B, self.M, self.N, self.H, self.W
+        # ---- setup (reference :59-95 / :347-381)
         self.Phi = ops.mosaic_to_state(Phi)
         self.y = ops.y_to_meas(y)
         self.Phisum, x0 = ops.pm_setup(self.Phi, self.y, want_x0=x0_bayer is None)
         if x0_bayer is not None:
             x0 = ops.mosaic_to_state(_dev(x0_bayer, self.device))
-        self.theta = x0                               # start point; x and theta are one tensor in the reference
+        self.theta = x0                  # x and theta are ONE tensor in the reference until the first clip
         self.x = torch.empty_like(x0)
         self.b = torch.zeros_like(x0)
-        self.theta_raw = torch.empty_like(x0)
-        self.orig = None
-        self.orig_np = None
+        self.orig = self.orig_np = None
         if X_orig is not None:
             self.orig_np = X_orig if isinstance(X_orig, np.ndarray) else X_orig.detach().cpu().numpy()
             self.orig = ops.mosaic_to_state(_dev(X_orig, self.device))
+        self.iqa = bool(show_iqa and X_orig is not None)
         self.sse_rows = []
+        # ---- constants (reference :101-110; one-stage uses _lambda/gamma directly)
+        if two_stage:
+            self.alpha = 0.01 if denoiser == 'tv' else 1
+            self.rou = 0.55 if denoiser == 'fastdvd_color' else 1
+            self.tau = 100
+        else:
+            self._lambda, self.gamma = _lambda, gamma
+        self.lr_, self.inital_iter, self.interval_iter = lr_, inital_iter, interval_iter
+        self.update_, self.update_per_iter, self.update_times = update_, update_per_iter, update_times
+        self.update_i = 0
+        self.k = 0
+        self.out_rgb = None
+        self.profile_events = None       # bench.py: list receiving (start,end) events around the body convs
+        # ---- prior workspaces
+        if denoiser == 'tv':
+            self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
+            self.theta_raw = torch.empty_like(x0)
+        else:
+            self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
+            self.w = torch.zeros_like(self.x_rgb) if two_stage else None
+            self.out_store = torch.empty_like(self.x_rgb)
+            if denoiser == 'ffdnet_color':
+                self.eng = FFDNetEngine(model, B, M, N, self.device)
+            else:
+                from .fastdvd import FastDVDEngine
+                self.eng = FastDVDEngine(model, B, H, W, self.device)
+                self.rgb_w = torch.empty_like(self.x_rgb)
 
-    def new_sse(self, nblocks):
+    # ------------------------------------------------------------------ one ADMM iteration
+    def step(self, nsig, last=False):
+        B, M, N = self.B, self.M, self.N
+        k = self.k
+        if self.two_stage:
+            inv_rho = 1 / self.rou
+            ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 0, inv_rho, self.alpha * self.rou,
+                           out=self.x)
+            coef, sign, which = inv_rho, +1.0, 0
+        else:
+            ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x)
+            coef, sign, which = -1.0, -1.0, 1
+        if self.denoiser == 'tv':
+            ops.tv_chambolle(self.x.view(4 * B, M, N), self.b.view(4 * B, M, N), coef,
+                             self.theta_raw.view(4 * B, M, N), self.plan, 0.1)
+            part = self._new_sse(ops.sse_nblocks(self.x.numel())) if self.iqa else None
+            ops.pm_dual_update(self.theta_raw, self.x, self.theta, self.b, sign, self.orig if self.iqa else None,
+                               part, which=which)
+        else:
+            self._cnn_step(nsig, k, last)
+        if ITERATE_HOOK is not None:
+            ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
+        self.k += 1
+
+    def _cnn_step(self, nsig, k, last):
+        B, M, N = self.B, self.M, self.N
+        gate = bool(self.update_ and k > self.inital_iter and k % self.interval_iter == 0)
+        if self.two_stage:
+            b_in, inv_rho, inv_tau, w = self.b, 1 / self.rou, 1 / self.tau, self.w
+        else:
+            # one-stage CNN branches (:439-496): demosaic(x - b), no w dual, b -= x - theta.  Run the
+            # kernels on -b:  x + 1*(-b) = x - b exactly, and (-b) + (x - theta) = -(b - (x - theta)).
+            b_in, inv_rho, inv_tau, w = self.b.neg(), 1.0, 0.0, None
+        if self.denoiser == 'ffdnet_color':
+            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, self.eng.in_c8, inv_rho, inv_tau, nsig)
+            if gate:
+                from .finetune import ffdnet_online_finetune
+                ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,
+                                       logf=self.logf)
+            self.eng.forward(events=self.profile_events)
+            src_rgb, src_c8 = None, self.eng.out_c8
+        else:
+            net_in = self.rgb_w if self.two_stage else self.x_rgb
+            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, self.rgb_w if self.two_stage else None, None,
+                               inv_rho, inv_tau, nsig)
+            if gate and self.two_stage and (self.update_i < self.update_times or self.update_times < 0):
+                from .finetune import fastdvdnet_online_finetune
+                fastdvdnet_online_finetune(self.model, self.eng, net_in, self.y, self.Phi, nsig, self.lr_,
+                                           self.update_per_iter, logf=self.logf)
+                self.update_i += 1
+            src_rgb, src_c8 = self.eng.forward(net_in, nsig), None
+        iqa_here = self.iqa and self.two_stage
+        part = self._new_sse(ops.post_nblocks(M, N, B)) if iqa_here else None
+        ops.pm_post_denoise(src_rgb, src_c8, self.out_store if (last and src_c8 is not None) else None,
+                            self.x, self.x_rgb if self.two_stage else None, self.theta, b_in, w, k == 0,
+                            self.orig if iqa_here else None, part)
+        if not self.two_stage:
+            self.b = b_in.neg()
+            if self.iqa:
+                ops.sse_partials(self.orig, self.x, self._new_sse(ops.sse_nblocks(self.x.numel())))
+        if last:
+            self.out_rgb = self.out_store if src_c8 is not None else src_rgb
+
+    # ------------------------------------------------------------------ reporting
+    def _new_sse(self, nblocks):
         t = torch.empty(nblocks, dtype=torch.float64, device=self.device)
         self.sse_rows.append(t)
         return t
@@ -96,6 +200,22 @@ class _Problem:
         sse = torch.stack([r.sum() for r in self.sse_rows]).cpu().numpy()
         n = float(self.H) * self.W * self.B
         return [float(10 * np.log10(1.0 / (s / n))) for s in sse]
+
+    def result_mosaic(self):
+        """(H,W,B) CUDA tensor of the reported iterate (theta two-stage, x one-stage; reference :312-315 / :538-541)."""
+        return ops.state_to_mosaic(self.theta if self.two_stage else self.x)
+
+    def final_report(self, mosaic_np):
+        if self.orig_np is None:
+            return [], []
+        return psnr_frames(self.orig_np, mosaic_np), ssim_frames(self.orig_np, mosaic_np)
+
+
+def _run_schedule(run, sigma, iter_max):
+    total = sum(iter_max)
+    for idx, nsig in enumerate(sigma):
+        for _ in range(iter_max[idx]):
+            run.step(nsig, last=(run.k == total - 1))
 
 
 def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, two_stage):
@@ -125,13 +245,9 @@ def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, tw
                 logf.write('  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255 \n'.format(name, k + 1, nsig * 255))
 
 
-def _final_report(P, mosaic_np):
-    if P.orig_np is None:
-        return [], []
-    return psnr_frames(P.orig_np, mosaic_np), ssim_frames(P.orig_np, mosaic_np)
-
-
-def _check_demosaic(demosaic_method, model_demosaic=None):
+def _check_demosaic(denoiser, demosaic_method, model_demosaic=None):
+    if denoiser == 'tv':
+        return
     if model_demosaic is not None:
         raise NotImplementedError('deep demosaicking (DDnet) is a "next" row of the scope table; pass model_demosaic=None')
     if demosaic_method != 'malvar2004':
@@ -146,79 +262,24 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                inital_iter=1, interval_iter=5, logf=None, useGPU=True, update_=False,
                                update_per_iter=1, close_form_demosaic=False,
                                large=False, update_times=-1, args=None):
-    if denoiser not in ('tv', 'ffdnet_color', 'fastdvd_color'):
+    if denoiser not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
     if close_form_demosaic:
         raise NotImplementedError('close_form_demosaic is a "next" row of the scope table')
+    _check_demosaic(denoiser, demosaic_method, model_demosaic)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
-    P = _Problem(y_bayer, Phi_bayer, x0_bayer, X_orig)
-    iqa = bool(show_iqa and X_orig is not None)
-    alpha = 0.01 if denoiser == 'tv' else 1
-    rou = 0.55 if denoiser == 'fastdvd_color' else 1
-    tau = 100
-    inv_rho, inv_tau = 1 / rou, 1 / tau
-    B, M, N, H, W = P.B, P.M, P.N, P.H, P.W
-    total_iters = sum(iter_max)
-    out_rgb = None
-    if denoiser == 'tv':
-        plan = ops.TvPlan(M, N, 4 * B, 5, P.device)
-    else:
-        _check_demosaic(demosaic_method, model_demosaic)
-        w = torch.zeros(B, 3, H, W, dtype=F32, device=P.device)
-        x_rgb = torch.empty_like(w)
-        out_rgb = torch.empty_like(w)
-        if denoiser == 'ffdnet_color':
-            eng = FFDNetEngine(model_denoise, B, M, N, P.device)
-        else:
-            from .fastdvd import FastDVDEngine
-            eng = FastDVDEngine(model_denoise, B, H, W, P.device)
-            rgb_w = torch.empty_like(w)
-    k = 0
-    update_i = 0
-    for idx, nsig in enumerate(sigma):
-        for it in range(iter_max[idx]):
-            ops.pm_project(P.theta, P.b, P.Phi, P.y, P.Phisum, 0, inv_rho, alpha * rou, out=P.x)
-            last = (k == total_iters - 1)
-            if denoiser == 'tv':
-                ops.tv_chambolle(P.x.view(4 * B, M, N), P.b.view(4 * B, M, N), inv_rho,
-                                 P.theta_raw.view(4 * B, M, N), plan, 0.1)
-                nb = ops.sse_nblocks(P.x.numel()) if iqa else 0
-                ops.pm_dual_update(P.theta_raw, P.x, P.theta, P.b, +1.0, P.orig if iqa else None,
-                                   P.new_sse(nb) if iqa else None, which=0)
-            else:
-                gate = bool(update_ and k > inital_iter and k % interval_iter == 0)
-                if denoiser == 'ffdnet_color':
-                    ops.pm_pre_denoise(P.x, P.b, w, x_rgb, None, eng.in_c8, inv_rho, inv_tau, nsig)
-                    if gate:
-                        from .finetune import ffdnet_online_finetune
-                        ffdnet_online_finetune(model_denoise, None, P.y, P.Phi, nsig, lr_, update_per_iter,
-                                               engine=eng, logf=logf)
-                    eng.forward()
-                    src_rgb, src_c8 = None, eng.out_c8
-                else:
-                    ops.pm_pre_denoise(P.x, P.b, w, x_rgb, rgb_w, None, inv_rho, inv_tau, nsig)
-                    if gate and (update_i < update_times or update_times < 0):
-                        from .finetune import fastdvdnet_online_finetune
-                        fastdvdnet_online_finetune(model_denoise, rgb_w, P.y, P.Phi, nsig, lr_, update_per_iter,
-                                                   engine=eng, logf=logf)
-                        update_i += 1
-                    src_rgb, src_c8 = eng.forward(rgb_w, nsig), None
-                ops.pm_post_denoise(src_rgb, src_c8, out_rgb if (last and src_c8 is not None) else None,
-                                    P.x, x_rgb, P.theta, P.b, w, k == 0, P.orig if iqa else None,
-                                    P.new_sse(ops.post_nblocks(M, N, B)) if iqa else None)
-                if last and src_rgb is not None:
-                    out_rgb = src_rgb
-            if ITERATE_HOOK is not None:
-                ITERATE_HOOK(k, ops.state_to_mosaic(P.theta))
-            k += 1
-    psnr_all = P.psnr_all()
-    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, iqa, True)
-    x_bayer_np = ops.state_to_mosaic(P.theta).cpu().numpy()
-    psnr_, ssim_ = _final_report(P, x_bayer_np)
+    run = AdmmRun(y_bayer, Phi_bayer, denoiser, True, x0_bayer, X_orig, model_denoise, show_iqa, lr_=lr_,
+                  inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
+                  update_per_iter=update_per_iter, update_times=update_times, logf=logf)
+    _run_schedule(run, sigma, iter_max)
+    psnr_all = run.psnr_all()
+    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True)
+    x_bayer_np = run.result_mosaic().cpu().numpy()
+    psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
         return x_bayer_np, psnr_, ssim_, psnr_all
-    return ops.rgb_to_cube(out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model_denoise, model_demosaic
+    return ops.rgb_to_cube(run.out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model_denoise, model_demosaic
 
 
 def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
@@ -228,71 +289,22 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                     lr_=0.000001,
                                     inital_iter=1, interval_iter=5, logf=None, useGPU=True, device=0,
                                     update_=False, update_per_iter=1):
-    if denoiser not in ('tv', 'ffdnet_color', 'fastdvd_color'):
+    if denoiser not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+    _check_demosaic(denoiser, demosaic_method)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
-    P = _Problem(y_bayer, Phi_bayer, x0_bayer, X_orig)
-    iqa = bool(show_iqa and X_orig is not None)
-    B, M, N, H, W = P.B, P.M, P.N, P.H, P.W
-    total_iters = sum(iter_max)
-    out_rgb = None
-    if denoiser == 'tv':
-        plan = ops.TvPlan(M, N, 4 * B, 5, P.device)
-    else:
-        _check_demosaic(demosaic_method)
-        x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=P.device)
-        out_rgb = torch.empty_like(x_rgb)
-        if denoiser == 'ffdnet_color':
-            eng = FFDNetEngine(model, B, M, N, P.device)
-        else:
-            from .fastdvd import FastDVDEngine
-            eng = FastDVDEngine(model, B, H, W, P.device)
-    k = 0
-    for idx, nsig in enumerate(sigma):
-        for it in range(iter_max[idx]):
-            ops.pm_project(P.theta, P.b, P.Phi, P.y, P.Phisum, 1, _lambda, gamma, out=P.x)
-            last = (k == total_iters - 1)
-            if denoiser == 'tv':
-                ops.tv_chambolle(P.x.view(4 * B, M, N), P.b.view(4 * B, M, N), -1.0,
-                                 P.theta_raw.view(4 * B, M, N), plan, 0.1)
-                nb = ops.sse_nblocks(P.x.numel()) if iqa else 0
-                ops.pm_dual_update(P.theta_raw, P.x, P.theta, P.b, -1.0, P.orig if iqa else None,
-                                   P.new_sse(nb) if iqa else None, which=1)
-            else:
-                # CNN branches of the one-stage solver (:439-496): demosaic(x - b), no w, b -= x - theta;
-                # at k = 0 x and theta are one tensor, so x becomes the raw denoiser output (reported, :509)
-                gate = bool(update_ and k > inital_iter and k % interval_iter == 0)
-                neg_b = P.b.neg()
-                if denoiser == 'ffdnet_color':
-                    ops.pm_pre_denoise(P.x, neg_b, None, x_rgb, None, eng.in_c8, 1.0, 0.0, nsig)
-                    if gate:
-                        from .finetune import ffdnet_online_finetune
-                        ffdnet_online_finetune(model, None, P.y, P.Phi, nsig, lr_, update_per_iter, engine=eng,
-                                               logf=logf)
-                    eng.forward()
-                    src_rgb, src_c8 = None, eng.out_c8
-                else:
-                    ops.pm_pre_denoise(P.x, neg_b, None, x_rgb, None, None, 1.0, 0.0, nsig)
-                    src_rgb, src_c8 = eng.forward(x_rgb, nsig), None
-                # post kernel computes b_tmp = (-b) + (x_eff - theta) = -(b - (x_eff - theta)) -> negate back
-                ops.pm_post_denoise(src_rgb, src_c8, out_rgb if (last and src_c8 is not None) else None,
-                                    P.x, None, P.theta, neg_b, None, k == 0, None, None)
-                P.b = neg_b.neg()
-                if last and src_rgb is not None:
-                    out_rgb = src_rgb
-                if iqa:
-                    ops.sse_partials(P.orig, P.x, P.new_sse(ops.sse_nblocks(P.x.numel())))
-            if ITERATE_HOOK is not None:
-                ITERATE_HOOK(k, ops.state_to_mosaic(P.x))
-            k += 1
-    psnr_all = P.psnr_all()
-    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, iqa, False)
-    x_bayer_np = ops.state_to_mosaic(P.x).cpu().numpy()
-    psnr_, ssim_ = _final_report(P, x_bayer_np)
+    run = AdmmRun(y_bayer, Phi_bayer, denoiser, False, x0_bayer, X_orig, model, show_iqa, _lambda=_lambda, gamma=gamma,
+                  lr_=lr_, inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
+                  update_per_iter=update_per_iter, logf=logf)
+    _run_schedule(run, sigma, iter_max)
+    psnr_all = run.psnr_all()
+    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, False)
+    x_bayer_np = run.result_mosaic().cpu().numpy()
+    psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
         return x_bayer_np, psnr_, ssim_, psnr_all
-    return ops.rgb_to_cube(out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model
+    return ops.rgb_to_cube(run.out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model
 
 
 def admm_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):

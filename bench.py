@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ADMM iterations/s (and reconstructed frames/s) of the two-stage PnP-ADMM +
+FFDNet-colour solver on a 512x512x8 Bayer cube per GPU (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One step = one ADMM iteration over one cube (projection, mosaic+Malvar+w fusion, FFDNet on 8 frames,
+theta/b/w updates, on-device PSNR partials) -- exactly `AdmmRun.step`, the code path behind
+`twoStageAdmm_denoise_bayer`.  Inputs are resident in HBM when the timed region starts.  With N GPUs every
+rank reconstructs its own cube (weak scaling, no collective inside the solve) and the (H,W,B)
+mosaics are gathered to rank 0 with ONE RCCL gather at the end of the timed region.
+
+The JSON line also carries
+  roofline     : the dominant kernel (FFDNet body layer conv3x3, fp32 MFMA), FLOP/s measured with
+                 HIP events around the body-layer launches inside the timed region;
+  cpu_baseline : the CPU oracle (bit-exact restatement of the reference) timed on this host on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 512
+B = 8
+SIGMA = 25 / 255
+NB, NC = 12, 96
+BODY_FLOP_PER_LAUNCH = 2.0 * 9 * NC * NC * (H // 2) * (W // 2) * B              # one body layer, 8 frames
+FFDNET_FLOP_PER_ITER = 2.0 * 9 * (13 * NC + (NB - 2) * NC * NC + NC * 12) * (H // 2) * (W // 2) * B
+PEAK_FP32_MFMA = 157.3e12                                                       # MI355X_MICROARCH.md
+
+
+def load_weights():
+    from adaptivepnp_sci_amd.nets import FFDNet
+    net = FFDNet()
+    path = os.path.join(ROOT, 'tests', 'golden', 'ffdnet_color_weights.npz')
+    if os.path.exists(path):
+        g = np.load(path)
+        net.load_state_dict({k: torch.from_numpy(g[k]) for k in g.files})
+        return net, 'ffdnet_color.pth (reference weights, committed fixture)'
+    torch.manual_seed(0)
+    return net, 'random init'
+
+
+def cpu_baseline(y, Phi, warm, orig, sd, iters):
+    from oracle import nets as ON
+    from oracle import solver as OS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(sd)
+    onet.eval()
+    with torch.no_grad():
+        OS.two_stage_admm(y[:64, :64], Phi[:64, :64], 'ffdnet_color', [1], [SIGMA], x0_bayer=warm[:64, :64],
+                          model_denoise=onet)                                   # warm-up of the CPU libraries
+        t0 = time.perf_counter()
+        OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+        dt = time.perf_counter() - t0
+    return dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port',
+                sample=f'{iters} two-stage ADMM+FFDNet iterations of the same 512x512x8 cube, PyTorch-CPU oracle, '
+                       f'{cores} threads ({dt:.1f} s)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=25)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    net, wdesc = load_weights()
+    y, Phi, orig = synth.make_problem(H, W, B, seed=rank)
+    # TV warm start, as the reference driver does (two_stage_ADMM_Online_FFD_Warm.py:259-263); untimed
+    tv = AdmmRun(y, Phi, 'tv', False)
+    for _ in range(40):
+        tv.step(0)
+    warm = tv.result_mosaic()
+    y_d, Phi_d, orig_d = (torch.from_numpy(a).to(dev) for a in (y, Phi, orig))
+    run = AdmmRun(y_d, Phi_d, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig_d, model=net)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.step(SIGMA)
+    events = []
+    run.profile_events = events
+    gathered = None
+    if dist is not None and rank == 0:
+        gathered = [torch.empty(H, W, B, device=dev) for _ in range(world)]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step(SIGMA)
+    mosaic = run.result_mosaic()
+    if dist is not None:
+        dist.gather(mosaic, gathered, dst=0)          # the single RCCL collective of the job
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    body_ms = [a.elapsed_time(b) for a, b in events]
+    body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
+    psnr = run.psnr_all()
+    if rank == 0:
+        iters_per_s = world * args.steps / dt
+        achieved = BODY_FLOP_PER_LAUNCH / body_launch_s
+        line = {
+            'metric': 'admm_iters_per_s', 'value': iters_per_s, 'unit': 'ADMM iterations/s',
+            'frames_per_s': iters_per_s * B,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': f'synthetic (seeded moving-sinusoid cube, Bernoulli(0.5) mask, noise-free y); weights: {wdesc}',
+            'config': {'workload': 'two-stage ADMM + FFDNet-color, one 512x512x8 Bayer cube per GPU, Malvar demosaic, '
+                                   'sigma=25/255, TV warm start, per-iteration PSNR on device', 'cube': [H, W, B],
+                       'parallelism': f'{world} independent cube(s), one per GPU, one RCCL gather at the end'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': PEAK_FP32_MFMA / 1e12, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA, 'traffic': None,
+                         'kernel': 'conv3x3_c8_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256, '
+                                   'v_mfma_f32_32x32x2_f32)',
+                         'flop_per_launch': BODY_FLOP_PER_LAUNCH, 'avg_launch_ms': body_launch_s * 1e3,
+                         'denoiser_flop_per_iter': FFDNET_FLOP_PER_ITER},
+            'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd = net.state_dict()
+            line['cpu_baseline'] = cpu_baseline(y, Phi, warm.cpu().numpy(), orig, sd, args.cpu_iters)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -143,7 +143,8 @@ int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, 
  * in/out in c8 layout [n][C/8][h][w][8]; weights pre-packed by scipnp_pack_conv3x3_weights.
  * fp32 operands, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products, fmaf chain).
  * Cin, Cout multiples of 8 (pad with zero channels); stride 1, zero padding 1.
- * flags: bit0 = ReLU, bit1 = add `residual` (c8, same shape as out) before the activation.
+ * flags: bit0 = ReLU, bit1 = add `residual` (c8, same shape as out) before the activation,
+ *        bit8 = "head layer" tag (same arithmetic, separate kernel symbol for profiling).
  * -- replaces nn.Conv2d(...,3,1,1)+ReLU at models/basicblock.py:61-98 as used by network_ffdnet.py:46-48
  *    and the CvBlock/UpBlock/OutputCvBlock convs of packages/fastdvdnet/models.py:16-89. */
 size_t scipnp_conv3x3_packed_floats(int Cin, int Cout);

@@ -1,0 +1,274 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle and the
+golden vectors generated from the reference.  Tolerances are written next to each check:
+streaming kernels are expected BIT-EXACT (same fp32 operations in the same order as the
+reference's PyTorch expressions); the Malvar correlations, TV and the MFMA convolutions differ from
+the CPU libraries only in summation order -> tight relative-L2 bounds."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_gold, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def planes_to_state(p):      # (M,N,B,4) -> [B][4][M][N]
+    return p.permute(2, 3, 0, 1).contiguous()
+
+
+def state_to_planes(s):
+    return s.permute(2, 3, 0, 1).contiguous()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from adaptivepnp_sci_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize('tag', ['8x8x8', '32x32x8'])
+def test_reference_layout_ops_bit_exact(ops, tag):
+    g = load_gold('ops_' + tag)
+    theta, b, Phi, y, Ps = (dev(g[k]) for k in ('theta', 'b', 'Phi', 'y', 'Phisum'))
+    assert torch.equal(ops.phisum(Phi).cpu(), torch.from_numpy(g['Phisum']))
+    assert torch.equal(ops.A_(theta, Phi).cpu(), torch.from_numpy(g['A_theta']))
+    assert torch.equal(ops.At_(y, Phi).cpu(), torch.from_numpy(g['At_y']))
+    x2 = ops.proj_twostage(theta, b, Phi, y, Ps, 1.0, 1.0)
+    assert torch.equal(x2.cpu(), torch.from_numpy(g['x_two_stage']))            # bit-exact
+    x2r = ops.proj_twostage(theta, b, Phi, y, Ps, 1 / 0.55, 1 * 0.55)
+    assert torch.equal(x2r.cpu(), torch.from_numpy(g['x_two_stage_rho055']))
+    x1 = ops.proj_onestage(theta, b, Phi, y, Ps, 1.0, 0.01)
+    assert torch.equal(x1.cpu(), torch.from_numpy(g['x_one_stage']))
+    # in place (x aliases theta), as the reference's first iteration does
+    th2 = theta.clone()
+    ops.proj_twostage(th2, b, Phi, y, Ps, 1.0, 1.0, out=th2)
+    assert torch.equal(th2.cpu(), torch.from_numpy(g['x_two_stage']))
+
+
+def test_reference_layout_rejects_odd_B(ops):
+    g = load_gold('ops_12x20x5')
+    Phi = dev(g['Phi'])
+    with pytest.raises(ValueError):
+        ops.phisum(Phi)
+
+
+@pytest.mark.parametrize('tag', ['8x8x8', '32x32x8', '12x20x5'])
+def test_plane_major_projection_bit_exact(ops, tag):
+    g = load_gold('ops_' + tag)
+    theta, b, Phi = (planes_to_state(dev(g[k])) for k in ('theta', 'b', 'Phi'))
+    y = dev(g['y']).permute(2, 0, 1).contiguous()
+    Ps_ref = torch.from_numpy(g['Phisum']).permute(2, 0, 1).contiguous()
+    Ps, x0 = ops.pm_setup(Phi, y)
+    assert torch.equal(Ps.cpu(), Ps_ref)
+    assert torch.equal(state_to_planes(x0).cpu(), torch.from_numpy(g['At_y']))
+    out = torch.empty_like(theta)
+    ops.pm_project(theta, b, Phi, y, Ps, 0, 1.0, 1.0, out)
+    assert torch.equal(state_to_planes(out).cpu(), torch.from_numpy(g['x_two_stage']))
+    ops.pm_project(theta, b, Phi, y, Ps, 0, 1 / 0.55, 0.55, out)
+    assert torch.equal(state_to_planes(out).cpu(), torch.from_numpy(g['x_two_stage_rho055']))
+    ops.pm_project(theta, b, Phi, y, Ps, 1, 1.0, 0.01, out)
+    assert torch.equal(state_to_planes(out).cpu(), torch.from_numpy(g['x_one_stage']))
+    th2 = theta.clone()
+    ops.pm_project(th2, b, Phi, y, Ps, 1, 1.0, 0.01, th2)      # in place
+    assert torch.equal(state_to_planes(th2).cpu(), torch.from_numpy(g['x_one_stage']))
+
+
+def test_layout_conversions_bit_exact(ops):
+    g = load_gold('bayer_12x20x5')
+    mos = dev(g['mosaic'])
+    rng = np.random.default_rng(0)
+    # reference layout split/merge need B in {1,2,4,8,16}: use an 8-frame cube
+    mos8 = dev(rng.uniform(size=(12, 20, 8)).astype(np.float32))
+    from oracle import sci_ops as OO
+    pl = ops.bayer_split(mos8)
+    assert torch.equal(pl.cpu(), OO.bayer_split(mos8.cpu()))
+    assert torch.equal(ops.bayer_merge(pl).cpu(), mos8.cpu())
+    # plane-major (any B)
+    st = ops.mosaic_to_state(mos)
+    assert torch.equal(state_to_planes(st).cpu(), torch.from_numpy(g['planes']))
+    assert torch.equal(ops.state_to_mosaic(st).cpu(), mos.cpu())
+    yy = dev(rng.uniform(size=(12, 20)).astype(np.float32))
+    assert torch.equal(ops.y_to_meas(yy).cpu(), OO.bayer_split(yy.cpu()).permute(2, 0, 1))
+    cube = dev(rng.uniform(size=(12, 20, 3, 5)).astype(np.float32))
+    rgb = ops.cube_to_rgb(cube)
+    assert torch.equal(rgb.cpu(), cube.cpu().permute(3, 2, 0, 1))
+    assert torch.equal(ops.rgb_to_cube(rgb).cpu(), cube.cpu())
+
+
+def test_tv_chambolle_matches_skimage_golden(ops):
+    g = load_gold('tv_chambolle')
+    v = dev(g['v']).permute(2, 0, 1).contiguous()     # (C, M, N)
+    C_, M, N = v.shape
+    for key, w, n in (('w01_n5', 0.1, 5), ('w01_n50', 0.1, 50), ('w003_n5', 0.03, 5)):
+        plan = ops.TvPlan(M, N, C_, n, v.device)
+        out = torch.empty_like(v)
+        ops.tv_chambolle(v, None, 0.0, out, plan, w)
+        ref = torch.from_numpy(g['out_' + key]).permute(2, 0, 1)
+        stop = plan.stop_iter.cpu().numpy()
+        assert (stop == g['stop_' + key]).all(), (key, stop, g['stop_' + key])   # incl. early-stopping channels
+        # same fp32 operations per pixel as skimage; only the energy sums differ (they do not enter `out`)
+        assert rel_l2(out.cpu().numpy(), ref.numpy()) == 0.0, key
+
+
+def test_tv_fused_input_and_ragged_size(ops):
+    from oracle.tv_chambolle import tv_chambolle_multichannel
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 2, (37, 45, 6)).astype(np.float32)
+    b = rng.normal(0, 0.3, (37, 45, 6)).astype(np.float32)
+    coef = np.float32(1 / 0.55)
+    ref, stops, _ = tv_chambolle_multichannel(x + coef * b, 0.1, n_iter_max=5, return_info=True)
+    xs, bs = dev(x).permute(2, 0, 1).contiguous(), dev(b).permute(2, 0, 1).contiguous()
+    plan = ops.TvPlan(37, 45, 6, 5, xs.device)
+    out = torch.empty_like(xs)
+    ops.tv_chambolle(xs, bs, float(coef), out, plan, 0.1)
+    assert rel_l2(out.permute(1, 2, 0).cpu().numpy(), ref) == 0.0
+    assert (plan.stop_iter.cpu().numpy() == stops).all()
+
+
+@pytest.mark.parametrize('tag', ['16x16', '64x64', '8x24'])
+def test_malvar_pre_denoise(ops, tag):
+    g = load_gold('malvar')
+    cfa = g['cfa_' + tag]
+    H, W = cfa.shape
+    B = 3
+    rng = np.random.default_rng(1)
+    mos = np.stack([cfa, rng.uniform(0, 1, (H, W)).astype(np.float32), cfa[::-1].copy()], -1)
+    from oracle.malvar import malvar_demosaic_cube
+    ref = malvar_demosaic_cube(torch.from_numpy(mos))            # (H,W,3,B)
+    assert rel_l2(ref[..., 0].numpy(), g['rgb_' + tag]) == 0.0   # oracle == reference golden
+    x = ops.mosaic_to_state(dev(mos))
+    x_rgb = torch.empty(B, 3, H, W, device='cuda')
+    ops.pm_pre_denoise(x, None, None, x_rgb, None, None, 1.0, 0.0, 0.0)
+    got = ops.rgb_to_cube(x_rgb).cpu().numpy()
+    # CFA sites are copied exactly; interpolated sites: 5x5 fp32 correlation, summation order only
+    assert rel_l2(got, ref.numpy()) < 2e-7
+    assert np.abs(got - ref.numpy()).max() < 1e-6
+
+
+def test_pre_post_denoise_fusion(ops):
+    from oracle import sci_ops as OO
+    from oracle.malvar import malvar_demosaic_cube
+    rng = np.random.default_rng(2)
+    M, N, B = 12, 40, 4
+    H, W = 2 * M, 2 * N
+    xp = torch.from_numpy(rng.uniform(0, 1, (M, N, B, 4)).astype(np.float32))
+    bp = torch.from_numpy(rng.normal(0, 0.1, (M, N, B, 4)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.5, (H, W, 3, B)).astype(np.float32))
+    inv_rho, inv_tau, sigma = np.float32(1 / 0.55), np.float32(1 / 100), 25 / 255
+    mosaic = OO.bayer_merge(xp + float(inv_rho) * bp)
+    x_rgb_ref = malvar_demosaic_cube(mosaic)
+    in_ref = x_rgb_ref - float(inv_tau) * w
+    x, b = planes_to_state(xp.cuda()), planes_to_state(bp.cuda())
+    w_d = ops.cube_to_rgb(w.cuda())
+    x_rgb = torch.empty(B, 3, H, W, device='cuda')
+    rgb_w = torch.empty_like(x_rgb)
+    c8 = torch.empty(B, 2, M, N, 8, device='cuda')
+    ops.pm_pre_denoise(x, b, w_d, x_rgb, rgb_w, c8, inv_rho, inv_tau, sigma)
+    assert rel_l2(ops.rgb_to_cube(x_rgb).cpu().numpy(), x_rgb_ref.numpy()) < 2e-7
+    assert rel_l2(ops.rgb_to_cube(rgb_w).cpu().numpy(), in_ref.numpy()) < 2e-7
+    # c8 = pixel-unshuffle(rgb_w) ++ sigma map ++ zeros  (reference network_ffdnet.py:61-64)
+    nchw = ops.from_c8(c8)                                   # (B,16,M,N)
+    un = rgb_w.reshape(B, 3, M, 2, N, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 12, M, N)
+    assert torch.equal(nchw[:, :12], un)
+    assert torch.equal(nchw[:, 12], torch.full((B, M, N), np.float32(sigma), device='cuda'))
+    assert (nchw[:, 13:] == 0).all()
+
+    # ---- post: theta gather, clip, duals, SSE; both the planar and the c8 (pre pixel-shuffle) sources
+    out_cube = torch.from_numpy(rng.uniform(-0.2, 1.2, (H, W, 3, B)).astype(np.float32))
+    orig = torch.from_numpy(rng.uniform(0, 1, (M, N, B, 4)).astype(np.float32))
+    raw = OO.rgb_to_bayer_planes(out_cube)
+    th_ref = torch.clip(raw, 0, 1)
+    for alias in (False, True):
+        b_ref = bp + ((raw if alias else xp) - th_ref)
+        w_ref = w + (x_rgb_ref - out_cube)
+        for src in ('rgb', 'c8'):
+            theta = torch.empty_like(x)
+            b2, w2, x2 = b.clone(), w_d.clone(), x.clone()
+            xr = ops.cube_to_rgb(x_rgb_ref.cuda())
+            out_rgb = ops.cube_to_rgb(out_cube.cuda())
+            part = torch.empty(ops.post_nblocks(M, N, B), dtype=torch.float64, device='cuda')
+            store = torch.empty_like(out_rgb)
+            if src == 'rgb':
+                ops.pm_post_denoise(out_rgb, None, store, x2, xr, theta, b2, w2, alias, planes_to_state(orig.cuda()), part)
+            else:
+                un = out_rgb.reshape(B, 3, M, 2, N, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 12, M, N)
+                oc8 = ops.to_c8(un)
+                ops.pm_post_denoise(None, oc8, store, x2, xr, theta, b2, w2, alias, planes_to_state(orig.cuda()), part)
+            assert torch.equal(state_to_planes(theta).cpu(), th_ref)             # bit-exact
+            assert torch.equal(state_to_planes(b2).cpu(), b_ref)
+            assert torch.equal(ops.rgb_to_cube(w2).cpu(), w_ref)
+            assert torch.equal(store, out_rgb)
+            if alias:
+                assert torch.equal(state_to_planes(x2).cpu(), raw)
+            sse_ref = float(((orig - th_ref).double() ** 2).sum())
+            assert abs(float(part.sum()) - sse_ref) <= 1e-9 * sse_ref
+
+
+def test_dual_update_and_sse(ops):
+    rng = np.random.default_rng(3)
+    B, M, N = 8, 16, 24
+    raw = torch.from_numpy(rng.uniform(-0.3, 1.3, (B, 4, M, N)).astype(np.float32))
+    x = torch.from_numpy(rng.uniform(0, 1, (B, 4, M, N)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(0, 0.1, (B, 4, M, N)).astype(np.float32))
+    orig = torch.from_numpy(rng.uniform(0, 1, (B, 4, M, N)).astype(np.float32))
+    th_ref = torch.clip(raw, 0, 1)
+    for sign, which in ((+1.0, 0), (-1.0, 1)):
+        theta = torch.empty_like(raw).cuda()
+        b2 = b.clone().cuda()
+        part = torch.empty(ops.sse_nblocks(raw.numel()), dtype=torch.float64, device='cuda')
+        ops.pm_dual_update(raw.cuda(), x.cuda(), theta, b2, sign, orig.cuda(), part, which)
+        assert torch.equal(theta.cpu(), th_ref)
+        assert torch.equal(b2.cpu(), b + (x - th_ref) if sign > 0 else b - (x - th_ref))
+        rep = th_ref if which == 0 else x
+        ref = float((((orig - rep) ** 2).double()).sum())
+        assert abs(float(part.sum()) - ref) <= 1e-12 * ref
+    assert abs(ops.sse(orig.cuda(), x.cuda()) - float((((orig - x) ** 2).double()).sum())) < 1e-9
+
+
+@pytest.mark.parametrize('cin,cout,h,w,n', [(16, 96, 16, 32, 2), (96, 96, 24, 40, 1), (96, 16, 9, 33, 2),
+                                            (32, 64, 16, 32, 1), (64, 128, 8, 32, 1), (128, 256, 8, 32, 1),
+                                            (8, 32, 5, 7, 3)])
+def test_conv3x3_mfma_vs_fp64(ops, cin, cout, h, w, n):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+    xc = ops.to_c8(x.cuda())
+    got = ops.from_c8(ops.conv3x3_c8(xc, packed, cout)).cpu()
+    # fp32 fmaf-chain accumulation over K = 9*cin terms: error ~ 1e-7 * sum|a b|
+    assert rel_l2(got.numpy(), ref.numpy()) < 3e-7
+    got = ops.from_c8(ops.conv3x3_c8(xc, packed, cout, relu=True, residual=ops.to_c8(res.cuda()))).cpu()
+    assert rel_l2(got.numpy(), torch.relu(ref + res.double()).numpy()) < 3e-7
+
+
+def test_conv3x3_identity_asymmetric(ops):
+    """A = I check with an asymmetric operand: catches row/col swaps of the MFMA output map."""
+    cin = cout = 32
+    wt = torch.zeros(cout, cin, 3, 3)
+    for c in range(cout):
+        wt[c, (c * 7 + 3) % cin, 1, 1] = 1.0          # a channel permutation, centre tap only
+    x = torch.arange(1 * cin * 8 * 32, dtype=torch.float32).reshape(1, cin, 8, 32) * 0.001
+    packed = ops.pack_conv3x3(wt, None, Cin=cin, Cout=cout, device='cuda')
+    got = ops.from_c8(ops.conv3x3_c8(ops.to_c8(x.cuda()), packed, cout)).cpu()
+    perm = [(c * 7 + 3) % cin for c in range(cout)]
+    assert torch.equal(got, x[:, perm])
+
+
+@pytest.mark.parametrize('tag,sigmas', [('64x64', (6, 12, 25, 50)), ('128x128', (25,)), ('37x50', (12,))])
+def test_ffdnet_forward_vs_reference_golden(ffdnet_state_dict, tag, sigmas):
+    from adaptivepnp_sci_amd.nets import FFDNet
+    g = load_gold('ffdnet_forward')
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    x = dev(g['in_' + tag])
+    for s in sigmas:
+        out = net(x, torch.full((1, 1, 1, 1), s / 255.)).cpu().numpy()
+        # 12 layers of fp32 MFMA vs oneDNN fp32 on the CPU: summation order only
+        assert rel_l2(out, g[f'out_{tag}_s{s}']) < 2e-6, (tag, s)
