@@ -35,14 +35,17 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int WAVE = 64;
 
-// Sum of nB addends in the order PyTorch's CPU reduction uses for `torch.sum(dim)` over a short
-// strided dim (verified against torch 2.10 for 1 <= nB <= 24): four accumulators over the full
-// groups of four (element i -> accumulator i%4), the remainder appended to accumulator 0, then
-// ((a0+a1)+a2)+a3.  Keeps the projection bit-identical to the reference's A_() (utilspy.py:33).
+// Sums of nB addends in the exact orders PyTorch's CPU `torch.sum(dim)` uses (cascade_sum in
+// ATen/native/cpu/SumKernel.cpp, 8-lane float vectors; verified against torch 2.10 for 1 <= nB <= 48),
+// so that the projection is bit-identical to the reference's expressions.  Both are fully unrolled
+// over MAXB with predicates, so `term(i)` only ever sees compile-time indices (register arrays stay
+// in registers).
+//
+// (1) reduced dim NOT contiguous (e.g. `torch.sum(Phiall[...,ib], dim=2)`, dvp...:72): four
+//     accumulators over the full groups of four (element i -> accumulator i%4), the remainder appended
+//     to accumulator 0, then ((a0+a1)+a2)+a3.
 template <int MAXB, typename F>
-__device__ __forceinline__ float torch_order_sum(int nB, F term) {
-    // fully unrolled over MAXB (a multiple of 4, or < 4) with predicates so that `term(i)` only ever
-    // sees compile-time indices: register arrays stay in registers (no scratch).
+__device__ __forceinline__ float torch_strided_sum(int nB, F term) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int n4 = nB & ~3;
 #pragma unroll
@@ -58,6 +61,30 @@ __device__ __forceinline__ float torch_order_sum(int nB, F term) {
     for (int i = 0; i < MAXB; ++i)
         if (i >= n4 && i < nB) a0 = a0 + term(i);
     return ((a0 + a1) + a2) + a3;
+}
+
+// (2) reduced dim contiguous (e.g. `torch.sum(x*Phi, dim=2)` on the fresh (M,N,B) product inside A_(),
+//     utilspy.py:33): for nB >= 8 the row is cut into 8-float vectors; lane sums L[k] = sum_j v[8j+k]
+//     (sequential in j for up to four vectors); result = (sum of the tail elements past the last full
+//     vector, sequential) then + L[0], + L[1], ... + L[7].  For nB < 8 the scalar path (1) applies.
+//     Valid for nB <= 39 (MAXB <= 32 here).
+template <int MAXB, typename F>
+__device__ __forceinline__ float torch_contig_sum(int nB, F term) {
+    if (nB < 8) return torch_strided_sum<MAXB>(nB, term);
+    const int nv = nB >> 3;
+    float f = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i)
+        if (i >= 8 * nv && i < nB) f = f + term(i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float L = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXB / 8; ++j)
+            if (j < nv) L = L + term(8 * j + k);
+        f = f + L;
+    }
+    return f;
 }
 
 // block-wide sum of one double per thread (block size a multiple of 64, <= 1024; `tid` is the

@@ -10,9 +10,10 @@ namespace scipnp {
 // One thread owns the four Bayer planes of one (quad, frame): a float4.  The B frames of a quad are
 // B consecutive lanes, so for B = 8 a quad is one 128-byte line and Sigma_t is a wavefront shuffle.
 
-template <int LOGB>
+template <int LOGB, bool CONTIG>
 __device__ __forceinline__ float4 frame_sum_shuffle(float4 v, int lane) {
     // every lane of a quad's group receives the torch-order sum over the group's B frames
+    // (CONTIG: the order of a contiguous reduced dim, else of a strided one -- common.hpp)
     constexpr int B = 1 << LOGB;
     const int base = lane & ~(B - 1);
     float4 r;
@@ -21,7 +22,8 @@ __device__ __forceinline__ float4 frame_sum_shuffle(float4 v, int lane) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float mine = vp[c];
-        rp[c] = torch_order_sum<B>(B, [&](int i) { return __shfl(mine, base + i, WAVE); });
+        auto term = [&](int i) { return __shfl(mine, base + i, WAVE); };
+        rp[c] = CONTIG ? torch_contig_sum<B>(B, term) : torch_strided_sum<B>(B, term);
     }
     return r;
 }
@@ -41,7 +43,7 @@ ref_layout_kernel(const float4* __restrict__ theta, const float4* __restrict__ b
     const int lane = threadIdx.x & 63;
     const float4 ph = Phi[idx];
     if (MODE == 4) {
-        float4 s = frame_sum_shuffle<LOGB>(ph, lane);
+        float4 s = frame_sum_shuffle<LOGB, false>(ph, lane);
         s.x = (s.x == 0.f) ? 1.f : s.x;
         s.y = (s.y == 0.f) ? 1.f : s.y;
         s.z = (s.z == 0.f) ? 1.f : s.z;
@@ -57,7 +59,7 @@ ref_layout_kernel(const float4* __restrict__ theta, const float4* __restrict__ b
     const float4 th = theta[idx];
     if (MODE == 2) {
         float4 pr = make_float4(th.x * ph.x, th.y * ph.y, th.z * ph.z, th.w * ph.w);
-        float4 s = frame_sum_shuffle<LOGB>(pr, lane);
+        float4 s = frame_sum_shuffle<LOGB, true>(pr, lane);
         if (live && (idx & (B - 1)) == 0) yout[quad] = s;
         return;
     }
@@ -69,7 +71,7 @@ ref_layout_kernel(const float4* __restrict__ theta, const float4* __restrict__ b
         p = make_float4(th.x + bv.x, th.y + bv.y, th.z + bv.z, th.w + bv.w);
     }
     float4 pr = make_float4(p.x * ph.x, p.y * ph.y, p.z * ph.z, p.w * ph.w);
-    const float4 yb = frame_sum_shuffle<LOGB>(pr, lane);
+    const float4 yb = frame_sum_shuffle<LOGB, true>(pr, lane);
     const float4 yy = y[quad];
     const float4 ps = Phisum[quad];
     float4 r;
@@ -271,7 +273,7 @@ pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
         float* sp = (float*)&so;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            float s = torch_order_sum<MAXB>(B, [&](int i) { return ph[i][v]; });
+            float s = torch_strided_sum<MAXB>(B, [&](int i) { return ph[i][v]; });
             s = (s == 0.f) ? 1.f : s;
             sp[v] = s;
             r[v] = yp[v];
@@ -283,7 +285,7 @@ pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
         const float* sp = (const float*)&sv;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const float yb = torch_order_sum<MAXB>(B, [&](int i) { return p[i][v] * ph[i][v]; });
+            const float yb = torch_contig_sum<MAXB>(B, [&](int i) { return p[i][v] * ph[i][v]; });
             r[v] = (MODE == 0) ? (yp[v] - yb) / (c1 + sp[v]) : (yp[v] - yb) / (sp[v] + c1);
         }
     }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_bench.sh output directory: per-kernel time statistics from the
+rocprofv3 kernel trace and per-kernel averages of every PMC counter collected in its own pass."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace('scipnp::', '')
+    return name[:100]
+
+
+def main(root):
+    rows = defaultdict(list)
+    for f in glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows[r['Kernel_Name']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    total = sum(sum(v) for v in rows.values())
+    print(f'== kernel trace: {sum(len(v) for v in rows.values())} dispatches, {total / 1e3:.2f} ms GPU time')
+    print(f'{"calls":>6} {"total_ms":>10} {"avg_us":>10} {"min_us":>10} {"max_us":>10} {"%":>6}  kernel')
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        print(f'{len(v):6d} {sum(v) / 1e3:10.3f} {sum(v) / len(v):10.2f} {min(v):10.2f} {max(v):10.2f} '
+              f'{100 * sum(v) / total:6.2f}  {short(k)}')
+    for d in sorted(glob.glob(os.path.join(root, 'pmc_*'))):
+        if not os.path.isdir(d):
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+        if not acc:
+            continue
+        print(f'\n== PMC pass {os.path.basename(d)} (per-dispatch averages)')
+        for k, cs in sorted(acc.items(), key=lambda kv: -sum(sum(x) for x in kv[1].values())):
+            vals = '  '.join(f'{c}={sum(v) / len(v):.4g}(n={len(v)})' for c, v in sorted(cs.items()))
+            print(f'  {short(k)}\n      {vals}')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
