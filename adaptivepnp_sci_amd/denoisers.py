@@ -57,8 +57,32 @@ def ffdnet_rgb_denoise_full_tensor(x, yall, Phiall, sigma, model, useGPU=True, l
     if updata_:
         from .finetune import ffdnet_online_finetune
         rgb = ops.cube_to_rgb(x.float().contiguous())
-        ffdnet_online_finetune(model, rgb, yall, Phiall, sigma, lr_, update_per_iter, planes_layout='reference')
-        out = ffdnet_forward_nchw(model, rgb, sigma)
+        B, _, H, W = rgb.shape
+        in_c8, h, w = _unshuffle_to_c8(rgb, sigma)
+        eng = _engine_for(model, B, h, w, x.device)
+        eng.in_c8.copy_(in_c8)
+        ffdnet_online_finetune(model, eng, yall.permute(2, 0, 1).contiguous(), Phiall.permute(2, 3, 0, 1).contiguous(),
+                               sigma, lr_, update_per_iter)
+        out = F.pixel_shuffle(ops.from_c8(eng.forward(), 12), 2)[..., :H, :W].contiguous()
         return ops.rgb_to_cube(out), model
     rgb = ops.cube_to_rgb(x.float().contiguous())
     return ops.rgb_to_cube(ffdnet_forward_nchw(model, rgb, sigma))
+
+
+def fastdvdnet_denoiser_full_tensor_v2(vnoisy, sigma, y_bayer=None, Phi=None, model=None, useGPU=True, lr_=0.000001,
+                                       updata_=False, update_per_iter=1, gray=False, update_times=-1):
+    """vnoisy (H,W,3,B) CUDA tensor -> denoised (H,W,3,B); with `updata_` first runs the online finetune on the
+    measurement loss (y_bayer / Phi as the reference's Bayer planes (M,N,4) / (M,N,B,4)) and returns (out, model)."""
+    from .fastdvd import FastDVDEngine
+    if gray:
+        raise NotImplementedError('grayscale FastDVDnet is outside the Bayer hot path')
+    H, W, _, B = vnoisy.shape
+    frames = ops.cube_to_rgb(vnoisy.float().contiguous())
+    eng = FastDVDEngine(model, B, H, W, vnoisy.device)
+    if updata_:
+        from .finetune import fastdvdnet_online_finetune
+        y_pm = y_bayer.permute(2, 0, 1).contiguous()
+        Phi_pm = Phi.permute(2, 3, 0, 1).contiguous()
+        fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter)
+        return ops.rgb_to_cube(eng.forward(frames, sigma)), model
+    return ops.rgb_to_cube(eng.forward(frames, sigma))

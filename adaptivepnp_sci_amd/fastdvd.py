@@ -1,0 +1,174 @@
+"""FastDVDnet on the HIP kernels.
+
+`FastDVDnet` is a parameter container with the reference's state-dict keys
+(packages/fastdvdnet/models.py:146-253: temp{1,2}.{inc,downc0,downc1,upc2,upc1,outc}.convblock.*); wrap it
+in nn.DataParallel like the reference driver does (two_stage_ADMM_Online_FastDVD_Warm.py:240-241) or not --
+the engine strips an optional `module.` prefix.
+
+`FastDVDEngine.forward(frames, sigma)` = packages/fastdvdnet/fastdvdnet.py:82-146 (sliding 5-frame window with
+circular temporal indexing) + models.py:227-251 (three stage-1 DenBlocks + one stage-2 DenBlock per output
+frame).  With circular indexing the 3*B stage-1 evaluations of the reference are only B distinct ones
+(triplets centred on each frame): each is computed once, all B at a time, then stage 2 runs on the B triplets
+of stage-1 outputs -- bit-identical to the reference's 4*B DenBlock calls.
+
+Per DenBlock: 16 conv3x3 launches (BatchNorm folded into the packed weights, ReLU / skip-add / PixelShuffle /
+stride 2 fused into the conv kernel) + pack + residual.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_BN_EPS = 1e-5
+
+
+def _cbr(cin, cout, stride=1, groups=1):
+    return [nn.Conv2d(cin, cout, 3, stride=stride, padding=1, groups=groups, bias=False),
+            nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+
+
+class _Blk(nn.Module):
+    def __init__(self, *mods):
+        super().__init__()
+        self.convblock = nn.Sequential(*mods)
+
+
+class DenBlock(nn.Module):
+    def __init__(self, num_input_frames=3, ncolor=3):
+        super().__init__()
+        f = num_input_frames
+        self.inc = _Blk(*_cbr(f * (ncolor + 1), f * 30, groups=f), *_cbr(f * 30, 32))
+        self.downc0 = _Blk(*_cbr(32, 64, stride=2), _Blk(*_cbr(64, 64), *_cbr(64, 64)))
+        self.downc1 = _Blk(*_cbr(64, 128, stride=2), _Blk(*_cbr(128, 128), *_cbr(128, 128)))
+        self.upc2 = _Blk(_Blk(*_cbr(128, 128), *_cbr(128, 128)), nn.Conv2d(128, 256, 3, padding=1, bias=False),
+                         nn.PixelShuffle(2))
+        self.upc1 = _Blk(_Blk(*_cbr(64, 64), *_cbr(64, 64)), nn.Conv2d(64, 128, 3, padding=1, bias=False),
+                         nn.PixelShuffle(2))
+        self.outc = _Blk(*_cbr(32, 32), nn.Conv2d(32, ncolor, 3, padding=1, bias=False))
+
+
+class FastDVDnet(nn.Module):
+    """Parameter container (Kaiming-normal init like the reference, models.py:213-220)."""
+
+    def __init__(self, num_input_frames=5, num_color_channels=3):
+        super().__init__()
+        if num_input_frames != 5 or num_color_channels != 3:
+            raise ValueError('only the 5-frame colour FastDVDnet of the reference is supported')
+        self.num_input_frames = num_input_frames
+        self.num_color_channels = num_color_channels
+        self.temp1 = DenBlock(3, num_color_channels)
+        self.temp2 = DenBlock(3, num_color_channels)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+
+    def forward(self, frames, sigma):
+        """frames (B,3,H,W) CUDA tensor of a whole sequence -> denoised (B,3,H,W); HIP kernels only."""
+        B, _, H, W = frames.shape
+        return FastDVDEngine(self, B, H, W, frames.device).forward(frames.float().contiguous(), float(sigma))
+
+
+# (key prefix, bn key or None, Cin, Cout, relu, stride2, shuffle)
+_LAYERS = [
+    ('inc.convblock.0', 'inc.convblock.1', 16, 96, True, False, False),          # grouped 12->90 as dense 16->96
+    ('inc.convblock.3', 'inc.convblock.4', 96, 32, True, False, False),
+    ('downc0.convblock.0', 'downc0.convblock.1', 32, 64, True, True, False),
+    ('downc0.convblock.3.convblock.0', 'downc0.convblock.3.convblock.1', 64, 64, True, False, False),
+    ('downc0.convblock.3.convblock.3', 'downc0.convblock.3.convblock.4', 64, 64, True, False, False),
+    ('downc1.convblock.0', 'downc1.convblock.1', 64, 128, True, True, False),
+    ('downc1.convblock.3.convblock.0', 'downc1.convblock.3.convblock.1', 128, 128, True, False, False),
+    ('downc1.convblock.3.convblock.3', 'downc1.convblock.3.convblock.4', 128, 128, True, False, False),
+    ('upc2.convblock.0.convblock.0', 'upc2.convblock.0.convblock.1', 128, 128, True, False, False),
+    ('upc2.convblock.0.convblock.3', 'upc2.convblock.0.convblock.4', 128, 128, True, False, False),
+    ('upc2.convblock.1', None, 128, 256, False, False, True),
+    ('upc1.convblock.0.convblock.0', 'upc1.convblock.0.convblock.1', 64, 64, True, False, False),
+    ('upc1.convblock.0.convblock.3', 'upc1.convblock.0.convblock.4', 64, 64, True, False, False),
+    ('upc1.convblock.1', None, 64, 128, False, False, True),
+    ('outc.convblock.0', 'outc.convblock.1', 32, 32, True, False, False),
+    ('outc.convblock.3', None, 32, 8, False, False, False),
+]
+
+
+def _dense_from_grouped(w, groups):
+    """(Cout, Cin/groups, 3, 3) grouped weights -> block-diagonal dense (Cout, Cin, 3, 3)."""
+    co, cig = w.shape[:2]
+    dense = torch.zeros(co, cig * groups, 3, 3, dtype=w.dtype)
+    per = co // groups
+    for g in range(groups):
+        dense[g * per:(g + 1) * per, g * cig:(g + 1) * cig] = w[g * per:(g + 1) * per]
+    return dense
+
+
+def _strip(sd):
+    return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+
+
+def pack_denblock(sd, prefix, device):
+    """Packed weights of one DenBlock from a (stripped) state dict; eval-mode BatchNorm folded:
+    y = conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps))."""
+    packed = []
+    for key, bn, cin, cout, _relu, _s2, _shuf in _LAYERS:
+        w = sd[f'{prefix}.{key}.weight'].detach().float().cpu()
+        if key == 'inc.convblock.0':
+            w = _dense_from_grouped(w, 3)
+        scale = shift = None
+        if bn is not None:
+            g, b_ = sd[f'{prefix}.{bn}.weight'].float().cpu(), sd[f'{prefix}.{bn}.bias'].float().cpu()
+            mu, var = sd[f'{prefix}.{bn}.running_mean'].float().cpu(), sd[f'{prefix}.{bn}.running_var'].float().cpu()
+            scale = g / torch.sqrt(var + _BN_EPS)
+            shift = b_ - mu * scale
+        packed.append(ops.pack_conv3x3(w, None, scale, shift, Cin=cin, Cout=cout, device=device))
+    return packed
+
+
+class FastDVDEngine:
+    def __init__(self, model, B, H, W, device):
+        if H % 4 or W % 4:
+            raise ValueError('FastDVDnet needs H and W to be multiples of 4 (the reference reflect-pads otherwise; '
+                             'its padding of the noise map breaks for more than one frame, fastdvdnet.py:126)')
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.refresh(model)
+        f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        self.t_in = f(16, H, W)
+        self.t96 = f(96, H, W)
+        self.x0 = f(32, H, W)
+        self.a64 = [f(64, H2, W2) for _ in range(3)]
+        self.a128 = [f(128, H4, W4) for _ in range(3)]
+        self.u32 = f(32, H, W)
+        self.o32 = f(32, H, W)
+        self.x8 = f(8, H, W)
+        self.s1 = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
+        self.out = torch.empty_like(self.s1)
+
+    def refresh(self, model):
+        sd = _strip(model.state_dict())
+        self.packed = {p: pack_denblock(sd, p, self.device) for p in ('temp1', 'temp2')}
+
+    def _denblock(self, pk, frames, sigma, out):
+        """out[n] = DenBlock(frames[n-1], frames[n], frames[n+1]) for all n (circular)."""
+        c = ops.conv3x3_c8
+        ops.fastdvd_pack_triplets(frames, sigma, self.t_in)
+        c(self.t_in, pk[0], 96, relu=True, out=self.t96, head=True)
+        c(self.t96, pk[1], 32, relu=True, out=self.x0)
+        a, d = self.a64, self.a128
+        c(self.x0, pk[2], 64, relu=True, stride2=True, out=a[0])
+        c(a[0], pk[3], 64, relu=True, out=a[1])
+        c(a[1], pk[4], 64, relu=True, out=a[0])                     # x1 = a[0]
+        c(a[0], pk[5], 128, relu=True, stride2=True, out=d[0])
+        c(d[0], pk[6], 128, relu=True, out=d[1])
+        c(d[1], pk[7], 128, relu=True, out=d[0])                    # x2 = d[0]
+        c(d[0], pk[8], 128, relu=True, out=d[1])
+        c(d[1], pk[9], 128, relu=True, out=d[2])
+        c(d[2], pk[10], 256, shuffle=True, residual=a[0], out=a[1])  # x1 + upc2(x2)
+        c(a[1], pk[11], 64, relu=True, out=a[2])
+        c(a[2], pk[12], 64, relu=True, out=a[1])
+        c(a[1], pk[13], 128, shuffle=True, residual=self.x0, out=self.u32)   # x0 + upc1(.)
+        c(self.u32, pk[14], 32, relu=True, out=self.o32)
+        c(self.o32, pk[15], 8, out=self.x8)
+        return ops.fastdvd_finish(frames, self.x8, out)
+
+    def forward(self, frames, sigma):
+        """frames planar (B,3,H,W) -> denoised planar (B,3,H,W) (owned by the engine, overwritten per call)."""
+        self._denblock(self.packed['temp1'], frames, sigma, self.s1)
+        return self._denblock(self.packed['temp2'], self.s1, sigma, self.out)

@@ -242,13 +242,38 @@ def pack_conv3x3(weight, bias=None, bn_scale=None, bn_shift=None, Cin=None, Cout
     return packed.to(device) if device is not None else packed
 
 
-def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False):
+def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False, stride2=False, shuffle=False):
+    """3x3 conv on c8 activations [n][Cin/8][h][w][8]; Cout = channels the conv produces.  With `shuffle`
+    the output is the PixelShuffle(2)-ed tensor [n][Cout/32][2h][2w][8]; with `stride2` it is half size."""
     n, cg, h, w, _ = x.shape
     if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
-    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (0x100 if head else 0)
+        if shuffle:
+            out = torch.empty(n, Cout // 32, 2 * h, 2 * w, 8, device=x.device, dtype=F32)
+        elif stride2:
+            out = torch.empty(n, Cout // 8, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 8, device=x.device, dtype=F32)
+        else:
+            out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) |
+             (0x100 if head else 0))
     _call('scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'), _p(out, 'out'), _p(residual, 'residual'),
           n, cg * 8, Cout, h, w, flags, _stream())
+    return out
+
+
+def fastdvd_pack_triplets(frames, sigma, out=None):
+    B, _, H, W = frames.shape
+    if out is None:
+        out = torch.empty(B, 2, H, W, 8, device=frames.device, dtype=F32)
+    _call('scipnp_fastdvd_pack_triplets', _p(frames, 'frames'), _p(out, 'out'), B, H, W, float(np.float32(sigma)),
+          _stream())
+    return out
+
+
+def fastdvd_finish(center, x_c8, out=None):
+    B, _, H, W = center.shape
+    if out is None:
+        out = torch.empty_like(center)
+    _call('scipnp_fastdvd_finish', _p(center, 'center'), _p(x_c8, 'x_c8'), _p(out, 'out'), B, H, W, _stream())
     return out
 
 

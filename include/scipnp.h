@@ -142,11 +142,15 @@ int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, 
 /* ---------------------------------------------------------------- denoiser: 3x3 convolutions on MFMA
  * in/out in c8 layout [n][C/8][h][w][8]; weights pre-packed by scipnp_pack_conv3x3_weights.
  * fp32 operands, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products, fmaf chain).
- * Cin, Cout multiples of 8 (pad with zero channels); stride 1, zero padding 1.
- * flags: bit0 = ReLU, bit1 = add `residual` (c8, same shape as out) before the activation,
+ * Cin, Cout multiples of 8 (pad with zero channels); zero padding 1.
+ * flags: bit0 = ReLU, bit1 = add `residual` (same layout and shape as out) before the activation,
+ *        bit2 = stride 2 (out is ((h-1)/2+1) x ((w-1)/2+1)),
+ *        bit3 = PixelShuffle(2) folded into the store: out is [n][Cout/32][2h][2w][8] with conv channel
+ *               4c+2dy+dx written to pixel (2y+dy, 2x+dx), channel c (needs Cout % 32 == 0),
  *        bit8 = "head layer" tag (same arithmetic, separate kernel symbol for profiling).
  * -- replaces nn.Conv2d(...,3,1,1)+ReLU at models/basicblock.py:61-98 as used by network_ffdnet.py:46-48
- *    and the CvBlock/UpBlock/OutputCvBlock convs of packages/fastdvdnet/models.py:16-89. */
+ *    and every conv of packages/fastdvdnet/models.py:16-89 (CvBlock, InputCvBlock as a block-diagonal
+ *    dense conv, DownBlock stride 2, UpBlock + nn.PixelShuffle(2), OutputCvBlock). */
 size_t scipnp_conv3x3_packed_floats(int Cin, int Cout);
 /* w: [Cout_real][Cin_real][3][3] (PyTorch OIHW), bias: [Cout_real] or NULL; scale/shift fold an
  * eval-mode BatchNorm (y = conv*scale[co] + shift[co]; NULL = identity).  HOST pointers in, HOST
@@ -164,6 +168,16 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
  * -- models/network_ffdnet.py:54-69 called per frame by packages/ffdnet/test_ffdnet_ipol.py:340-354 */
 int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,
                           float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------- FastDVDnet glue
+ * DenBlock input from planar frames [B][3][H][W] with circular temporal indexing: out c8 [B][2][H][W][8],
+ * entry n = (frame n-1, sigma, frame n, sigma | frame n+1, sigma, 0...), indices mod B.
+ * -- packages/fastdvdnet/models.py:187 (torch.cat), packages/fastdvdnet/fastdvdnet.py:113-116 */
+int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int H, int W, float sigma,
+                                 scipnp_stream_t s);
+/* DenBlock residual: out[n][c] = center[n][c] - x_c8[n][0][..][c], c < 3  -- models.py:196 (in1 - x) */
+int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,
+                          scipnp_stream_t s);
 
 #ifdef __cplusplus
 }

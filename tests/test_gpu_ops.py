@@ -273,3 +273,43 @@ def test_ffdnet_forward_vs_reference_golden(ffdnet_state_dict, tag, sigmas):
         out = net(x, torch.full((1, 1, 1, 1), s / 255.)).cpu().numpy()
         # 12 layers of fp32 MFMA vs oneDNN fp32 on the CPU: summation order only
         assert rel_l2(out, g[f'out_{tag}_s{s}']) < 2e-6, (tag, s)
+
+
+def test_conv3x3_stride2_and_pixelshuffle(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 12, 36, generator=g)
+    wt = torch.randn(64, 32, 3, 3, generator=g) * 0.06
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride=2, padding=1)
+    packed = ops.pack_conv3x3(wt, None, Cin=32, Cout=64, device='cuda')
+    got = ops.from_c8(ops.conv3x3_c8(ops.to_c8(x.cuda()), packed, 64, stride2=True)).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 1e-6
+    # odd input size: out = (h-1)//2+1
+    x = torch.randn(1, 8, 9, 35, generator=g)
+    wt = torch.randn(32, 8, 3, 3, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride=2, padding=1)
+    packed = ops.pack_conv3x3(wt, None, Cin=8, Cout=32, device='cuda')
+    got = ops.from_c8(ops.conv3x3_c8(ops.to_c8(x.cuda()), packed, 32, stride2=True)).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 1e-6
+    # PixelShuffle(2) epilogue with a residual in the shuffled layout and folded BatchNorm-style scale/shift
+    x = torch.randn(2, 64, 10, 33, generator=g)
+    wt = torch.randn(128, 64, 3, 3, generator=g) * 0.04
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = torch.randn(2, 32, 20, 66, generator=g)
+    conv = torch.nn.functional.conv2d(x.double(), wt.double(), None, padding=1) * sc.double()[None, :, None, None] \
+        + sh.double()[None, :, None, None]
+    ref = torch.nn.functional.pixel_shuffle(conv, 2) + res.double()
+    packed = ops.pack_conv3x3(wt, None, sc, sh, Cin=64, Cout=128, device='cuda')
+    got = ops.from_c8(ops.conv3x3_c8(ops.to_c8(x.cuda()), packed, 128, shuffle=True, residual=ops.to_c8(res.cuda()))).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 1e-6
+
+
+def test_fastdvdnet_forward_vs_reference_golden():
+    """Synthetic seeded weights (the reference's model.pth is not in the snapshot); circular-window edge frames
+    0,1,6,7 included (B = 8); golden produced by the reference's fastdvdnet_denoiser_full_tensor_v2."""
+    from adaptivepnp_sci_amd import fastdvdnet_denoiser_full_tensor_v2
+    from oracle.nets import synth_fastdvdnet_weights
+    g = load_gold('fastdvd_forward')
+    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))          # the reference wraps it like this
+    out = fastdvdnet_denoiser_full_tensor_v2(dev(g['v']), float(g['sigma']), None, None, net, True, 1e-6)
+    # 32 fp32-MFMA conv layers + folded BatchNorm vs PyTorch-CPU: summation order / fold rounding only
+    assert rel_l2(out.cpu().numpy(), g['out']) < 5e-6

@@ -153,3 +153,18 @@ def test_full_size_properties(solver):
     xb, psnr_, ssim_, psnr_all = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [6], False, [0],
                                                                         X_orig=orig, logf=io.StringIO())
     assert all(np.diff(psnr_all) > 0) and xb.shape == (512, 512, 8)
+
+
+def test_two_stage_fastdvdnet_iterates(solver):
+    from oracle.nets import synth_fastdvdnet_weights
+    g = load_gold('fastdvdadmm_64x64x8')
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [4], False, [8 / 255],
+                                            x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, show_iqa=True,
+                                            demosaic_method='malvar2004', logf=io.StringIO())
+    for k in range(4):
+        assert rel_l2(tr.it[k], g['theta'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta'][k]))
+    assert rel_l2(res[0], g['rgb']) <= REL_TOL
+    assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL
