@@ -181,7 +181,7 @@ conv3x3_c8_kernel(const ConvArgs a) {
 
     // ---- epilogue
     const float* bias = a.wpk + (size_t)a.CGin * 9 * a.CoutP_total * 8;
-    const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual;
+    const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.residual;
     const int Ho = a.Ho, Wo = a.Wo;
     const int x = x0 + li;
 #pragma unroll
@@ -208,6 +208,11 @@ conv3x3_c8_kernel(const ConvArgs a) {
                             if (relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
+                                const f32x4 fw = *(const f32x4*)(a.residual + o);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (fw[e] > 0.f) ? v[e] : 0.f;
                             }
                             *(f32x4*)(a.out + o) = v;
                         } else {
@@ -305,6 +310,7 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
     if (residual) SCIPNP_ALIGNED(residual);
     const bool stride2 = flags & 4, shuf = flags & 8;
     SCIPNP_REQUIRE(!(stride2 && shuf), "stride-2 and pixel-shuffle epilogue cannot be combined");
+    SCIPNP_REQUIRE(!((flags & 16) && ((flags & 2) || shuf)), "ReLU-mask epilogue excludes residual add / pixel shuffle");
     SCIPNP_REQUIRE(!shuf || Cout % 32 == 0, "pixel-shuffle epilogue needs Cout %% 32 == 0 (got %d)", Cout);
     SCIPNP_REQUIRE((long long)h * w * 8 < (1ll << 31), "image too large for 32-bit tile offsets");
     ConvArgs a;

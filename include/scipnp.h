@@ -147,6 +147,8 @@ int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, 
  *        bit2 = stride 2 (out is ((h-1)/2+1) x ((w-1)/2+1)),
  *        bit3 = PixelShuffle(2) folded into the store: out is [n][Cout/32][2h][2w][8] with conv channel
  *               4c+2dy+dx written to pixel (2y+dy, 2x+dx), channel c (needs Cout % 32 == 0),
+ *        bit4 = ReLU-backward mask: out = (residual > 0) ? out : 0 with `residual` = the forward activation
+ *               (backward-data pass of the online finetune; excludes bit1/bit3),
  *        bit8 = "head layer" tag (same arithmetic, separate kernel symbol for profiling).
  * -- replaces nn.Conv2d(...,3,1,1)+ReLU at models/basicblock.py:61-98 as used by network_ffdnet.py:46-48
  *    and every conv of packages/fastdvdnet/models.py:16-89 (CvBlock, InputCvBlock as a block-diagonal
@@ -168,6 +170,30 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
  * -- models/network_ffdnet.py:54-69 called per frame by packages/ffdnet/test_ffdnet_ipol.py:340-354 */
 int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,
                           float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------- online finetune (measurement loss)
+ * -- packages/ffdnet/test_ffdnet_ipol.py:248-300: Adam steps on  MSE( sum_t Phi * bayer_sample(net(x)), y ).
+ * Backward-data of a conv layer is scipnp_conv3x3_c8 with weights packed by scipnp_pack_conv3x3_device(...,
+ * transpose_flip=1) and flag bit4. */
+/* loss partials (sum of squared residuals per block, double; L = sum/(4MN)) and dL/d(net tail output) in c8
+ * [B][2][M][N][8]; loss_part == NULL only returns *nblocks.            -- test_ffdnet_ipol.py:275-293 */
+int scipnp_ffdnet_loss_grad(const float* out_c8, const float* Phi, const float* y, float* gout_c8,
+                            double* loss_part, int M, int N, int B, int* nblocks, scipnp_stream_t s);
+/* dW (OIHW, real channel counts) of a 3x3/pad-1/stride-1 conv from its input activations and output gradient;
+ * MFMA GEMM over pixels with nslab persistent workgroups; workspace >= ..._workspace_floats floats. */
+size_t scipnp_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int nslab);
+int scipnp_conv3x3_wgrad(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
+                         int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s);
+/* db[co] = sum dz; workspace >= (Cout/8)*64*8 floats */
+int scipnp_conv_bias_grad(const float* dz_c8, float* db, float* workspace, int n, int Cout_real, int Cout,
+                          int h, int w, scipnp_stream_t s);
+/* one torch.optim.Adam step (amsgrad=False, weight_decay=0) on a flat float32 tensor; step counts from 1 */
+int scipnp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                     double beta1, double beta2, double eps, int step, scipnp_stream_t s);
+/* device-side weight packing (OIHW device tensor -> packed buffer of scipnp_conv3x3_packed_floats floats);
+ * transpose_flip = 1 packs the backward-data convolution (Cout -> Cin channels, taps flipped, no bias). */
+int scipnp_pack_conv3x3_device(const float* w, const float* bias, float* packed, int Cin_real, int Cout_real,
+                               int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------- FastDVDnet glue
  * DenBlock input from planar frames [B][3][H][W] with circular temporal indexing: out c8 [B][2][H][W][8],

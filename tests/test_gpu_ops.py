@@ -313,3 +313,83 @@ def test_fastdvdnet_forward_vs_reference_golden():
     out = fastdvdnet_denoiser_full_tensor_v2(dev(g['v']), float(g['sigma']), None, None, net, True, 1e-6)
     # 32 fp32-MFMA conv layers + folded BatchNorm vs PyTorch-CPU: summation order / fold rounding only
     assert rel_l2(out.cpu().numpy(), g['out']) < 5e-6
+
+
+def test_wgrad_bgrad_backward_data_vs_autograd(ops):
+    """conv weight / bias gradients (MFMA GEMM over pixels) and the backward-data conv (transposed, flipped
+    weights + ReLU mask) against PyTorch autograd in float64."""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, h, w = 2, 96, 96, 10, 37
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    bias = torch.randn(cout, generator=g)
+    dz = torch.randn(n, cout, h, w, generator=g)
+    xd, wd, bd = x.double().requires_grad_(), wt.double().requires_grad_(), bias.double().requires_grad_()
+    out = torch.nn.functional.conv2d(xd, wd, bd, padding=1)
+    out.backward(dz.double())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    x8, dz8 = ops.to_c8(x.cuda()), ops.to_c8(dz.cuda())
+    nslab = 16
+    ws = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(cin, cout, nslab), device='cuda')
+    dW = torch.empty(cout, cin, 3, 3, device='cuda')
+    _lib.check(lib.scipnp_conv3x3_wgrad(p(x8), p(dz8), p(dW), p(ws), nslab, n, cin, cout, cin, cout, h, w, s), 'wgrad')
+    assert rel_l2(dW.cpu().numpy(), wd.grad.numpy()) < 1e-6
+    db = torch.empty(cout, device='cuda')
+    bws = torch.empty((cout // 8) * 64 * 8, device='cuda')
+    _lib.check(lib.scipnp_conv_bias_grad(p(dz8), p(db), p(bws), n, cout, cout, h, w, s), 'bgrad')
+    assert rel_l2(db.cpu().numpy(), bd.grad.numpy()) < 1e-6
+    # head-like shapes: 13 real input channels in 16, and 12 real output channels in 16
+    for ci_r, co_r, ci, co in ((13, 96, 16, 96), (96, 12, 96, 16)):
+        x = torch.randn(n, ci_r, h, w, generator=g)
+        wt2 = (torch.randn(co_r, ci_r, 3, 3, generator=g) * 0.05).double().requires_grad_()
+        dz = torch.randn(n, co_r, h, w, generator=g)
+        torch.nn.functional.conv2d(x.double(), wt2, None, padding=1).backward(dz.double())
+        ws = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, nslab), device='cuda')
+        dW = torch.empty(co_r, ci_r, 3, 3, device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad(p(ops.to_c8(x.cuda())), p(ops.to_c8(dz.cuda())), p(dW), p(ws), nslab, n, ci_r,
+                                            co_r, ci, co, h, w, s), 'wgrad')
+        assert rel_l2(dW.cpu().numpy(), wt2.grad.numpy()) < 1e-6
+    # backward-data with device-side transposed/flipped packing and the ReLU mask
+    dz = torch.randn(n, cout, h, w, generator=g)
+    packed = torch.empty(lib.scipnp_conv3x3_packed_floats(cout, cin), device='cuda')
+    wdev = wt.cuda()
+    _lib.check(lib.scipnp_pack_conv3x3_device(p(wdev), None, p(packed), cin, cout, cin, cout, 1, s), 'pack bwd')
+    xin = torch.randn(n, cin, h, w, generator=g)
+    act = torch.relu(xin)
+    xin_d = xin.double().requires_grad_()
+    torch.nn.functional.conv2d(torch.relu(xin_d), wt.double(), None, padding=1).backward(dz.double())
+    got = torch.empty(n, cin // 8, h, w, 8, device='cuda')
+    _lib.check(lib.scipnp_conv3x3_c8(p(ops.to_c8(dz.cuda())), p(packed), p(got), p(ops.to_c8(act.cuda())), n, cout, cin, h, w,
+                                     16, s), 'bwd-data')
+    assert rel_l2(ops.from_c8(got).cpu().numpy(), xin_d.grad.numpy()) < 1e-6
+    # forward device packing == host packing
+    pk_host = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+    pk_dev = torch.empty_like(pk_host)
+    _lib.check(lib.scipnp_pack_conv3x3_device(p(wdev), p(bias.cuda()), p(pk_dev), cin, cout, cin, cout, 0, s), 'pack fwd')
+    assert torch.equal(pk_host, pk_dev)
+
+
+def test_adam_step_matches_torch(ops):
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(5000, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=2e-6)
+    pd, m, v = p0.clone().cuda(), torch.zeros(5000, device='cuda'), torch.zeros(5000, device='cuda')
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in (1, 2, 3):
+        grad = torch.randn(5000, generator=g) * 10 ** float(torch.randint(-4, 1, (1,), generator=g))
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        _lib.check(lib.scipnp_adam_step(C.c_void_p(pd.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(m.data_ptr()),
+                                        C.c_void_p(v.data_ptr()), 5000, 2e-6, 0.9, 0.999, 1e-8, step, s), 'adam')
+        upd_ref, upd = (ref.detach() - p0).numpy(), (pd.cpu() - p0).numpy()
+        assert rel_l2(upd, upd_ref) < 1e-3, step          # the update itself (~lr), float32 round-off of p dominates
+        assert rel_l2(pd.cpu().numpy(), ref.detach().numpy()) < 1e-7

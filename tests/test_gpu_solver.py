@@ -168,3 +168,38 @@ def test_two_stage_fastdvdnet_iterates(solver):
         assert rel_l2(tr.it[k], g['theta'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta'][k]))
     assert rel_l2(res[0], g['rgb']) <= REL_TOL
     assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL
+
+
+def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict):
+    """update_=True, lr 2e-6, update_per_iter 2 (the reference driver's values), gate at k = 2: hand-written
+    backward (loss grad, backward-data convs, MFMA weight gradients, Adam) vs the reference's autograd run."""
+    from adaptivepnp_sci_amd import finetune
+    g = load_gold('ffdnet_finetune_64x64x8')
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    net = make_ffdnet(ffdnet_state_dict)
+    losses = []
+    orig_ft = finetune.ffdnet_online_finetune
+    finetune.ffdnet_online_finetune = lambda *a, **k: orig_ft(*a, trace=losses, **k)
+    try:
+        res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
+                                                x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, show_iqa=True,
+                                                demosaic_method='malvar2004', lr_=2e-6, inital_iter=1, interval_iter=2,
+                                                logf=io.StringIO(), update_=True, update_per_iter=2)
+    finally:
+        finetune.ffdnet_online_finetune = orig_ft
+    for k in range(4):
+        assert rel_l2(tr.it[k], g['theta'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta'][k]))
+    assert rel_l2(res[0], g['rgb']) <= REL_TOL
+    # losses of the two Adam steps (the golden's third entry is the reference's post-update print)
+    assert len(losses) == 2 and np.allclose(losses, g['losses'][:2], rtol=1e-5)
+    # the module was updated in place: parameter deltas vs the reference's.  Adam's first steps are ~ -lr*sign(g),
+    # so deltas agree except where a gradient is ~0 (sign undetermined at round-off level)
+    sd = net.state_dict()
+    assert res[5] is net
+    for k0, w0 in ffdnet_state_dict.items():
+        d_ref = g[k0.replace('.', '_') + '_delta']
+        d_got = (sd[k0] - w0).numpy()
+        assert np.abs(d_ref).max() > 0
+        assert rel_l2(d_got, d_ref) < 2e-2, (k0, rel_l2(d_got, d_ref))
+        assert rel_l2(sd[k0].numpy(), (w0 + torch.from_numpy(d_ref)).numpy()) < 1e-6
