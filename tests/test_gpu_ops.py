@@ -350,8 +350,8 @@ def test_wgrad_bgrad_backward_data_vs_autograd(ops):
         torch.nn.functional.conv2d(x.double(), wt2, None, padding=1).backward(dz.double())
         ws = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, nslab), device='cuda')
         dW = torch.empty(co_r, ci_r, 3, 3, device='cuda')
-        _lib.check(lib.scipnp_conv3x3_wgrad(p(ops.to_c8(x.cuda())), p(ops.to_c8(dz.cuda())), p(dW), p(ws), nslab, n, ci_r,
-                                            co_r, ci, co, h, w, s), 'wgrad')
+        x8b, dz8b = ops.to_c8(x.cuda()), ops.to_c8(dz.cuda())      # keep alive: p() only takes the address
+        _lib.check(lib.scipnp_conv3x3_wgrad(p(x8b), p(dz8b), p(dW), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, s), 'wgrad')
         assert rel_l2(dW.cpu().numpy(), wt2.grad.numpy()) < 1e-6
     # backward-data with device-side transposed/flipped packing and the ReLU mask
     dz = torch.randn(n, cout, h, w, generator=g)
@@ -363,8 +363,8 @@ def test_wgrad_bgrad_backward_data_vs_autograd(ops):
     xin_d = xin.double().requires_grad_()
     torch.nn.functional.conv2d(torch.relu(xin_d), wt.double(), None, padding=1).backward(dz.double())
     got = torch.empty(n, cin // 8, h, w, 8, device='cuda')
-    _lib.check(lib.scipnp_conv3x3_c8(p(ops.to_c8(dz.cuda())), p(packed), p(got), p(ops.to_c8(act.cuda())), n, cout, cin, h, w,
-                                     16, s), 'bwd-data')
+    dz8c, act8 = ops.to_c8(dz.cuda()), ops.to_c8(act.cuda())
+    _lib.check(lib.scipnp_conv3x3_c8(p(dz8c), p(packed), p(got), p(act8), n, cout, cin, h, w, 16, s), 'bwd-data')
     assert rel_l2(ops.from_c8(got).cpu().numpy(), xin_d.grad.numpy()) < 1e-6
     # forward device packing == host packing
     pk_host = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
