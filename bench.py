@@ -138,16 +138,15 @@ def main():
         run.step(SIGMA)
     events = []
     run.profile_events = events
-    gathered = None
-    if dist is not None and rank == 0:
-        gathered = [torch.empty(H, W, B, device=dev) for _ in range(world)]
+    from adaptivepnp_sci_amd import shard
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.step(SIGMA)
     mosaic = run.result_mosaic()
-    if dist is not None:
-        dist.gather(mosaic, gathered, dst=0)          # the single RCCL collective of the job
+    if dist is not None:                              # unit `rank` lives on this rank; ONE RCCL gather for the job
+        gathered = shard.gather_units({rank: mosaic}, world, (H, W, B), dev, dst=0)
+        assert rank != 0 or len(gathered) == world
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -1,0 +1,105 @@
+"""CPU: the C-ABI library loads and exports every symbol include/scipnp.h declares; host-only entry points
+work; device entry points fail LOUDLY without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from adaptivepnp_sci_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'scipnp.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(scipnp_\w+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from adaptivepnp_sci_amd import _lib
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/scipnp.h but not exported'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.py'
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_identity(lib):
+    assert b'scipnp' in lib.scipnp_version()
+    assert lib.scipnp_arch() == b'gfx950'
+
+
+def test_host_weight_packing_layout(lib):
+    from adaptivepnp_sci_amd import ops
+    rng = np.random.default_rng(0)
+    co_r, ci_r, ci, co = 12, 13, 16, 16
+    w = torch.from_numpy(rng.normal(size=(co_r, ci_r, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=co_r).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, co_r).astype(np.float32))
+    sh = torch.from_numpy(rng.normal(size=co_r).astype(np.float32))
+    packed = ops.pack_conv3x3(w, b, sc, sh, Cin=ci, Cout=co).numpy()
+    coP = 32
+    assert packed.size == lib.scipnp_conv3x3_packed_floats(ci, co) == (ci // 8) * 9 * coP * 8 + coP
+    body = packed[:-coP].reshape(ci // 8, 9, coP, 8)
+    for o in range(coP):
+        for i in range(ci):
+            exp = (w[o, i].reshape(9) * sc[o]).numpy() if (o < co_r and i < ci_r) else np.zeros(9, np.float32)
+            assert np.array_equal(body[i // 8, :, o, i % 8], exp)
+    assert np.array_equal(packed[-coP:][:co_r], (b * sc + sh).numpy())
+    assert not packed[-coP:][co_r:].any()
+    assert lib.scipnp_conv3x3_packed_floats(13, 16) == 0          # channels must be padded to multiples of 8
+
+
+def test_workspace_queries(lib):
+    assert lib.scipnp_tv_workspace_bytes(128, 128, 32, 5) > 2 * 2 * 32 * 128 * 128 * 4
+    assert lib.scipnp_tv_workspace_bytes(0, 128, 32, 5) == 0
+    assert lib.scipnp_conv3x3_wgrad_workspace_floats(96, 96, 256) == 256 * 9 * 96 * 96
+    nb = C.c_int(0)
+    assert lib.scipnp_sse_partials(C.c_void_p(1), C.c_void_p(1), 5000, None, C.byref(nb), None) == 0
+    assert nb.value == 3
+
+
+def test_argument_errors_are_reported(lib):
+    rc = lib.scipnp_A(None, None, None, 4, 4, 8, None)
+    assert rc == -1 and b'null' in lib.scipnp_last_error()
+    rc = lib.scipnp_conv3x3_c8(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, 1, 13, 96, 8, 8, 0, None)
+    assert rc == -1 and b'multiples of 8' in lib.scipnp_last_error()
+    rc = lib.scipnp_proj_twostage(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16),
+                                  C.c_void_p(20), 4, 4, 8, 1.0, 1.0, None)
+    assert rc == -2 and b'aligned' in lib.scipnp_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_no_cpu_fallback():
+    from adaptivepnp_sci_amd import _lib, synth, twoStageAdmm_denoise_bayer
+    y, Phi, _ = synth.make_problem(16, 16, 8, seed=0)
+    with pytest.raises(_lib.ScipnpError, match='no CPU fallback'):
+        twoStageAdmm_denoise_bayer(y, Phi, denoiser='tv', sigma=[0], iter_max=[1])
+
+
+def test_signatures_mirror_the_reference():
+    import inspect
+    from adaptivepnp_sci_amd import admm_denoise_bayer_demosaic_pre, twoStageAdmm_denoise_bayer
+    two = list(inspect.signature(twoStageAdmm_denoise_bayer).parameters)
+    assert two == ['y_bayer', 'Phi_bayer', '_lambda', 'gamma', 'denoiser', 'iter_max', 'noise_estimate', 'sigma',
+                   'x0_bayer', 'X_orig', 'model_denoise', 'model_demosaic', 'show_iqa', 'demosaic_method', 'lr_',
+                   'inital_iter', 'interval_iter', 'logf', 'useGPU', 'update_', 'update_per_iter',
+                   'close_form_demosaic', 'large', 'update_times', 'args']
+    one = list(inspect.signature(admm_denoise_bayer_demosaic_pre).parameters)
+    assert one == ['y_bayer', 'Phi_bayer', '_lambda', 'gamma', 'denoiser', 'iter_max', 'noise_estimate', 'sigma',
+                   'x0_bayer', 'X_orig', 'model', 'show_iqa', 'demosaic_method', 'lr_', 'inital_iter', 'interval_iter',
+                   'logf', 'useGPU', 'device', 'update_', 'update_per_iter']
+    d = inspect.signature(twoStageAdmm_denoise_bayer).parameters
+    assert d['iter_max'].default == 50 and d['lr_'].default == 1e-6 and d['interval_iter'].default == 5

@@ -1,0 +1,65 @@
+"""CPU (gloo, world_size 2): the N>1 plumbing -- unit partition and the single end-of-job gather."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_units, ret):
+    sys.path.insert(0, ROOT)
+    from adaptivepnp_sci_amd import shard
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        shape = (6, 8, 3)
+
+        def solve(args, model):
+            seed, scale = args
+            g = torch.Generator().manual_seed(seed)
+            return torch.rand(shape, generator=g) * scale     # stand-in for the GPU solve of one unit
+
+        units = [(100 + i, float(i + 1)) for i in range(n_units)]
+        out = shard.reconstruct_sharded(units, solve, shape, torch.device('cpu'))
+        if rank == 0:
+            ok = len(out) == n_units
+            for i, o in enumerate(out):
+                g = torch.Generator().manual_seed(100 + i)
+                ok = ok and torch.equal(o, torch.rand(shape, generator=g) * float(i + 1))
+            ret.put(ok)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_units', [4, 5, 1])
+def test_partition_and_single_gather_gloo(n_units):
+    world = 2
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() + n_units) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+def test_partition_is_a_partition():
+    sys.path.insert(0, ROOT)
+    from adaptivepnp_sci_amd import shard
+    for n in (0, 1, 7, 8, 16):
+        for world in (1, 2, 4, 8):
+            seen = sorted(u for r in range(world) for u in shard.partition(n, world, r))
+            assert seen == list(range(n))
+            assert all(len(shard.partition(n, world, r)) <= shard.slots_per_rank(n, world) for r in range(world))
+    with pytest.raises(ValueError):
+        shard.partition(4, 2, 2)
