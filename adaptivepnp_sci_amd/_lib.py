@@ -53,6 +53,15 @@ SIGNATURES = {
     'scipnp_conv_bias_grad': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'scipnp_adam_step': (_int, [_vp, _vp, _vp, _vp, _sz, C.c_double, C.c_double, C.c_double, C.c_double, _int, _vp]),
     'scipnp_pack_conv3x3_device': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_pack_conv3x3_device_scaled': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_bn_fold': (_int, [_vp, _vp, _vp, _vp, _flt, _vp, _vp, _int, _vp]),
+    'scipnp_bn_fold_grads': (_int, [_vp] * 6 + [_flt, _vp, _vp, _vp, _int, _int, _vp]),
+    'scipnp_upsample_zero_c8': (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_pixel_shuffle_bwd_c8': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_fastdvd_loss_grad': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_fastdvd_finish_bwd': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_fastdvd_unpack_bwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),

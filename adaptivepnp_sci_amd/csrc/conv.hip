@@ -55,6 +55,7 @@ struct ConvArgs {
     const float* wpk;
     float* out;
     const float* residual;
+    const float* mask_src;   // ReLU-backward mask source (forward activation), flag bit 4
     int CGin, CGout, CoutP_total, nsplit;
     int H, W;        // input size
     int Ho, Wo;      // conv output size (before any pixel shuffle)
@@ -181,7 +182,7 @@ conv3x3_c8_kernel(const ConvArgs a) {
 
     // ---- epilogue
     const float* bias = a.wpk + (size_t)a.CGin * 9 * a.CoutP_total * 8;
-    const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.residual;
+    const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
     const int Ho = a.Ho, Wo = a.Wo;
     const int x = x0 + li;
 #pragma unroll
@@ -210,7 +211,7 @@ conv3x3_c8_kernel(const ConvArgs a) {
                                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                             }
                             if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
-                                const f32x4 fw = *(const f32x4*)(a.residual + o);
+                                const f32x4 fw = *(const f32x4*)(a.mask_src + o);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = (fw[e] > 0.f) ? v[e] : 0.f;
                             }
@@ -301,20 +302,22 @@ int scipnp_pack_conv3x3_weights(const float* w, const float* bias, const float* 
     return SCIPNP_OK;
 }
 
-int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const float* residual, int n, int Cin,
-                      int Cout, int h, int w, int flags, scipnp_stream_t s) {
+int scipnp_conv3x3_c8_ex(const float* in, const float* packed_w, float* out, const float* residual,
+                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && packed_w && out, "null pointer");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0,
                    "bad shape n=%d Cin=%d Cout=%d h=%d w=%d (channels must be multiples of 8)", n, Cin, Cout, h, w);
     SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(packed_w); SCIPNP_ALIGNED(out);
     if (residual) SCIPNP_ALIGNED(residual);
+    if (mask_src) SCIPNP_ALIGNED(mask_src);
     const bool stride2 = flags & 4, shuf = flags & 8;
     SCIPNP_REQUIRE(!(stride2 && shuf), "stride-2 and pixel-shuffle epilogue cannot be combined");
-    SCIPNP_REQUIRE(!((flags & 16) && ((flags & 2) || shuf)), "ReLU-mask epilogue excludes residual add / pixel shuffle");
+    SCIPNP_REQUIRE(!((flags & 16) && shuf), "ReLU-mask epilogue excludes pixel shuffle");
+    SCIPNP_REQUIRE(!(flags & 16) || mask_src, "flag bit4 needs mask_src");
     SCIPNP_REQUIRE(!shuf || Cout % 32 == 0, "pixel-shuffle epilogue needs Cout %% 32 == 0 (got %d)", Cout);
     SCIPNP_REQUIRE((long long)h * w * 8 < (1ll << 31), "image too large for 32-bit tile offsets");
     ConvArgs a;
-    a.in = in; a.wpk = packed_w; a.out = out; a.residual = residual;
+    a.in = in; a.wpk = packed_w; a.out = out; a.residual = residual; a.mask_src = mask_src;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up(Cout, 32); a.nsplit = 1;
     a.H = h; a.W = w;
     a.Ho = stride2 ? (h - 1) / 2 + 1 : h;
@@ -325,6 +328,15 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
     if (stride2) return dispatch_cob<2, 0>(a, n, st);
     if (shuf) return dispatch_cob<1, 1>(a, n, st);
     return dispatch_cob<1, 0>(a, n, st);
+}
+
+int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const float* residual, int n, int Cin,
+                      int Cout, int h, int w, int flags, scipnp_stream_t s) {
+    // historical form: with flag bit4 (and no bit1) `residual` is the mask source
+    if ((flags & 16) && !(flags & 2))
+        return scipnp_conv3x3_c8_ex(in, packed_w, out, nullptr, residual, n, Cin, Cout, h, w, flags, s);
+    SCIPNP_REQUIRE(!(flags & 16), "mask + residual needs scipnp_conv3x3_c8_ex");
+    return scipnp_conv3x3_c8_ex(in, packed_w, out, residual, nullptr, n, Cin, Cout, h, w, flags, s);
 }
 
 int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,

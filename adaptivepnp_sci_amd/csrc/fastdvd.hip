@@ -39,6 +39,123 @@ fastdvd_finish_kernel(const float* __restrict__ center, const float* __restrict_
     out[o + 2 * HW] = center[o + 2 * HW] - x.z;
 }
 
+// ------------------------------------------------------------------ backward-pass glue (online finetune)
+// zero-insertion upsample: out[n][cg][2y][2x] = in[n][cg][y][x], zero elsewhere (out is H x W).  The gradient of
+// a stride-2 conv w.r.t. its input / weights is the stride-1 backward applied to this tensor.
+__global__ void __launch_bounds__(256)
+upsample_zero_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w, int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index over out
+    if (i >= total) return;
+    const int half = i & 1;
+    const size_t pix = i >> 1;
+    const int X = (int)(pix % W), Y = (int)((pix / W) % H);
+    const size_t img = pix / ((size_t)W * H);                           // n*CG + cg
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(X & 1) && !(Y & 1) && (Y >> 1) < h && (X >> 1) < w)
+        v = *(const float4*)(in + ((img * h + (Y >> 1)) * (size_t)w + (X >> 1)) * 8 + 4 * half);
+    *(float4*)(out + pix * 8 + 4 * half) = v;
+}
+
+// PixelShuffle(2) backward in c8: dconv[n][4c+2dy+dx][y][x] = dshuf[n][c][2y+dy][2x+dx]
+// dshuf: [n][Cs/8][2h][2w][8], dconv: [n][4*Cs/8][h][w][8]; thread = (n, conv channel group, y, x)
+__global__ void __launch_bounds__(256)
+unshuffle_bwd_kernel(const float* __restrict__ dshuf, float* __restrict__ dconv, int CGs, int h, int w, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const int cog = (int)((i / ((size_t)w * h)) % (4 * CGs));
+    const size_t n = i / ((size_t)w * h * 4 * CGs);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = cog * 8 + e;                 // conv channel
+        const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+        v[e] = dshuf[(((n * CGs + (c >> 3)) * (2 * h) + 2 * y + dy) * (size_t)(2 * w) + 2 * x + dx) * 8 + (c & 7)];
+    }
+    float4* d = (float4*)(dconv + i * 8);
+    d[0] = make_float4(v[0], v[1], v[2], v[3]);
+    d[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// measurement loss on planar RGB frames and its gradient (reference test_fastdvdnet.py:424-431):
+//   L = mean_{r,c} ( sum_t Phi_mosaic[r,c,t] * out[t][color(r,c)][r][c] - y_mosaic[r,c] )^2
+// thread = one Bayer quad; Phi, y plane-major ([B][4][M][N], [4][M][N]); dout planar, zero off the CFA sites.
+__global__ void __launch_bounds__(256)
+fastdvd_loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ Phi, const float* __restrict__ y,
+                         float* __restrict__ dout, double* __restrict__ loss_part, int M, int N, int B) {
+    __shared__ double red[16];
+    const size_t plane = (size_t)M * N;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (q < plane) {
+        const int m = (int)(q / N), n = (int)(q % N);
+        const int W = 2 * N;
+        const size_t HW = 4 * plane;
+        const int col[4] = {0, 1, 1, 2};
+        size_t off[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+            off[ib] = (size_t)col[ib] * HW + (size_t)(2 * m + (ib >> 1)) * W + 2 * n + (ib & 1);
+        float up[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < B; ++t)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                up[ib] = up[ib] + out[(size_t)t * 3 * HW + off[ib]] * Phi[((size_t)t * 4 + ib) * plane + q];
+        const float norm = 2.0f / (float)(4 * plane);
+        float g[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const float d = up[ib] - y[(size_t)ib * plane + q];
+            acc += (double)(d * d);
+            g[ib] = norm * d;
+        }
+        for (int t = 0; t < B; ++t) {
+            float* dt = dout + (size_t)t * 3 * HW;
+            // zero the quad in all three planes, then the four CFA sites
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+                    *(float2*)(dt + (size_t)c * HW + (size_t)(2 * m + dy) * W + 2 * n) = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) dt[off[ib]] = g[ib] * Phi[((size_t)t * 4 + ib) * plane + q];
+        }
+    }
+    const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = s;
+}
+
+// DenBlock residual backward: out = center - x  ->  dx (c8, 8 channels: 0..2 = -dout, rest 0)
+__global__ void __launch_bounds__(256)
+fastdvd_finish_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx_c8, size_t HW) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (p >= HW) return;
+    const size_t o = (size_t)n * 3 * HW + p;
+    float4* d = (float4*)(dx_c8 + ((size_t)n * HW + p) * 8);
+    d[0] = make_float4(-dout[o], -dout[o + HW], -dout[o + 2 * HW], 0.f);
+    d[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// gradient w.r.t. the planar frames that fed scipnp_fastdvd_pack_triplets (+ the `center -` path):
+//   dframes[m][c] = dtin[m+1][c] + dtin[m][4+c] + dtin[m-1][8+c] + extra[m][c]     (indices mod B)
+__global__ void __launch_bounds__(256)
+fastdvd_unpack_bwd_kernel(const float* __restrict__ dtin, const float* __restrict__ extra, float* __restrict__ dframes,
+                          int B, size_t HW) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (p >= HW) return;
+    const int nxt = (m + 1) % B, prv = (m + B - 1) % B;
+    const float4 a = *(const float4*)(dtin + (((size_t)nxt * 2 + 0) * HW + p) * 8);          // frame m is f0 of window m+1
+    const float4 b = *(const float4*)(dtin + (((size_t)m * 2 + 0) * HW + p) * 8 + 4);        // f1 of window m
+    const float4 c = *(const float4*)(dtin + (((size_t)prv * 2 + 1) * HW + p) * 8);          // f2 of window m-1
+    const size_t o = (size_t)m * 3 * HW + p;
+    const float e0 = extra ? extra[o] : 0.f, e1 = extra ? extra[o + HW] : 0.f, e2 = extra ? extra[o + 2 * HW] : 0.f;
+    dframes[o] = ((a.x + b.x) + c.x) + e0;
+    dframes[o + HW] = ((a.y + b.y) + c.y) + e1;
+    dframes[o + 2 * HW] = ((a.z + b.z) + c.z) + e2;
+}
+
 }  // namespace scipnp
 
 using namespace scipnp;
@@ -63,6 +180,57 @@ int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, in
     hipLaunchKernelGGL(fastdvd_finish_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, center,
                        x_c8, out, HW);
     return launch_status("fastdvd_finish_kernel");
+}
+
+int scipnp_upsample_zero_c8(const float* in, float* out, int n, int C, int h, int w, int H, int W, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && out && n > 0 && C % 8 == 0 && h > 0 && w > 0 && H >= 2 * h - 1 && W >= 2 * w - 1 && H <= 2 * h &&
+                   W <= 2 * w, "bad arguments");
+    SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(out);
+    const size_t total = (size_t)n * (C / 8) * H * W * 2;
+    hipLaunchKernelGGL(upsample_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, h,
+                       w, H, W, total);
+    return launch_status("upsample_zero_kernel");
+}
+
+int scipnp_pixel_shuffle_bwd_c8(const float* dshuf, float* dconv, int n, int Cs, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(dshuf && dconv && n > 0 && Cs % 8 == 0 && h > 0 && w > 0, "bad arguments");
+    SCIPNP_ALIGNED(dconv);
+    const size_t total = (size_t)n * (4 * Cs / 8) * h * w;
+    hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, dshuf,
+                       dconv, Cs / 8, h, w, total);
+    return launch_status("unshuffle_bwd_kernel");
+}
+
+int scipnp_fastdvd_loss_grad(const float* out, const float* Phi, const float* y, float* dout, double* loss_part, int M,
+                             int N, int B, int* nblocks, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(nblocks && M > 0 && N > 0 && B > 0, "bad arguments");
+    const size_t plane = (size_t)M * N;
+    const unsigned blocks = (unsigned)((plane + 255) / 256);
+    *nblocks = (int)blocks;
+    if (loss_part == nullptr) return SCIPNP_OK;
+    SCIPNP_REQUIRE(out && Phi && y && dout, "null pointer");
+    hipLaunchKernelGGL(fastdvd_loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, out, Phi, y, dout, loss_part, M,
+                       N, B);
+    return launch_status("fastdvd_loss_grad_kernel");
+}
+
+int scipnp_fastdvd_finish_bwd(const float* dout, float* dx_c8, int B, int H, int W, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(dout && dx_c8 && B > 0 && B <= 65535, "bad arguments");
+    SCIPNP_ALIGNED(dx_c8);
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(fastdvd_finish_bwd_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, dout,
+                       dx_c8, HW);
+    return launch_status("fastdvd_finish_bwd_kernel");
+}
+
+int scipnp_fastdvd_unpack_bwd(const float* dtin_c8, const float* extra, float* dframes, int B, int H, int W,
+                              scipnp_stream_t s) {
+    SCIPNP_REQUIRE(dtin_c8 && dframes && B > 0 && B <= 65535, "bad arguments");
+    SCIPNP_ALIGNED(dtin_c8);
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(fastdvd_unpack_bwd_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s,
+                       dtin_c8, extra, dframes, B, HW);
+    return launch_status("fastdvd_unpack_bwd_kernel");
 }
 
 }  // extern "C"

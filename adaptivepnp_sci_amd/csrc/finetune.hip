@@ -73,7 +73,8 @@ constexpr int WG_THREADS = 9 * 64;                   // wave t <-> tap t
 template <int COB>
 __global__ void __launch_bounds__(WG_THREADS)
 conv3x3_wgrad_kernel(const float* __restrict__ act, const float* __restrict__ dz, float* __restrict__ slabs,
-                     int n_img, int CGin, int CGout, int H, int W) {
+                     int n_img, int CGin, int CGout, int cg0 /* first output channel group of this launch */,
+                     int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzs = smem;                                            // [4*COB][WG_DPITCH][8]
     float* as = smem + 4 * COB * WG_DPITCH * 8;                   // [4][WG_APITCH][8]
@@ -101,12 +102,13 @@ conv3x3_wgrad_kernel(const float* __restrict__ act, const float* __restrict__ dz
         __syncthreads();   // previous tile's reads done
         // dZ tile: all COB*4 channel groups x 64 pixels x 8
         for (int e = tid; e < 4 * COB * WG_PX * 2; e += WG_THREADS) {
-            const int half = e & 1, px = (e >> 1) % WG_PX, cg = (e >> 1) / WG_PX;
+            const int half = e & 1, px = (e >> 1) % WG_PX, cgl = (e >> 1) / WG_PX;
+            const int cg = cg0 + cgl;
             const int gy = y0 + px / WG_TW, gx = x0 + px % WG_TW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cg < CGout && gy < H && gx < W)
                 v = *(const float4*)(dz + (((size_t)n * CGout + cg) * HW + (size_t)gy * W + gx) * 8 + 4 * half);
-            *(float4*)(dzs + (cg * WG_DPITCH + px) * 8 + 4 * half) = v;
+            *(float4*)(dzs + (cgl * WG_DPITCH + px) * 8 + 4 * half) = v;
         }
         // activation tile with halo: the 4 channel groups of this ci block
         for (int e = tid; e < 4 * WG_AW * WG_AR * 2; e += WG_THREADS) {
@@ -145,17 +147,17 @@ conv3x3_wgrad_kernel(const float* __restrict__ act, const float* __restrict__ dz
 
 // dW[co][ci][tap] (OIHW, real channel counts) = sum over slabs in fixed order
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dW, int Cin_real, int Cout_real,
-                    int coP, int ciP) {
+wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ dW, int Cin_real, int co0,
+                    int co_count /* real output channels of this chunk */, int coP, int ciP) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = Cout_real * Cin_real * 9;
+    const int total = co_count * Cin_real * 9;
     if (idx >= total) return;
     const int tap = idx % 9, ci = (idx / 9) % Cin_real, co = idx / (9 * Cin_real);
     const size_t stride = (size_t)9 * coP * ciP;
     const float* p = slabs + ((size_t)tap * coP + co) * ciP + ci;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += p[k * stride];
-    dW[idx] = s;
+    for (int k = 0; k < nslab; ++k) s += p[(size_t)k * stride];
+    dW[((size_t)(co0 + co) * Cin_real + ci) * 9 + tap] = s;
 }
 
 // db[co] = sum_{n,y,x} dz[n][co/8][y][x][co%8]: one block per (channel group, image chunk) -> partials, then reduce
@@ -215,8 +217,9 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 // backward: the conv that maps dZ (Cout ch) to dA (Cin ch):  W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
 //           -> packed'[cog][tap][ciP][8], no bias
 __global__ void __launch_bounds__(256)
-pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ packed,
-                   int Cin_real, int Cout_real, int Kin /*padded in-ch of the packed conv*/, int KoutP, int transpose) {
+pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                   float* __restrict__ packed, int Cin_real, int Cout_real, int Kin /*padded in-ch of the packed conv*/,
+                   int KoutP, int transpose) {
     const size_t nw = (size_t)(Kin / 8) * 9 * KoutP * 8;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + KoutP) return;
@@ -232,12 +235,48 @@ pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, 
     const int in_ch = ig * 8 + c8;
     float val = 0.f;
     if (!transpose) {
-        if (o < Cout_real && in_ch < Cin_real) val = w[((size_t)o * Cin_real + in_ch) * 9 + tap];
+        if (o < Cout_real && in_ch < Cin_real) {
+            val = w[((size_t)o * Cin_real + in_ch) * 9 + tap];
+            if (scale) val = val * scale[o];
+        }
     } else {
         // packed conv: input channel = original co (in_ch), output channel = original ci (o), flipped tap
-        if (o < Cin_real && in_ch < Cout_real) val = w[((size_t)in_ch * Cin_real + o) * 9 + (8 - tap)];
+        if (o < Cin_real && in_ch < Cout_real) {
+            val = w[((size_t)in_ch * Cin_real + o) * 9 + (8 - tap)];
+            if (scale) val = val * scale[in_ch];
+        }
     }
     packed[i] = val;
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean[c] * sc;
+}
+
+// one wave per output channel
+__global__ void __launch_bounds__(64)
+bn_fold_grads_kernel(const float* __restrict__ W, const float* __restrict__ G, const float* __restrict__ sdy,
+                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ var,
+                     float eps, float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta, int K) {
+    const int co = blockIdx.x;
+    const float sd = sqrtf(var[co] + eps);
+    const float sc = gamma[co] / sd;
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const float g = G[(size_t)co * K + k];
+        dot += W[(size_t)co * K + k] * g;
+        dW[(size_t)co * K + k] = sc * g;
+    }
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+    if (threadIdx.x == 0) {
+        dgamma[co] = (dot - mean[co] * sdy[co]) / sd;
+        dbeta[co] = sdy[co];
+    }
 }
 
 static inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
@@ -247,6 +286,10 @@ static inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 using namespace scipnp;
 
 extern "C" {
+
+int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
+                                      int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
+                                      scipnp_stream_t s);
 
 int scipnp_ffdnet_loss_grad(const float* out_c8, const float* Phi, const float* y, float* gout_c8, double* loss_part,
                             int M, int N, int B, int* nblocks, scipnp_stream_t s) {
@@ -264,7 +307,8 @@ int scipnp_ffdnet_loss_grad(const float* out_c8, const float* Phi, const float* 
 
 size_t scipnp_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int nslab) {
     if (Cin <= 0 || Cout <= 0 || nslab <= 0) return 0;
-    return (size_t)nslab * 9 * round_up_i(Cout, 32) * round_up_i(Cin, 32);
+    const int chunk = round_up_i(Cout, 32) < 96 ? round_up_i(Cout, 32) : 96;
+    return (size_t)nslab * 9 * chunk * round_up_i(Cin, 32);
 }
 
 int scipnp_conv3x3_wgrad(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
@@ -273,23 +317,30 @@ int scipnp_conv3x3_wgrad(const float* act_c8, const float* dz_c8, float* dW, flo
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin_real <= Cin && Cout_real <= Cout &&
                    nslab > 0 && nslab <= 65535, "bad shape");
     SCIPNP_ALIGNED(act_c8); SCIPNP_ALIGNED(dz_c8);
-    const int coP = round_up_i(Cout, 32), ciP = round_up_i(Cin, 32);
-    const int COB = coP / 32;
-    SCIPNP_REQUIRE(COB >= 1 && COB <= 3, "wgrad supports Cout <= 96 (got %d)", Cout);
+    const int ciP = round_up_i(Cin, 32);
     hipStream_t st = (hipStream_t)s;
-    const dim3 grid(nslab, ciP / 32);
-    const size_t lds = (size_t)(4 * COB * WG_DPITCH + 4 * WG_APITCH) * 8 * sizeof(float);
+    // output channels in chunks of <= 96 (3 MFMA row blocks per wave); one slab set + reduction per chunk
+    for (int co0 = 0; co0 < Cout_real; co0 += 96) {
+        const int left = round_up_i(Cout, 32) - co0;
+        const int coP = left < 96 ? left : 96;
+        const int COB = coP / 32;
+        const dim3 grid(nslab, ciP / 32);
+        const size_t lds = (size_t)(4 * COB * WG_DPITCH + 4 * WG_APITCH) * 8 * sizeof(float);
 #define SCIPNP_GO(C)                                                                                           \
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<C>), grid, dim3(WG_THREADS), lds, st, act_c8, dz_c8, workspace, n, \
-                       Cin / 8, Cout / 8, h, w)
-    if (COB == 1) SCIPNP_GO(1); else if (COB == 2) SCIPNP_GO(2); else SCIPNP_GO(3);
+                       Cin / 8, Cout / 8, co0 / 8, h, w)
+        if (COB == 1) SCIPNP_GO(1); else if (COB == 2) SCIPNP_GO(2); else SCIPNP_GO(3);
 #undef SCIPNP_GO
-    int rc = launch_status("conv3x3_wgrad_kernel");
-    if (rc) return rc;
-    const int total = Cout_real * Cin_real * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, nslab, dW, Cin_real,
-                       Cout_real, coP, ciP);
-    return launch_status("wgrad_reduce_kernel");
+        int rc = launch_status("conv3x3_wgrad_kernel");
+        if (rc) return rc;
+        const int co_count = (Cout_real - co0) < coP ? (Cout_real - co0) : coP;
+        const int total = co_count * Cin_real * 9;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, nslab, dW,
+                           Cin_real, co0, co_count, coP, ciP);
+        rc = launch_status("wgrad_reduce_kernel");
+        if (rc) return rc;
+    }
+    return SCIPNP_OK;
 }
 
 int scipnp_conv_bias_grad(const float* dz_c8, float* db, float* workspace, int n, int Cout_real, int Cout, int h, int w,
@@ -321,14 +372,40 @@ int scipnp_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 
 int scipnp_pack_conv3x3_device(const float* w, const float* bias, float* packed, int Cin_real, int Cout_real, int Cin,
                                int Cout, int transpose_flip, scipnp_stream_t s) {
+    return scipnp_pack_conv3x3_device_scaled(w, bias, nullptr, packed, Cin_real, Cout_real, Cin, Cout, transpose_flip, s);
+}
+
+int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
+                                      int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
+                                      scipnp_stream_t s) {
     SCIPNP_REQUIRE(w && packed && Cin % 8 == 0 && Cout % 8 == 0 && Cin_real <= Cin && Cout_real <= Cout, "bad arguments");
     // forward: packed conv has Cin inputs, Cout outputs; backward-data: Cout inputs, Cin outputs
     const int Kin = transpose_flip ? Cout : Cin;
     const int KoutP = round_up_i(transpose_flip ? Cin : Cout, 32);
     const size_t total = (size_t)(Kin / 8) * 9 * KoutP * 8 + KoutP;
     hipLaunchKernelGGL(pack_device_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, bias,
-                       packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
+                       scale, packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
     return launch_status("pack_device_kernel");
+}
+
+// ---- eval-mode BatchNorm folded into the preceding bias-free conv:  y = conv(x; W)*s + t,
+//      s = gamma/sqrt(var+eps), t = beta - mean*s.  Given G = wgrad(x, dy) and sdy = sum dy:
+//      dW = s*G,  dgamma = (<W,G> - mean*sdy)/sqrt(var+eps),  dbeta = sdy.
+int scipnp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                   float* shift, int C, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, gamma, beta, mean, var, eps, scale,
+                       shift, C);
+    return launch_status("bn_fold_kernel");
+}
+
+int scipnp_bn_fold_grads(const float* W, const float* G, const float* sdy, const float* gamma, const float* mean,
+                         const float* var, float eps, float* dW, float* dgamma, float* dbeta, int Cout, int K,
+                         scipnp_stream_t s) {
+    SCIPNP_REQUIRE(W && G && sdy && gamma && mean && var && dW && dgamma && dbeta && Cout > 0 && K > 0, "bad arguments");
+    hipLaunchKernelGGL(bn_fold_grads_kernel, dim3(Cout), dim3(64), 0, (hipStream_t)s, W, G, sdy, gamma, mean, var, eps, dW,
+                       dgamma, dbeta, K);
+    return launch_status("bn_fold_grads_kernel");
 }
 
 }  // extern "C"

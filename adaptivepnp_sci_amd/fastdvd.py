@@ -121,6 +121,51 @@ def pack_denblock(sd, prefix, device):
     return packed
 
 
+BUF_KEYS = ('t_in', 't96', 'x0', 'a0', 'a1', 'x1', 'd0', 'd1', 'x2', 'u0', 'u1', 's64', 'c0', 'c1', 's32', 'o32', 'x8')
+
+
+def alloc_denblock_buffers(B, H, W, device, alias=True):
+    """c8 activation buffers of one DenBlock evaluation on B triplets.  alias=True reuses dead buffers
+    (inference); alias=False keeps every activation (the finetune's backward pass needs them)."""
+    f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
+    H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+    b = dict(t_in=f(16, H, W), t96=f(96, H, W), x0=f(32, H, W), s32=f(32, H, W), o32=f(32, H, W), x8=f(8, H, W))
+    if alias:
+        a = [f(64, H2, W2) for _ in range(3)]
+        d = [f(128, H4, W4) for _ in range(3)]
+        b.update(a0=a[0], a1=a[1], x1=a[0], d0=d[0], d1=d[1], x2=d[0], u0=d[1], u1=d[2], s64=a[1], c0=a[2], c1=a[1])
+    else:
+        for k in ('a0', 'a1', 'x1', 's64', 'c0', 'c1'):
+            b[k] = f(64, H2, W2)
+        for k in ('d0', 'd1', 'x2', 'u0', 'u1'):
+            b[k] = f(128, H4, W4)
+    return b
+
+
+def denblock_forward(pk, frames, sigma, out, b):
+    """out[n] = DenBlock(frames[n-1], frames[n], frames[n+1]) for all n (circular); pk = 16 packed layers,
+    b = buffers from alloc_denblock_buffers.  reference packages/fastdvdnet/models.py:179-198."""
+    c = ops.conv3x3_c8
+    ops.fastdvd_pack_triplets(frames, sigma, b['t_in'])
+    c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
+    c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
+    c(b['x0'], pk[2], 64, relu=True, stride2=True, out=b['a0'])
+    c(b['a0'], pk[3], 64, relu=True, out=b['a1'])
+    c(b['a1'], pk[4], 64, relu=True, out=b['x1'])
+    c(b['x1'], pk[5], 128, relu=True, stride2=True, out=b['d0'])
+    c(b['d0'], pk[6], 128, relu=True, out=b['d1'])
+    c(b['d1'], pk[7], 128, relu=True, out=b['x2'])
+    c(b['x2'], pk[8], 128, relu=True, out=b['u0'])
+    c(b['u0'], pk[9], 128, relu=True, out=b['u1'])
+    c(b['u1'], pk[10], 256, shuffle=True, residual=b['x1'], out=b['s64'])     # x1 + upc2(x2)
+    c(b['s64'], pk[11], 64, relu=True, out=b['c0'])
+    c(b['c0'], pk[12], 64, relu=True, out=b['c1'])
+    c(b['c1'], pk[13], 128, shuffle=True, residual=b['x0'], out=b['s32'])     # x0 + upc1(.)
+    c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
+    c(b['o32'], pk[15], 8, out=b['x8'])
+    return ops.fastdvd_finish(frames, b['x8'], out)
+
+
 class FastDVDEngine:
     def __init__(self, model, B, H, W, device):
         if H % 4 or W % 4:
@@ -128,16 +173,7 @@ class FastDVDEngine:
                              'its padding of the noise map breaks for more than one frame, fastdvdnet.py:126)')
         self.B, self.H, self.W, self.device = B, H, W, device
         self.refresh(model)
-        f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
-        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
-        self.t_in = f(16, H, W)
-        self.t96 = f(96, H, W)
-        self.x0 = f(32, H, W)
-        self.a64 = [f(64, H2, W2) for _ in range(3)]
-        self.a128 = [f(128, H4, W4) for _ in range(3)]
-        self.u32 = f(32, H, W)
-        self.o32 = f(32, H, W)
-        self.x8 = f(8, H, W)
+        self.bufs = alloc_denblock_buffers(B, H, W, device, alias=True)
         self.s1 = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
         self.out = torch.empty_like(self.s1)
 
@@ -145,30 +181,7 @@ class FastDVDEngine:
         sd = _strip(model.state_dict())
         self.packed = {p: pack_denblock(sd, p, self.device) for p in ('temp1', 'temp2')}
 
-    def _denblock(self, pk, frames, sigma, out):
-        """out[n] = DenBlock(frames[n-1], frames[n], frames[n+1]) for all n (circular)."""
-        c = ops.conv3x3_c8
-        ops.fastdvd_pack_triplets(frames, sigma, self.t_in)
-        c(self.t_in, pk[0], 96, relu=True, out=self.t96, head=True)
-        c(self.t96, pk[1], 32, relu=True, out=self.x0)
-        a, d = self.a64, self.a128
-        c(self.x0, pk[2], 64, relu=True, stride2=True, out=a[0])
-        c(a[0], pk[3], 64, relu=True, out=a[1])
-        c(a[1], pk[4], 64, relu=True, out=a[0])                     # x1 = a[0]
-        c(a[0], pk[5], 128, relu=True, stride2=True, out=d[0])
-        c(d[0], pk[6], 128, relu=True, out=d[1])
-        c(d[1], pk[7], 128, relu=True, out=d[0])                    # x2 = d[0]
-        c(d[0], pk[8], 128, relu=True, out=d[1])
-        c(d[1], pk[9], 128, relu=True, out=d[2])
-        c(d[2], pk[10], 256, shuffle=True, residual=a[0], out=a[1])  # x1 + upc2(x2)
-        c(a[1], pk[11], 64, relu=True, out=a[2])
-        c(a[2], pk[12], 64, relu=True, out=a[1])
-        c(a[1], pk[13], 128, shuffle=True, residual=self.x0, out=self.u32)   # x0 + upc1(.)
-        c(self.u32, pk[14], 32, relu=True, out=self.o32)
-        c(self.o32, pk[15], 8, out=self.x8)
-        return ops.fastdvd_finish(frames, self.x8, out)
-
     def forward(self, frames, sigma):
         """frames planar (B,3,H,W) -> denoised planar (B,3,H,W) (owned by the engine, overwritten per call)."""
-        self._denblock(self.packed['temp1'], frames, sigma, self.s1)
-        return self._denblock(self.packed['temp2'], self.s1, sigma, self.out)
+        denblock_forward(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
+        return denblock_forward(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)

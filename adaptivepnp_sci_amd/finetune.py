@@ -152,6 +152,253 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
     return model
 
 
-def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None):
-    raise NotImplementedError('FastDVDnet online finetune (reference test_fastdvdnet.py:343-451) is not built yet: '
-                              'run with update_=False for the fastdvd_color denoiser')
+# ============================================================================================ FastDVDnet
+class _DenBlockTrainer:
+    """Master parameters, folded/packed weights, gradients and Adam state of one DenBlock (temp1 / temp2)."""
+
+    # per layer: (input buffer key, output-gradient resolution divisor, stride2, shuffle)
+    def __init__(self, sd, prefix, device, lib):
+        from .fastdvd import _LAYERS, _BN_EPS
+        self.lib, self.dev, self.prefix = lib, device, prefix
+        self.eps = _BN_EPS
+        self.spec = _LAYERS
+        self.sd_keys = []
+        self.W, self.gamma, self.beta, self.mean, self.var = [], [], [], [], []
+        for key, bn, cin, cout, *_ in _LAYERS:
+            wk = f'{prefix}.{key}.weight'
+            self.W.append(sd[wk].detach().to(device, F32).contiguous().clone())
+            if bn is not None:
+                self.gamma.append(sd[f'{prefix}.{bn}.weight'].detach().to(device, F32).clone())
+                self.beta.append(sd[f'{prefix}.{bn}.bias'].detach().to(device, F32).clone())
+                self.mean.append(sd[f'{prefix}.{bn}.running_mean'].detach().to(device, F32).clone())
+                self.var.append(sd[f'{prefix}.{bn}.running_var'].detach().to(device, F32).clone())
+            else:
+                self.gamma.append(None); self.beta.append(None); self.mean.append(None); self.var.append(None)
+        n = len(_LAYERS)
+        self.scale = [None if g is None else torch.empty_like(g) for g in self.gamma]
+        self.shift = [None if g is None else torch.empty_like(g) for g in self.gamma]
+        self.fwd = [torch.empty(lib.scipnp_conv3x3_packed_floats(ci, co), dtype=F32, device=device)
+                    for _, _, ci, co, *_ in _LAYERS]
+        self.bwd = [torch.empty(lib.scipnp_conv3x3_packed_floats(co, ci), dtype=F32, device=device)
+                    for _, _, ci, co, *_ in _LAYERS]
+        self.dense0 = torch.zeros(90, 12, 3, 3, dtype=F32, device=device)      # block-diagonal form of the grouped conv
+        self.G = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
+        self.dW = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
+        self.dW0_grouped = torch.empty_like(self.W[0])
+        self.sdy = [None if g is None else torch.empty_like(g) for g in self.gamma]
+        self.dgamma = [None if g is None else torch.empty_like(g) for g in self.gamma]
+        self.dbeta = [None if g is None else torch.empty_like(g) for g in self.gamma]
+        self.params = [(f'{prefix}.{key}.weight', self.W[i]) for i, (key, *_r) in enumerate(_LAYERS)]
+        for i, (key, bn, *_r) in enumerate(_LAYERS):
+            if bn is not None:
+                self.params.append((f'{prefix}.{bn}.weight', self.gamma[i]))
+                self.params.append((f'{prefix}.{bn}.bias', self.beta[i]))
+        self.m = [torch.zeros_like(p) for _, p in self.params]
+        self.v = [torch.zeros_like(p) for _, p in self.params]
+
+    def dense_w(self, i):
+        if i != 0:
+            return self.W[i]
+        for g in range(3):                                   # data movement only: grouped -> block-diagonal
+            self.dense0[g * 30:(g + 1) * 30, g * 4:(g + 1) * 4] = self.W[0][g * 30:(g + 1) * 30]
+        return self.dense0
+
+    def pack(self):
+        lib = self.lib
+        for i, (key, bn, cin, cout, *_r) in enumerate(self.spec):
+            w = self.dense_w(i)
+            co_r, ci_r = w.shape[0], w.shape[1]
+            sc = sh = None
+            if bn is not None:
+                _lib.check(lib.scipnp_bn_fold(_ptr(self.gamma[i]), _ptr(self.beta[i]), _ptr(self.mean[i]), _ptr(self.var[i]),
+                                              self.eps, _ptr(self.scale[i]), _ptr(self.shift[i]), co_r, _s()), 'bn_fold')
+                sc, sh = self.scale[i], self.shift[i]
+            _lib.check(lib.scipnp_pack_conv3x3_device_scaled(_ptr(w), _ptr(sh), _ptr(sc), _ptr(self.fwd[i]), ci_r, co_r, cin,
+                                                             cout, 0, _s()), 'pack fwd')
+            _lib.check(lib.scipnp_pack_conv3x3_device_scaled(_ptr(w), None, _ptr(sc), _ptr(self.bwd[i]), ci_r, co_r, cin,
+                                                             cout, 1, _s()), 'pack bwd')
+
+    def grads_of_layer(self, i, x_in, dy, n, h, w, ws, bws, nslab):
+        """parameter gradients of layer i from its input activation and the gradient at its (BN) output"""
+        lib = self.lib
+        key, bn, cin, cout, *_r = self.spec[i]
+        wd = self.dense_w(i)
+        co_r, ci_r = wd.shape[0], wd.shape[1]
+        _lib.check(lib.scipnp_conv3x3_wgrad(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin, cout,
+                                            h, w, _s()), 'wgrad')
+        if bn is not None:
+            _lib.check(lib.scipnp_conv_bias_grad(_ptr(dy), _ptr(self.sdy[i]), _ptr(bws), n, co_r, cout, h, w, _s()), 'bgrad')
+            _lib.check(lib.scipnp_bn_fold_grads(_ptr(wd), _ptr(self.G[i]), _ptr(self.sdy[i]), _ptr(self.gamma[i]),
+                                                _ptr(self.mean[i]), _ptr(self.var[i]), self.eps, _ptr(self.dW[i]),
+                                                _ptr(self.dgamma[i]), _ptr(self.dbeta[i]), co_r, ci_r * 9, _s()), 'bn grads')
+        else:
+            self.dW[i].copy_(self.G[i])
+        if i == 0:
+            for g in range(3):
+                self.dW0_grouped[g * 30:(g + 1) * 30] = self.dW[0][g * 30:(g + 1) * 30, g * 4:(g + 1) * 4]
+
+    def grad_list(self):
+        out = [self.dW0_grouped] + self.dW[1:]
+        for i, (key, bn, *_r) in enumerate(self.spec):
+            if bn is not None:
+                out += [self.dgamma[i], self.dbeta[i]]
+        return out
+
+
+class _FastDVDTrainer:
+    NSLAB = 256
+
+    def __init__(self, model, eng):
+        from .fastdvd import _strip, alloc_denblock_buffers
+        self.eng = eng
+        self.lib = _lib.load()
+        dev = eng.device
+        self.model_sd = model.state_dict()
+        self.prefixed = any(k.startswith('module.') for k in self.model_sd)
+        sd = _strip(self.model_sd)
+        self.blocks = {p: _DenBlockTrainer(sd, p, dev, self.lib) for p in ('temp1', 'temp2')}
+        B, H, W = eng.B, eng.H, eng.W
+        self.stash = {p: alloc_denblock_buffers(B, H, W, dev, alias=False) for p in ('temp1', 'temp2')}
+        f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=F32, device=dev)  # noqa: E731
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        # gradient scratch (reused by both stages)
+        self.g = dict(x8=f(8, H, W), f32a=f(32, H, W), f32b=f(32, H, W), f32c=f(32, H, W), f96=f(96, H, W), f16=f(16, H, W),
+                      up64=f(64, H, W), h64a=f(64, H2, W2), h64b=f(64, H2, W2), h64c=f(64, H2, W2), h128=f(128, H2, W2),
+                      q128a=f(128, H4, W4), q128b=f(128, H4, W4), q256=f(256, H4, W4))
+        self.s1 = torch.empty(B, 3, H, W, dtype=F32, device=dev)
+        self.out = torch.empty_like(self.s1)
+        self.dout = torch.empty_like(self.s1)
+        self.ds1 = torch.empty_like(self.s1)
+        ws = max(self.lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, self.NSLAB)
+                 for _, _, ci, co, *_ in self.blocks['temp1'].spec)
+        self.ws = torch.empty(ws, dtype=F32, device=dev)
+        self.bws = torch.empty(32 * 64 * 8, dtype=F32, device=dev)
+        nb_ = C.c_int(0)
+        _lib.check(self.lib.scipnp_fastdvd_loss_grad(None, None, None, None, None, H // 2, W // 2, B, C.byref(nb_), None), 'size')
+        self.loss_part = torch.empty(nb_.value, dtype=torch.float64, device=dev)
+        self.step = 0
+
+    def pack(self):
+        for b in self.blocks.values():
+            b.pack()
+
+    def forward(self, frames, sigma):
+        from .fastdvd import denblock_forward
+        denblock_forward(self.blocks['temp1'].fwd, frames, sigma, self.s1, self.stash['temp1'])
+        denblock_forward(self.blocks['temp2'].fwd, self.s1, sigma, self.out, self.stash['temp2'])
+
+    def loss_and_grad(self, y_pm, Phi_pm):
+        eng = self.eng
+        nb_ = C.c_int(0)
+        _lib.check(self.lib.scipnp_fastdvd_loss_grad(_ptr(self.out), _ptr(Phi_pm), _ptr(y_pm), _ptr(self.dout),
+                                                     _ptr(self.loss_part), eng.H // 2, eng.W // 2, eng.B, C.byref(nb_), _s()),
+                   'scipnp_fastdvd_loss_grad')
+        return self.loss_part.sum() / float(eng.H * eng.W)
+
+    def _bwd(self, blk, i, dz, out, n, h, w, residual=None, mask=None):
+        """backward-data of layer i: out = [mask]( conv(dz; W_i^T flipped, BN scale folded) [+ residual] );
+        (h, w) = size of dz (already zero-upsampled for stride-2 layers)."""
+        _k, _bn, cin, cout, *_r = blk.spec[i]
+        flags = (2 if residual is not None else 0) | (16 if mask is not None else 0)
+        _lib.check(self.lib.scipnp_conv3x3_c8_ex(_ptr(dz), _ptr(blk.bwd[i]), _ptr(out), _ptr(residual), _ptr(mask), n, cout,
+                                                 cin, h, w, flags, _s()), 'backward-data conv')
+        return out
+
+    def backward_block(self, name, dout, dframes=None):
+        """dout: planar gradient at the DenBlock output; fills the block's parameter gradients and, if `dframes`
+        is given, the gradient w.r.t. the planar input frames (incl. the `center -` path)."""
+        lib, eng, g = self.lib, self.eng, self.g
+        blk, a = self.blocks[name], self.stash[name]
+        B, H, W = eng.B, eng.H, eng.W
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(i, x_in, dy, B, h, w, self.ws, self.bws, self.NSLAB)  # noqa: E731
+        _lib.check(lib.scipnp_fastdvd_finish_bwd(_ptr(dout), _ptr(g['x8']), B, H, W, _s()), 'finish_bwd')
+        gl(15, a['o32'], g['x8'], H, W)
+        dy14 = self._bwd(blk, 15, g['x8'], g['f32a'], B, H, W, mask=a['o32'])
+        gl(14, a['s32'], dy14, H, W)
+        d_s32 = self._bwd(blk, 14, dy14, g['f32b'], B, H, W)                          # skip: also the gradient of x0
+        _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(_ptr(d_s32), _ptr(g['h128']), B, 32, H2, W2, _s()), 'unshuffle')
+        gl(13, a['c1'], g['h128'], H2, W2)
+        dy12 = self._bwd(blk, 13, g['h128'], g['h64a'], B, H2, W2, mask=a['c1'])
+        gl(12, a['c0'], dy12, H2, W2)
+        dy11 = self._bwd(blk, 12, dy12, g['h64b'], B, H2, W2, mask=a['c0'])
+        gl(11, a['s64'], dy11, H2, W2)
+        d_s64 = self._bwd(blk, 11, dy11, g['h64c'], B, H2, W2)                        # skip: also the gradient of x1
+        _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(_ptr(d_s64), _ptr(g['q256']), B, 64, H4, W4, _s()), 'unshuffle')
+        gl(10, a['u1'], g['q256'], H4, W4)
+        dy9 = self._bwd(blk, 10, g['q256'], g['q128a'], B, H4, W4, mask=a['u1'])
+        gl(9, a['u0'], dy9, H4, W4)
+        dy8 = self._bwd(blk, 9, dy9, g['q128b'], B, H4, W4, mask=a['u0'])
+        gl(8, a['x2'], dy8, H4, W4)
+        dy7 = self._bwd(blk, 8, dy8, g['q128a'], B, H4, W4, mask=a['x2'])
+        gl(7, a['d1'], dy7, H4, W4)
+        dy6 = self._bwd(blk, 7, dy7, g['q128b'], B, H4, W4, mask=a['d1'])
+        gl(6, a['d0'], dy6, H4, W4)
+        dy5 = self._bwd(blk, 6, dy6, g['q128a'], B, H4, W4, mask=a['d0'])
+        # stride-2 layer 5 (x1 @H/2 -> d0 @H/4): gradient = stride-1 backward of the zero-upsampled dy5
+        _lib.check(lib.scipnp_upsample_zero_c8(_ptr(dy5), _ptr(g['h128']), B, 128, H4, W4, H2, W2, _s()), 'upsample')
+        gl(5, a['x1'], g['h128'], H2, W2)
+        dy4 = self._bwd(blk, 5, g['h128'], g['h64a'], B, H2, W2, residual=d_s64, mask=a['x1'])
+        gl(4, a['a1'], dy4, H2, W2)
+        dy3 = self._bwd(blk, 4, dy4, g['h64b'], B, H2, W2, mask=a['a1'])
+        gl(3, a['a0'], dy3, H2, W2)
+        dy2 = self._bwd(blk, 3, dy3, g['h64a'], B, H2, W2, mask=a['a0'])
+        _lib.check(lib.scipnp_upsample_zero_c8(_ptr(dy2), _ptr(g['up64']), B, 64, H2, W2, H, W, _s()), 'upsample')
+        gl(2, a['x0'], g['up64'], H, W)
+        dy1 = self._bwd(blk, 2, g['up64'], g['f32c'], B, H, W, residual=d_s32, mask=a['x0'])
+        gl(1, a['t96'], dy1, H, W)
+        dy0 = self._bwd(blk, 1, dy1, g['f96'], B, H, W, mask=a['t96'])
+        gl(0, a['t_in'], dy0, H, W)
+        if dframes is not None:
+            d_tin = self._bwd(blk, 0, dy0, g['f16'], B, H, W)
+            _lib.check(lib.scipnp_fastdvd_unpack_bwd(_ptr(d_tin), _ptr(dout), _ptr(dframes), B, H, W, _s()), 'unpack_bwd')
+
+    def adam(self, lr):
+        self.step += 1
+        for blk in self.blocks.values():
+            for (_, p), gr, m, v in zip(blk.params, blk.grad_list(), blk.m, blk.v):
+                _lib.check(self.lib.scipnp_adam_step(_ptr(p), _ptr(gr), _ptr(m), _ptr(v), p.numel(), float(lr), 0.9, 0.999,
+                                                     1e-8, self.step, _s()), 'scipnp_adam_step')
+
+    def write_back(self):
+        with torch.no_grad():
+            for blk in self.blocks.values():
+                for key, p in blk.params:
+                    self.model_sd[('module.' + key) if self.prefixed else key].copy_(p)
+
+
+def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None,
+                               noise=None):
+    """reference packages/fastdvdnet/test_fastdvdnet.py:343-451.  frames: planar (B,3,H,W) net input; the net is
+    trained on  frames + float32(float64(frames) + N(0,(5/255)^2))  -- i.e. 2*frames + noise, the reference's
+    helper already returns input+noise (utils/utils_image.py:183-192) -- with the noise drawn from the GLOBAL
+    NumPy RNG like the reference (pass `noise` (B,3,H,W) float64 to override).  All conv weights and BatchNorm
+    affine parameters are updated (BatchNorm statistics frozen: every BN is in eval(), :376-379)."""
+    _lib.require_gpu()
+    steps = [update_per_iter] if isinstance(update_per_iter, int) else list(update_per_iter)
+    lrs = [lr_] if isinstance(update_per_iter, int) else list(lr_)
+    v_np = frames.detach().cpu().numpy()
+    if noise is None:
+        noise = np.random.normal(0, 5 / 255, v_np.shape)
+    v_plus = (frames + torch.from_numpy(v_np + noise).float().to(frames.device)).contiguous()
+    tr = _FastDVDTrainer(model, eng)
+    tr.pack()
+    for n_steps, lr_i in zip(steps, lrs):
+        tr.step = 0
+        for blk in tr.blocks.values():                        # a new Adam per lr group (:385)
+            for m, v in zip(blk.m, blk.v):
+                m.zero_(); v.zero_()
+        for _ in range(n_steps):
+            tr.forward(v_plus, sigma)
+            loss = tr.loss_and_grad(y_pm, Phi_pm)
+            tr.backward_block('temp2', tr.dout, tr.ds1)
+            tr.backward_block('temp1', tr.ds1, None)
+            tr.adam(lr_i)
+            tr.pack()
+            val = float(loss.item())
+            print('loss:', val)
+            if trace is not None:
+                trace.append(val)
+    tr.write_back()
+    eng.packed = {p: b.fwd for p, b in tr.blocks.items()}
+    return model

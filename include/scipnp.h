@@ -162,6 +162,11 @@ int scipnp_pack_conv3x3_weights(const float* w, const float* bias, const float* 
                                 float* packed);
 int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const float* residual,
                       int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+/* same with separate pointers for the residual add (bit1) and the ReLU-backward mask source (bit4), so that a
+ * skip-connection gradient can be added before masking: out = mask(conv + residual) */
+int scipnp_conv3x3_c8_ex(const float* in, const float* packed_w, float* out, const float* residual,
+                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags,
+                         scipnp_stream_t s);
 
 /* whole FFDNet-colour forward on B frames: 12 (nb) conv layers ping-ponging between two c8 scratch
  * buffers of n*nc*h*w floats each.  in_c8: [B][2][M][N][8] from scipnp_pm_pre_denoise, out_c8:
@@ -195,6 +200,20 @@ int scipnp_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 int scipnp_pack_conv3x3_device(const float* w, const float* bias, float* packed, int Cin_real, int Cout_real,
                                int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
 
+/* same with a per-output-channel scale folded into the weights (eval-mode BatchNorm: scale = gamma/sqrt(var+eps),
+ * `bias` = the folded shift) */
+int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
+                                      int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
+                                      scipnp_stream_t s);
+/* eval-mode BatchNorm after a bias-free conv, y = conv(x;W)*s + t: fold (s, t) and the parameter gradients
+ * dW = s*G, dgamma = (<W,G> - mean*sum(dy))/sqrt(var+eps), dbeta = sum(dy), G = wgrad(x, dy), K = Cin*9
+ * -- packages/fastdvdnet/models.py:16-89 with BN kept in eval() during finetune (test_fastdvdnet.py:376-379) */
+int scipnp_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   float* scale, float* shift, int C, scipnp_stream_t s);
+int scipnp_bn_fold_grads(const float* W, const float* G, const float* sdy, const float* gamma, const float* mean,
+                         const float* var, float eps, float* dW, float* dgamma, float* dbeta, int Cout, int K,
+                         scipnp_stream_t s);
+
 /* ---------------------------------------------------------------- FastDVDnet glue
  * DenBlock input from planar frames [B][3][H][W] with circular temporal indexing: out c8 [B][2][H][W][8],
  * entry n = (frame n-1, sigma, frame n, sigma | frame n+1, sigma, 0...), indices mod B.
@@ -204,6 +223,22 @@ int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int 
 /* DenBlock residual: out[n][c] = center[n][c] - x_c8[n][0][..][c], c < 3  -- models.py:196 (in1 - x) */
 int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,
                           scipnp_stream_t s);
+
+/* backward-pass glue of the FastDVDnet online finetune (reference test_fastdvdnet.py:343-451) */
+/* zero-insertion upsample (gradient path of a stride-2 conv): out[n][cg][2y][2x] = in[n][cg][y][x] */
+int scipnp_upsample_zero_c8(const float* in, float* out, int n, int C, int h, int w, int H, int W,
+                            scipnp_stream_t s);
+/* PixelShuffle(2) backward: dshuf [n][Cs/8][2h][2w][8] -> dconv [n][4Cs/8][h][w][8] */
+int scipnp_pixel_shuffle_bwd_c8(const float* dshuf, float* dconv, int n, int Cs, int h, int w, scipnp_stream_t s);
+/* measurement loss on planar frames [B][3][H][W] and its gradient (zero off the CFA sites); loss partials as in
+ * scipnp_ffdnet_loss_grad                                       -- test_fastdvdnet.py:424-431 */
+int scipnp_fastdvd_loss_grad(const float* out, const float* Phi, const float* y, float* dout, double* loss_part,
+                             int M, int N, int B, int* nblocks, scipnp_stream_t s);
+/* d(center - x)/dx: dx_c8 [B][1][H][W][8] = (-dout.rgb, 0...) */
+int scipnp_fastdvd_finish_bwd(const float* dout, float* dx_c8, int B, int H, int W, scipnp_stream_t s);
+/* gradient w.r.t. the planar frames behind scipnp_fastdvd_pack_triplets, plus `extra` (may be NULL) */
+int scipnp_fastdvd_unpack_bwd(const float* dtin_c8, const float* extra, float* dframes, int B, int H, int W,
+                              scipnp_stream_t s);
 
 #ifdef __cplusplus
 }

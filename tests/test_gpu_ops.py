@@ -393,3 +393,65 @@ def test_adam_step_matches_torch(ops):
         upd_ref, upd = (ref.detach() - p0).numpy(), (pd.cpu() - p0).numpy()
         assert rel_l2(upd, upd_ref) < 1e-3, step          # the update itself (~lr), float32 round-off of p dominates
         assert rel_l2(pd.cpu().numpy(), ref.detach().numpy()) < 1e-7
+
+
+def test_fastdvd_backward_glue_vs_autograd(ops):
+    """stride-2 conv gradients through zero-insertion upsampling, PixelShuffle backward, folded-BN parameter
+    gradients: against float64 autograd."""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+    g = torch.Generator().manual_seed(21)
+    n, cin, cout, h, w = 2, 32, 64, 12, 40
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    mean, var = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    dy = torch.randn(n, cout, h // 2, w // 2, generator=g)
+    xd, wd, gd, bd = (t.double().requires_grad_() for t in (x, wt, gamma, beta))
+    u = torch.nn.functional.conv2d(xd, wd, None, stride=2, padding=1)
+    y = torch.nn.functional.batch_norm(u, mean.double(), var.double(), gd, bd, training=False, eps=1e-5)
+    y.backward(dy.double())
+    # device side
+    dy8 = ops.to_c8(dy.cuda())
+    up = torch.empty(n, cout // 8, h, w, 8, device='cuda')
+    _lib.check(lib.scipnp_upsample_zero_c8(p(dy8), p(up), n, cout, h // 2, w // 2, h, w, s), 'up')
+    x8 = ops.to_c8(x.cuda())
+    nslab = 8
+    ws = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(cin, cout, nslab), device='cuda')
+    G = torch.empty(cout, cin, 3, 3, device='cuda')
+    _lib.check(lib.scipnp_conv3x3_wgrad(p(x8), p(up), p(G), p(ws), nslab, n, cin, cout, cin, cout, h, w, s), 'wgrad')
+    sdy = torch.empty(cout, device='cuda')
+    bws = torch.empty((cout // 8) * 64 * 8, device='cuda')
+    _lib.check(lib.scipnp_conv_bias_grad(p(dy8), p(sdy), p(bws), n, cout, cout, h // 2, w // 2, s), 'bgrad')
+    dW, dga, dbe = torch.empty_like(G), torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    W_d, ga_d, mu_d, var_d = wt.cuda(), gamma.cuda(), mean.cuda(), var.cuda()
+    _lib.check(lib.scipnp_bn_fold_grads(p(W_d), p(G), p(sdy), p(ga_d), p(mu_d), p(var_d), 1e-5, p(dW), p(dga), p(dbe), cout,
+                                        cin * 9, s), 'bn grads')
+    assert rel_l2(dW.cpu().numpy(), wd.grad.numpy()) < 2e-6
+    assert rel_l2(dga.cpu().numpy(), gd.grad.numpy()) < 2e-5
+    assert rel_l2(dbe.cpu().numpy(), bd.grad.numpy()) < 2e-6
+    # backward-data of the stride-2 + BN layer = stride-1 transposed conv of the upsampled gradient, scale folded
+    sc, sh = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    be_d = beta.cuda()
+    _lib.check(lib.scipnp_bn_fold(p(ga_d), p(be_d), p(mu_d), p(var_d), 1e-5, p(sc), p(sh), cout, s), 'fold')
+    pk = torch.empty(lib.scipnp_conv3x3_packed_floats(cout, cin), device='cuda')
+    _lib.check(lib.scipnp_pack_conv3x3_device_scaled(p(W_d), None, p(sc), p(pk), cin, cout, cin, cout, 1, s), 'pack')
+    dx = torch.empty(n, cin // 8, h, w, 8, device='cuda')
+    _lib.check(lib.scipnp_conv3x3_c8_ex(p(up), p(pk), p(dx), None, None, n, cout, cin, h, w, 0, s), 'bwd')
+    assert rel_l2(ops.from_c8(dx).cpu().numpy(), xd.grad.numpy()) < 2e-6
+    # forward with the folded pack == conv + BN
+    pkf = torch.empty(lib.scipnp_conv3x3_packed_floats(cin, cout), device='cuda')
+    _lib.check(lib.scipnp_pack_conv3x3_device_scaled(p(W_d), p(sh), p(sc), p(pkf), cin, cout, cin, cout, 0, s), 'pack')
+    yf = ops.from_c8(ops.conv3x3_c8(x8, pkf, cout, stride2=True)).cpu()
+    assert rel_l2(yf.numpy(), y.detach().numpy()) < 2e-6
+    # PixelShuffle backward
+    ds = torch.randn(n, 16, 2 * h, 2 * w, generator=g)
+    cd = torch.randn(n, 64, h, w, generator=g).double().requires_grad_()
+    torch.nn.functional.pixel_shuffle(cd, 2).backward(ds.double())
+    ds8 = ops.to_c8(ds.cuda())
+    dc = torch.empty(n, 8, h, w, 8, device='cuda')
+    _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(p(ds8), p(dc), n, 16, h, w, s), 'unshuffle')
+    assert torch.equal(ops.from_c8(dc).cpu(), cd.grad.float())
