@@ -1,0 +1,112 @@
+"""-m gpu: the BASELINE.json configurations at (or near) their full sizes, HIP path vs the CPU oracle on the same
+seeded inputs, with the oracle leg bounded to seconds (few iterations)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+REL_TOL, PSNR_TOL = 1e-5, 1e-4
+
+
+class Trace:
+    def __init__(self):
+        self.it = []
+
+    def __call__(self, k, mosaic):
+        self.it.append(mosaic.cpu().numpy())
+
+
+@pytest.fixture()
+def solver():
+    from adaptivepnp_sci_amd import solver as S
+    yield S
+    S.ITERATE_HOOK = None
+
+
+def test_config0_admm_tv_256x256x8_50_iterations(solver):
+    """configs[0]: ADMM-TV warm start (ADMM_TV_Warm_Start_save.py), 256x256x8, 50 iterations, every iterate."""
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(256, 256, 8, seed=0)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    xb, psnr_, ssim_, psnr_all = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [50], False, [0],
+                                                                        X_orig=orig, logf=io.StringIO())
+    o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [50], [0], X_orig=orig)
+    worst = max(rel_l2(tr.it[k], o['x_iterates'][k]) for k in range(50))
+    assert worst <= REL_TOL, worst
+    assert np.abs(np.array(psnr_all) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+
+
+def test_config1_ffdnet_512x512x8(solver, ffdnet_state_dict):
+    """configs[1]: two-stage ADMM + FFDNet-colour on one 512x512x8 cube (3 iterations against the oracle)."""
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=0)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [10], False, [0], logf=io.StringIO())[0]
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2, 1], False, [25 / 255, 12 / 255],
+                                            x0_bayer=warm, X_orig=orig, model_denoise=net, logf=io.StringIO())
+    with torch.no_grad():
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2, 1], [25 / 255, 12 / 255], x0_bayer=warm, X_orig=orig,
+                              model_denoise=onet)
+    for k in range(3):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, k
+    assert rel_l2(res[0], o['rgb']) <= REL_TOL
+    assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+
+
+def test_config2_fastdvdnet_512x512x8(solver):
+    """configs[2]: two-stage ADMM + FastDVDnet (5-frame temporal window), 512x512x8, rho = 0.55; 2 iterations."""
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    from oracle.nets import synth_fastdvdnet_weights
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=1)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [10], False, [0], logf=io.StringIO())[0]
+    net = torch.nn.DataParallel(synth_fastdvdnet_weights(1))
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [2], False, [8 / 255], x0_bayer=warm,
+                                            X_orig=orig, model_denoise=net, logf=io.StringIO())
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [2], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=net)
+    for k in range(2):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, k
+    assert rel_l2(res[0], o['rgb']) <= REL_TOL
+
+
+def test_config4_tile_256x256x16_with_online_finetune(solver, ffdnet_state_dict):
+    """configs[4]: one 256x256 tile of the 1024x1024x16 colour cube (16 frames), FFDNet with online finetune firing
+    once (gate at k = 2), per-tile model copy as in shard.reconstruct_sharded."""
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(256, 256, 16, seed=3)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [10], False, [0], logf=io.StringIO())[0]
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    kw = dict(lr_=2e-6, inital_iter=1, interval_iter=2, update_=True, update_per_iter=1)
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [3], False, [25 / 255], x0_bayer=warm,
+                                            X_orig=orig, model_denoise=net, logf=io.StringIO(), **kw)
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [3], [25 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                          lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=1)
+    for k in range(3):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, k
+    assert res[1].shape == (256, 256, 16)
