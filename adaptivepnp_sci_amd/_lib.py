@@ -42,6 +42,7 @@ SIGNATURES = {
     'scipnp_pm_dual_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _flt, _int, _int, _int,
                                      C.POINTER(_int), _vp]),
     'scipnp_pm_pre_denoise': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
+    'scipnp_pm_pre_denoise_ex': (_int, [_vp] * 7 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
     'scipnp_pm_post_denoise': (_int, [_vp] * 10 + [_int, _int, _int, _int, C.POINTER(_int), _vp]),
     'scipnp_sse_partials': (_int, [_vp, _vp, _sz, _vp, C.POINTER(_int), _vp]),
     'scipnp_conv3x3_packed_floats': (_sz, [_int, _int]),
@@ -62,6 +63,10 @@ SIGNATURES = {
     'scipnp_fastdvd_loss_grad': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, C.POINTER(_int), _vp]),
     'scipnp_fastdvd_finish_bwd': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_fastdvd_unpack_bwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_split_packed_bytes': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_split': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_c8_to_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),

@@ -103,4 +103,19 @@ __device__ __forceinline__ double block_sum_double(double v, double* lds /* >= 1
     return r;
 }
 
+// ---- split-fp16 operand format of conv_split.hip: v = hi + lo' * 2^-11
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+constexpr float SPLIT_LO_SCALE = 2048.f;
+__device__ __forceinline__ void split8_store(const float (&v)[8], char* hi_ptr, char* lo_ptr) {
+    half8_t h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        h[e] = hh;
+        l[e] = (_Float16)((v[e] - (float)hh) * SPLIT_LO_SCALE);
+    }
+    *(half8_t*)hi_ptr = h;
+    *(half8_t*)lo_ptr = l;
+}
+
 }  // namespace scipnp

@@ -1,0 +1,354 @@
+// 3x3 convolution with ERROR-COMPENSATED SPLIT-FP16 operands on the CDNA4 matrix cores.
+//
+// Every fp32 operand v is carried as two fp16 numbers  v = hi + lo' * 2^-11,  hi = fp16(v),
+// lo' = fp16((v - hi) * 2^11)  (22 significant bits; the 2^11 keeps lo' in fp16's NORMAL range so nothing
+// depends on subnormal handling).  A product a*b is evaluated as
+//     a_hi*b_hi  +  2^-11 * (a_lo'*b_hi + a_hi*b_lo')          (the a_lo*b_lo term, 2^-22 relative, is dropped)
+// with v_mfma_f32_32x32x16_f16: fp16 x fp16 products are exact in fp32 and the accumulation is fp32, so the
+// only error beyond an fp32 convolution is the 2^-22 operand representation -- measured in the PnP loop:
+// <= 3.4e-6 relative L2 per iterate over the reference's 25-iteration FFDNet schedule (bar: 1e-5), where plain
+// fp16/bf16 operands give 3e-3.  Cost: 14 MFMAs of 32 cycles per (8 input channels x 9 taps x 32x32 block)
+// against 36 fp32 MFMAs of 64 cycles: 5.1x fewer matrix-pipe cycles.
+//
+//   acc += [2^11 w_hi(tap a) | 2^11 w_hi(tap b)] x [x_hi(tap a) | x_hi(tap b)]   taps paired along K = 16 (5 MFMAs)
+//   acc += [w_lo'(tap)       | w_hi(tap)       ] x [x_hi(tap)   | x_lo'(tap)  ]   both cross terms in one K (9 MFMAs)
+//   out  = 2^-11 * acc + bias
+// (one accumulator: the hi*hi term is scaled UP by the exact factor 2^11 -- applied to the w_hi fragment with a
+//  packed fp16 multiply, |w| < 31.9 is checked when packing -- instead of scaling the cross terms down.)
+//
+// Layout "c8s": activations [n][C/8][2][h][w][8] fp16 -- per 8-channel group a hi plane and a lo' plane, 16 bytes
+// per pixel and plane: the same footprint as fp32 c8, lanes of a wave read/write 16 B at 16-B stride in both
+// global memory and LDS (bank-conflict free).  The epilogue splits the fp32 result again, or stores fp32 c8
+// for the network's last layer.  Workgroup / K-loop structure as conv.hip (8x32 pixels x 96 channels, 4 waves,
+// double-buffered LDS stages of one 8-channel group, one barrier per group).
+#include "common.hpp"
+#include <hip/hip_fp16.h>
+#include <cstring>
+#include <cmath>
+
+namespace scipnp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CS_TH = 8, CS_TW = 32;
+constexpr int CS_TWP = CS_TW + 2, CS_THP = CS_TH + 2;
+constexpr int CS_THREADS = 256;
+constexpr int CS_IN_PLANE = CS_THP * CS_TWP * 16;             // bytes of one plane of the input tile (5440)
+constexpr int CS_IN_BYTES = 2 * CS_IN_PLANE;
+constexpr int CS_IN_VEC = CS_IN_BYTES / 16;                   // 680
+constexpr int CS_IN_ITERS = (CS_IN_VEC + CS_THREADS - 1) / CS_THREADS;
+constexpr float CS_LO_SCALE = 2048.f, CS_LO_INV = 1.f / 2048.f;
+
+template <int COB>
+struct SplitCfg {
+    static constexpr int COUTP = 32 * COB;
+    static constexpr int W_PLANE = COUTP * 16;                // bytes of one (tap, plane)
+    static constexpr int W_BYTES = 9 * 2 * W_PLANE;
+    static constexpr int W_VEC = W_BYTES / 16;
+    static constexpr int W_ITERS = (W_VEC + CS_THREADS - 1) / CS_THREADS;
+    static constexpr int STAGE = CS_IN_BYTES + W_BYTES;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
+};
+
+struct SplitArgs {
+    const char* in;      // c8s activations
+    const char* wpk;     // packed split weights: [cig][tap][2][CoutP][8] fp16, then bias fp32 [CoutP]
+    char* out;           // c8s (fp16 split) or fp32 c8
+    int CGin, CGout, CoutP_total, nsplit;
+    int H, W;
+    int flags;           // bit0 ReLU, bit5 (32) = fp32 c8 output
+};
+
+__device__ __forceinline__ void split_store(float v0, float v1, float v2, float v3, char* hi_ptr, char* lo_ptr) {
+    f16x4 h, l;
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        h[e] = hh;
+        l[e] = (_Float16)((v[e] - (float)hh) * CS_LO_SCALE);
+    }
+    *(f16x4*)hi_ptr = h;
+    *(f16x4*)lo_ptr = l;
+}
+
+template <int COB, int TAG>
+__global__ void __launch_bounds__(CS_THREADS, 2)
+conv3x3_c8s_kernel(const SplitArgs a) {
+    using Cfg = SplitCfg<COB>;
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * CS_TH;
+    const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const size_t grp_bytes = 2 * HW * 16;                      // one channel group (both planes)
+
+    // staging plan (byte offsets inside one channel group / one weight slab), -1 = zero fill
+    int in_off[CS_IN_ITERS];
+#pragma unroll
+    for (int k = 0; k < CS_IN_ITERS; ++k) {
+        const int e = tid + k * CS_THREADS;
+        in_off[k] = -1;
+        if (e < CS_IN_VEC) {
+            const int plane = e / (CS_THP * CS_TWP), pix = e - plane * (CS_THP * CS_TWP);
+            const int r = pix / CS_TWP, c = pix - r * CS_TWP;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[k] = (int)((plane * HW + (size_t)gy * W + gx) * 16);
+        }
+    }
+    int w_off[Cfg::W_ITERS];
+#pragma unroll
+    for (int k = 0; k < Cfg::W_ITERS; ++k) {
+        const int e = tid + k * CS_THREADS;
+        w_off[k] = -1;
+        if (e < Cfg::W_VEC) {
+            const int tp = e / Cfg::COUTP, co = e - tp * Cfg::COUTP;       // tp = tap*2 + plane
+            w_off[k] = (tp * a.CoutP_total + split * Cfg::COUTP + co) * 16;
+        }
+    }
+    const char* in_g = a.in + (size_t)n * a.CGin * grp_bytes;
+    const char* w_g = a.wpk;
+    const size_t w_step = (size_t)9 * 2 * a.CoutP_total * 16;
+
+    f32x4 st_in[CS_IN_ITERS];
+    f32x4 st_w[Cfg::W_ITERS];
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int k = 0; k < CS_IN_ITERS; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in_off[k] >= 0) v = *(const f32x4*)(in_g + in_off[k]);
+            st_in[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::W_ITERS; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_off[k] >= 0) v = *(const f32x4*)(w_g + w_off[k]);
+            st_w[k] = v;
+        }
+        in_g += grp_bytes;
+        w_g += w_step;
+    };
+    auto write_lds = [&](char* buf) {
+#pragma unroll
+        for (int k = 0; k < CS_IN_ITERS; ++k) {
+            const int e = tid + k * CS_THREADS;
+            if (e < CS_IN_VEC) *(f32x4*)(buf + 16 * e) = st_in[k];
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::W_ITERS; ++k) {
+            const int e = tid + k * CS_THREADS;
+            if (e < Cfg::W_VEC) *(f32x4*)(buf + CS_IN_BYTES + 16 * e) = st_w[k];
+        }
+    };
+
+    f32x16 acc1[2][COB];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[pb][cb][r] = 0.f;
+
+    issue_loads();
+    write_lds(smem_s);
+    __syncthreads();
+
+    // LDS byte offsets.  input: plane p at p*CS_IN_PLANE, pixel (r,c) at (r*TWP + c)*16
+    //                    weights: CS_IN_BYTES + ((tap*2 + plane)*COUTP + co)*16
+    const int px_base = ((2 * wv) * CS_TWP + li) * 16;                       // + ((pb+ky)*TWP + kx)*16
+    const int co_base = CS_IN_BYTES + li * 16;                               // + ((tap*2+plane)*COUTP + cb*32)*16
+
+    for (int cig = 0; cig < a.CGin; ++cig) {
+        const char* buf = smem_s + (cig & 1) * Cfg::STAGE;
+        const bool more = (cig + 1 < a.CGin);
+        if (more) issue_loads();
+        // ---- hi x hi, taps paired along K: lane half h handles tap 2p+h (tap 9 does not exist -> zeros)
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int tap_h = 2 * p + lh;                                    // runtime (lane half), < 10
+            const bool live = tap_h < 9;
+            const int tp = live ? tap_h : 8;
+            const int ky = tp / 3, kx = tp - 3 * ky;
+            f16x8 bf[2], af[COB];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+                bf[pb] = *(const f16x8*)(buf + px_base + ((pb + ky) * CS_TWP + kx) * 16);
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) {
+                f16x8 t = *(const f16x8*)(buf + co_base + ((tp * 2 + 0) * Cfg::COUTP + cb * 32) * 16);
+                af[cb] = t * (f16x8)(_Float16)(live ? CS_LO_SCALE : 0.f);          // exact power-of-two scale (or 0)
+            }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb)
+                    acc1[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc1[pb][cb], 0, 0, 0);
+            if (p == 1 && more) write_lds(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+        }
+        // ---- cross terms: k 0..7 = w_lo' * x_hi (lane half 0), k 8..15 = w_hi * x_lo' (lane half 1)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            f16x8 bf[2], af[COB];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+                bf[pb] = *(const f16x8*)(buf + lh * CS_IN_PLANE + px_base + ((pb + ky) * CS_TWP + kx) * 16);
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+                af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb)
+                    acc1[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc1[pb][cb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const float* bias = (const float*)(a.wpk + (size_t)a.CGin * w_step);
+    const bool relu = a.flags & 1, f32out = a.flags & 32;
+    const int x = x0 + li;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int y = y0 + 2 * wv + pb;
+        if (y < H && x < W) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cog = (split * COB + cb) * 4 + g;
+                    if (cog < a.CGout) {
+                        const f32x4 bs = *(const f32x4*)(bias + cog * 8 + 4 * lh);
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc1[pb][cb][4 * g + e] * CS_LO_INV + bs[e];
+                            if (relu) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        const size_t pix = (size_t)y * W + x;
+                        if (f32out) {
+                            f32x4 o = {v[0], v[1], v[2], v[3]};
+                            *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HW + pix) * 8 + 4 * lh) * 4) = o;
+                        } else {
+                            char* grp = a.out + ((size_t)n * a.CGout + cog) * grp_bytes;
+                            split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 8 * lh, grp + HW * 16 + pix * 16 + 8 * lh);
+                        }
+                    }
+                }
+        }
+    }
+}
+
+template <int COB, int TAG>
+static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
+    using Cfg = SplitCfg<COB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const dim3 grid((a.W + CS_TW - 1) / CS_TW, (a.H + CS_TH - 1) / CS_TH, n * a.nsplit);
+    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG>), grid, dim3(CS_THREADS), Cfg::LDS_BYTES, st, a);
+    return launch_status("conv3x3_c8s_kernel");
+}
+
+static inline int round_up_s(int v, int m) { return (v + m - 1) / m * m; }
+
+// fp32 -> (hi, lo') halves on the host (round-to-nearest-even through _Float16)
+static inline void split_host(float v, _Float16* hi, _Float16* lo) {
+    const _Float16 h = (_Float16)v;
+    *hi = h;
+    *lo = (_Float16)((v - (float)h) * CS_LO_SCALE);
+}
+
+// fp32 c8 -> c8s (test / entry helper)
+__global__ void __launch_bounds__(256)
+c8_to_c8s_kernel(const float* __restrict__ in, char* __restrict__ out, size_t HW, size_t total /* n*CG*HW */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t grp = i / HW, pix = i - grp * HW;
+    const f32x4 a = *(const f32x4*)(in + i * 8), b = *(const f32x4*)(in + i * 8 + 4);
+    char* g = out + grp * (2 * HW * 16);
+    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16);
+    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
+}
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
+    const int CoutP = round_up_s(Cout, 32);
+    return (size_t)(Cin / 8) * 9 * 2 * CoutP * 16 + (size_t)CoutP * 4;
+}
+
+int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
+                              void* packed) {
+    SCIPNP_REQUIRE(w && packed, "null pointer");
+    SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
+                   "bad channel counts");
+    const int CoutP = round_up_s(Cout, 32);
+    const size_t nw_bytes = (size_t)(Cin / 8) * 9 * 2 * CoutP * 16;
+    memset(packed, 0, nw_bytes + (size_t)CoutP * 4);
+    _Float16* p = (_Float16*)packed;
+    for (int co = 0; co < Cout_real; ++co)
+        for (int ci = 0; ci < Cin_real; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                _Float16 hi, lo;
+                const float wv_ = w[((size_t)co * Cin_real + ci) * 9 + tap];
+                if (!(fabsf(wv_) < 31.9f)) return fail(SCIPNP_EINVAL, "split-fp16 conv needs |w| < 31.9 (got %g)", (double)wv_);
+                split_host(wv_, &hi, &lo);
+                const size_t base = ((size_t)(ci / 8) * 9 + tap) * 2;
+                p[((base + 0) * CoutP + co) * 8 + (ci % 8)] = hi;
+                p[((base + 1) * CoutP + co) * 8 + (ci % 8)] = lo;
+            }
+    float* b = (float*)((char*)packed + nw_bytes);
+    for (int co = 0; co < Cout_real; ++co) b[co] = bias ? bias[co] : 0.f;
+    return SCIPNP_OK;
+}
+
+int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout, int h, int w,
+                       int flags, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8s && packed_split && out, "null pointer");
+    SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
+    SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(packed_split); SCIPNP_ALIGNED(out);
+    SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 31), "image too large for 32-bit tile offsets");
+    SplitArgs a;
+    a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out;
+    a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up_s(Cout, 32);
+    a.H = h; a.W = w; a.flags = flags;
+    hipStream_t st = (hipStream_t)s;
+    const int CoutP = a.CoutP_total;
+    SCIPNP_REQUIRE((long long)n * (CoutP / 32) <= 65535, "grid too large");
+    if (CoutP % 96 == 0) {
+        a.nsplit = CoutP / 96;
+        if (flags & 0x100) return launch_split<3, 1>(a, n, st);
+        return launch_split<3, 0>(a, n, st);
+    }
+    if (CoutP % 64 == 0) { a.nsplit = CoutP / 64; return launch_split<2, 0>(a, n, st); }
+    a.nsplit = CoutP / 32;
+    return launch_split<1, 0>(a, n, st);
+}
+
+int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8s && n > 0 && C % 8 == 0 && h > 0 && w > 0, "bad arguments");
+    SCIPNP_ALIGNED(in_c8); SCIPNP_ALIGNED(out_c8s);
+    const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
+    hipLaunchKernelGGL(c8_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
+                       (char*)out_c8s, HW, total);
+    return launch_status("c8_to_c8s_kernel");
+}
+
+}  // extern "C"

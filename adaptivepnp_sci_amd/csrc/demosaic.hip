@@ -47,8 +47,8 @@ __device__ __forceinline__ int reflect_plane(int mm, int d, int M) {
 __global__ void __launch_bounds__(256)
 pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
                       const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
-                      float* __restrict__ net_in, int M, int N, int B, float inv_rho, float inv_tau,
-                      float sigma) {
+                      float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N, int B, float inv_rho,
+                      float inv_tau, float sigma) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
     const int t = blockIdx.z;
@@ -111,6 +111,15 @@ pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
         dst0[1] = make_float4(in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]);
         dst1[0] = make_float4(in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1]);
         dst1[1] = make_float4(sigma, 0.f, 0.f, 0.f);
+    }
+    if (net_in_s) {
+        // c8s layout [t][2 groups][2 planes (hi, lo')][M][N][8 fp16] for the split-fp16 convolutions
+        const float g0[8] = {in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1], in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]};
+        const float g1[8] = {in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1], sigma, 0.f, 0.f, 0.f};
+        const size_t pix = (size_t)m * N + n;
+        char* base = net_in_s + (size_t)t * 2 * (2 * plane * 16);
+        split8_store(g0, base + pix * 16, base + plane * 16 + pix * 16);
+        split8_store(g1, base + 2 * plane * 16 + pix * 16, base + 3 * plane * 16 + pix * 16);
     }
 }
 
@@ -192,19 +201,30 @@ using namespace scipnp;
 
 extern "C" {
 
+int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, float* x_rgb, float* rgb_w,
+                             float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho, float inv_tau,
+                             float sigma, scipnp_stream_t s);
+
 int scipnp_pm_pre_denoise(const float* x, const float* b, const float* w, float* x_rgb, float* rgb_w,
                           float* net_in_c8, int M, int N, int B, float inv_rho, float inv_tau, float sigma,
                           scipnp_stream_t s) {
+    return scipnp_pm_pre_denoise_ex(x, b, w, x_rgb, rgb_w, net_in_c8, nullptr, M, N, B, inv_rho, inv_tau, sigma, s);
+}
+
+int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, float* x_rgb, float* rgb_w,
+                             float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho, float inv_tau,
+                             float sigma, scipnp_stream_t s) {
     SCIPNP_REQUIRE(x && x_rgb, "null pointer");
     SCIPNP_REQUIRE(M >= 2 && N >= 2 && B > 0 && B <= 65535 && M <= 65535, "bad shape M=%d N=%d B=%d", M, N, B);
     SCIPNP_ALIGNED(x_rgb);
     if (w) SCIPNP_ALIGNED(w);
     if (rgb_w) SCIPNP_ALIGNED(rgb_w);
     if (net_in_c8) SCIPNP_ALIGNED(net_in_c8);
+    if (net_in_c8s) SCIPNP_ALIGNED(net_in_c8s);
     const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
     const dim3 grid((N + threads - 1) / threads, M, B);
     hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, x_rgb, rgb_w,
-                       net_in_c8, M, N, B, inv_rho, inv_tau, sigma);
+                       net_in_c8, (char*)net_in_c8s, M, N, B, inv_rho, inv_tau, sigma);
     return launch_status("pm_pre_denoise_kernel");
 }
 

@@ -63,7 +63,7 @@ def ffdnet_rgb_denoise_full_tensor(x, yall, Phiall, sigma, model, useGPU=True, l
         eng.in_c8.copy_(in_c8)
         ffdnet_online_finetune(model, eng, yall.permute(2, 0, 1).contiguous(), Phiall.permute(2, 3, 0, 1).contiguous(),
                                sigma, lr_, update_per_iter)
-        out = F.pixel_shuffle(ops.from_c8(eng.forward(), 12), 2)[..., :H, :W].contiguous()
+        out = F.pixel_shuffle(ops.from_c8(eng.forward(eng.in_c8), 12), 2)[..., :H, :W].contiguous()
         return ops.rgb_to_cube(out), model
     rgb = ops.cube_to_rgb(x.float().contiguous())
     return ops.rgb_to_cube(ffdnet_forward_nchw(model, rgb, sigma))

@@ -147,8 +147,7 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
         if trace is not None:
             trace.append(val)
     tr.write_back()
-    eng.packed = tr.fwd
-    eng._ptrs = (C.c_void_p * eng.nb)(*[p.data_ptr() for p in eng.packed])
+    eng.refresh(model)            # repack (fp32 and, if enabled, split-fp16) from the updated parameters
     return model
 
 

@@ -51,16 +51,29 @@ def ffdnet_layers(model):
     return out
 
 
+def default_precision():
+    """'f16x3' (error-compensated split-fp16 MFMA, csrc/conv_split.hip) or 'f32' (fp32 MFMA, csrc/conv.hip);
+    override with SCIPNP_FFDNET_PRECISION."""
+    import os
+    p = os.environ.get('SCIPNP_FFDNET_PRECISION', 'f16x3')
+    if p not in ('f32', 'f16x3'):
+        raise ValueError("SCIPNP_FFDNET_PRECISION must be 'f32' or 'f16x3'")
+    return p
+
+
 class FFDNetEngine:
     """Packed weights + scratch for B frames of M x N (half-resolution) activations."""
 
-    def __init__(self, model, B, M, N, device):
+    def __init__(self, model, B, M, N, device, precision=None):
         self.device = device
         self.B, self.M, self.N = B, M, N
+        self.precision = precision or default_precision()
         self.refresh(model)
         nc = self.nc
         self.scratch = [torch.empty(B * nc * M * N, dtype=torch.float32, device=device) for _ in range(2)]
         self.in_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
+        self.in_c8s = (torch.empty(B, 2, 2, M, N, 8, dtype=torch.float16, device=device)
+                       if self.precision == 'f16x3' else None)
         self.out_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
 
     def refresh(self, model):
@@ -76,14 +89,23 @@ class FFDNetEngine:
             cout = 16 if i == self.nb - 1 else self.nc
             self.packed.append(ops.pack_conv3x3(w, b, Cin=cin, Cout=cout, device=self.device))
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
+        self.packed_split = None
+        if self.precision == 'f16x3':
+            self.packed_split = []
+            for i, (w, b) in enumerate(layers):
+                cin = 16 if i == 0 else self.nc
+                cout = 16 if i == self.nb - 1 else self.nc
+                self.packed_split.append(ops.pack_conv3x3_split(w, b, Cin=cin, Cout=cout, device=self.device))
 
     def forward(self, in_c8=None, out_c8=None, events=None):
         """12 conv launches on the current stream (same sequence as the C entry scipnp_ffdnet_forward).
         `events`, if a list, receives (start, end) torch.cuda.Event pairs bracketing the nb-2 body layers
         (bench.py's live roofline measurement)."""
-        in_c8 = self.in_c8 if in_c8 is None else in_c8
         out_c8 = self.out_c8 if out_c8 is None else out_c8
         B, M, N, nc = self.B, self.M, self.N, self.nc
+        if self.precision == 'f16x3':
+            return self._forward_split(in_c8, out_c8, events)
+        in_c8 = self.in_c8 if in_c8 is None else in_c8
         buf = [s.view(B, nc // 8, M, N, 8) for s in self.scratch]
         ops.conv3x3_c8(in_c8, self.packed[0], nc, relu=True, out=buf[0], head=True)
         if events is not None:
@@ -97,6 +119,27 @@ class FFDNetEngine:
             e1.record()
             events.append((e0, e1))
         ops.conv3x3_c8(buf[cur], self.packed[self.nb - 1], 16, relu=False, out=out_c8)
+        return out_c8
+
+    def _forward_split(self, in_c8, out_c8, events):
+        """same 12 layers on the split-fp16 kernels; the input is self.in_c8s (written by scipnp_pm_pre_denoise_ex)
+        unless an fp32 c8 tensor is passed, the output is fp32 c8."""
+        B, M, N, nc = self.B, self.M, self.N, self.nc
+        x = self.in_c8s if in_c8 is None else ops.c8_to_c8s(in_c8)
+        buf = [s.view(torch.float16).view(B, nc // 8, 2, M, N, 8) for s in self.scratch]   # same bytes as fp32 c8
+        pk = self.packed_split
+        ops.conv3x3_c8s(x, pk[0], nc, relu=True, out=buf[0], head=True)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        cur = 0
+        for l in range(1, self.nb - 1):
+            ops.conv3x3_c8s(buf[cur], pk[l], nc, relu=True, out=buf[cur ^ 1])
+            cur ^= 1
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        ops.conv3x3_c8s(buf[cur], pk[self.nb - 1], 16, relu=False, out=out_c8, f32_out=True)
         return out_c8
 
     def forward_c_entry(self, in_c8=None, out_c8=None):

@@ -168,11 +168,11 @@ def pm_dual_update(theta_raw, x, theta, b, sign, orig=None, sse_part=None, which
     return nb.value
 
 
-def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma):
+def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma, net_in_c8s=None):
     B, _, M, N = x.shape
-    _call('scipnp_pm_pre_denoise', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(x_rgb, 'x_rgb'), _p(rgb_w, 'rgb_w'),
-          _p(net_in_c8, 'net_in_c8'), M, N, B, float(np.float32(inv_rho)), float(np.float32(inv_tau)),
-          float(np.float32(sigma)), _stream())
+    _call('scipnp_pm_pre_denoise_ex', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(x_rgb, 'x_rgb'), _p(rgb_w, 'rgb_w'),
+          _p(net_in_c8, 'net_in_c8'), _p(net_in_c8s, 'net_in_c8s', torch.float16), M, N, B,
+          float(np.float32(inv_rho)), float(np.float32(inv_tau)), float(np.float32(sigma)), _stream())
 
 
 def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first_iter_alias, orig=None,
@@ -258,6 +258,44 @@ def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False,
     _call('scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'), _p(out, 'out'), _p(residual, 'residual'),
           n, cg * 8, Cout, h, w, flags, _stream())
     return out
+
+
+def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None):
+    """OIHW fp32 weights -> packed split-fp16 buffer (uint8 tensor) for scipnp_conv3x3_c8s."""
+    w = weight.detach().to('cpu', F32).contiguous()
+    co, ci = w.shape[0], w.shape[1]
+    Cin = Cin or (ci + 7) // 8 * 8
+    Cout = Cout or (co + 7) // 8 * 8
+    lib = _lib.load()
+    packed = torch.empty(lib.scipnp_conv3x3_split_packed_bytes(Cin, Cout), dtype=torch.uint8)
+    b = None if bias is None else bias.detach().to('cpu', F32).contiguous()
+    _lib.check(lib.scipnp_pack_conv3x3_split(C.c_void_p(w.data_ptr()), C.c_void_p(0 if b is None else b.data_ptr()), ci, co,
+                                             Cin, Cout, C.c_void_p(packed.data_ptr())), 'scipnp_pack_conv3x3_split')
+    return packed.to(device) if device is not None else packed
+
+
+def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False):
+    """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s (or fp32 c8 [n][Cout/8][h][w][8] if f32_out)."""
+    n, cg, _two, h, w, _ = x.shape
+    if out is None:
+        out = (torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32) if f32_out else
+               torch.empty(n, Cout // 8, 2, h, w, 8, device=x.device, dtype=torch.float16))
+    flags = (1 if relu else 0) | (32 if f32_out else 0) | (0x100 if head else 0)
+    _call('scipnp_conv3x3_c8s', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
+          _p(out, 'out', F32 if f32_out else torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
+    return out
+
+
+def c8_to_c8s(x):
+    n, cg, h, w, _ = x.shape
+    out = torch.empty(n, cg, 2, h, w, 8, device=x.device, dtype=torch.float16)
+    _call('scipnp_c8_to_c8s', _p(x, 'x'), _p(out, 'out', torch.float16), n, cg * 8, h, w, _stream())
+    return out
+
+
+def c8s_to_float(x):
+    """c8s (hi, lo') -> fp32 c8 values hi + lo'/2048 (test helper, torch arithmetic)"""
+    return x[:, :, 0].float() + x[:, :, 1].float() / 2048.0
 
 
 def fastdvd_pack_triplets(frames, sigma, out=None):

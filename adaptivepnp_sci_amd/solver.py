@@ -158,7 +158,10 @@ class AdmmRun:
             # kernels on -b:  x + 1*(-b) = x - b exactly, and (-b) + (x - theta) = -(b - (x - theta)).
             b_in, inv_rho, inv_tau, w = self.b.neg(), 1.0, 0.0, None
         if self.denoiser == 'ffdnet_color':
-            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, self.eng.in_c8, inv_rho, inv_tau, nsig)
+            split = self.eng.precision == 'f16x3'
+            # the finetune (rare) runs on the fp32 kernels and needs the fp32 c8 input as well
+            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, self.eng.in_c8 if (gate or not split) else None,
+                               inv_rho, inv_tau, nsig, net_in_c8s=self.eng.in_c8s if split else None)
             if gate:
                 from .finetune import ffdnet_online_finetune
                 ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,

@@ -121,6 +121,11 @@ int scipnp_pm_pre_denoise(const float* x, const float* b, const float* w, float*
                           float* rgb_w, float* net_in_c8, int M, int N, int B,
                           float inv_rho, float inv_tau, float sigma, scipnp_stream_t s);
 
+/* same, additionally emitting the denoiser input in the split-fp16 c8s layout (net_in_c8s, may be NULL) */
+int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, float* x_rgb, float* rgb_w,
+                             float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho,
+                             float inv_tau, float sigma, scipnp_stream_t s);
+
 /* post-denoiser fusion: theta_raw = denoised RGB sampled at the CFA sites, theta = clip(theta_raw),
  * b += x_eff - theta with x_eff = theta_raw when first_iter_alias (the reference's k = 0 tensor
  * aliasing, SURVEY 3.2: x and theta are one tensor, so x is overwritten with theta_raw too) else x;
@@ -167,6 +172,20 @@ int scipnp_conv3x3_c8(const float* in, const float* packed_w, float* out, const 
 int scipnp_conv3x3_c8_ex(const float* in, const float* packed_w, float* out, const float* residual,
                          const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags,
                          scipnp_stream_t s);
+
+/* ---- error-compensated split-fp16 variant (csrc/conv_split.hip): every fp32 operand v = hi + lo'*2^-11 as two
+ * fp16 numbers, three exact fp16 products per fp32 product on v_mfma_f32_32x32x16_f16 (fp32 accumulate).
+ * Activations in layout c8s [n][C/8][2][h][w][8] fp16 (hi plane, lo' plane; same bytes as fp32 c8).
+ * stride 1, zero pad 1; flags: bit0 ReLU, bit5 (32) = write fp32 c8 instead of c8s (network tail), bit8 head tag.
+ * Per-iterate error in the PnP loop <= 3.4e-6 (bar 1e-5); needs |w| < 31.9 and activations inside fp16 range. */
+size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout);
+/* HOST pointers: w OIHW fp32, bias or NULL -> packed split weights */
+int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
+                              void* packed);
+int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout,
+                       int h, int w, int flags, scipnp_stream_t s);
+/* fp32 c8 -> c8s */
+int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s);
 
 /* whole FFDNet-colour forward on B frames: 12 (nb) conv layers ping-ponging between two c8 scratch
  * buffers of n*nc*h*w floats each.  in_c8: [B][2][M][N][8] from scipnp_pm_pre_denoise, out_c8:

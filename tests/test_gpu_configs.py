@@ -42,7 +42,9 @@ def test_config0_admm_tv_256x256x8_50_iterations(solver):
     assert np.abs(np.array(psnr_all) - np.array(o['psnr_all'])).max() <= PSNR_TOL
 
 
-def test_config1_ffdnet_512x512x8(solver, ffdnet_state_dict):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_config1_ffdnet_512x512x8(solver, ffdnet_state_dict, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision)
     """configs[1]: two-stage ADMM + FFDNet-colour on one 512x512x8 cube (3 iterations against the oracle)."""
     from adaptivepnp_sci_amd import synth
     from adaptivepnp_sci_amd.nets import FFDNet

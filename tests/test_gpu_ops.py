@@ -455,3 +455,39 @@ def test_fastdvd_backward_glue_vs_autograd(ops):
     dc = torch.empty(n, 8, h, w, 8, device='cuda')
     _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(p(ds8), p(dc), n, 16, h, w, s), 'unshuffle')
     assert torch.equal(ops.from_c8(dc).cpu(), cd.grad.float())
+
+
+@pytest.mark.parametrize('cin,cout,h,w,n', [(16, 96, 16, 32, 2), (96, 96, 24, 40, 1), (96, 16, 9, 33, 2), (32, 64, 8, 32, 1)])
+def test_conv3x3_split_fp16_vs_fp64(ops, cin, cout, h, w, n):
+    """error-compensated split-fp16 MFMA conv: 22-bit operands, exact products, fp32 accumulation."""
+    g = torch.Generator().manual_seed(cin * 77 + cout)
+    x = torch.randn(n, cin, h, w, generator=g) * 3.0
+    x[0, 0, 0, :8] = torch.tensor([1e-6, -3e-5, 2e-4, 0.0, 1e-3, -0.04, 37.5, -120.0])   # tiny and large magnitudes
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    wt[0, 0, 1, 1] = 4.4886
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    packed = ops.pack_conv3x3_split(wt, bias, Cin=cin, Cout=cout, device='cuda')
+    xs = ops.c8_to_c8s(ops.to_c8(x.cuda()))
+    assert rel_l2(ops.c8s_to_float(xs).cpu().numpy(), ops.to_c8(x).numpy()) < 3e-7          # 2^-22 operand format
+    got = ops.from_c8(ops.conv3x3_c8s(xs, packed, cout, f32_out=True)).cpu()
+    assert rel_l2(got.numpy(), ref.numpy()) < 2e-6, rel_l2(got.numpy(), ref.numpy())
+    got_s = ops.conv3x3_c8s(xs, packed, cout, relu=True)                                     # split output + ReLU
+    got2 = ops.from_c8(ops.c8s_to_float(got_s)).cpu()
+    assert rel_l2(got2.numpy(), torch.relu(ref).numpy()) < 2e-6
+
+
+def test_split_pack_rejects_huge_weights(ops):
+    with pytest.raises(ValueError):
+        ops.pack_conv3x3_split(torch.full((8, 8, 3, 3), 40.0), None, Cin=8, Cout=8)
+
+
+def test_ffdnet_forward_split_precision(ffdnet_state_dict, monkeypatch):
+    from adaptivepnp_sci_amd.nets import FFDNet
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', 'f16x3')
+    g = load_gold('ffdnet_forward')
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    x = dev(g['in_128x128'])
+    out = net(x, torch.full((1, 1, 1, 1), 25 / 255.)).cpu().numpy()
+    assert rel_l2(out, g['out_128x128_s25']) < 5e-6

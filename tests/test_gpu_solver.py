@@ -69,7 +69,9 @@ def test_two_stage_tv_iterates_and_log(solver):
     assert logf.getvalue().split('\n')[0] in ref_lines
 
 
-def test_two_stage_ffdnet_cold_start_alias_rule(solver, ffdnet_state_dict):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_two_stage_ffdnet_cold_start_alias_rule(solver, ffdnet_state_dict, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision)      # fp32 MFMA vs error-compensated split-fp16 MFMA
     """x0 = Phi*y (values up to B) -> clipping at k = 0 -> exposes the reference's tensor aliasing."""
     g = load_gold('ffdadmm_cold_64x64x8')
     tr = Trace()
@@ -87,7 +89,9 @@ def test_two_stage_ffdnet_cold_start_alias_rule(solver, ffdnet_state_dict):
     assert np.abs(np.array(res[3]) - g['ssim_frames']).max() <= 1e-5
 
 
-def test_two_stage_ffdnet_driver_schedule_free_running(solver, ffdnet_state_dict):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_two_stage_ffdnet_driver_schedule_free_running(solver, ffdnet_state_dict, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision)      # fp32 MFMA vs error-compensated split-fp16 MFMA
     """sigma = [25,12,6]/255 x [15,6,4] iterations from a TV warm start: the reference driver's schedule
     (two_stage_ADMM_Online_FFD_Warm.py:71-72), free running for all 25 iterations."""
     g = load_gold('ffdadmm_warm_128x128x8')
@@ -108,7 +112,9 @@ def test_two_stage_ffdnet_driver_schedule_free_running(solver, ffdnet_state_dict
     print('worst per-iterate rel-L2 over the 25-iteration schedule:', worst)
 
 
-def test_one_stage_ffdnet_branch(solver, ffdnet_state_dict):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_one_stage_ffdnet_branch(solver, ffdnet_state_dict, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision)      # fp32 MFMA vs error-compensated split-fp16 MFMA
     g = load_gold('ffdadmm_onestage_64x64x8')
     tr = Trace()
     solver.ITERATE_HOOK = tr
@@ -170,7 +176,9 @@ def test_two_stage_fastdvdnet_iterates(solver):
     assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL
 
 
-def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision)      # fp32 MFMA vs error-compensated split-fp16 MFMA
     """update_=True, lr 2e-6, update_per_iter 2 (the reference driver's values), gate at k = 2: hand-written
     backward (loss grad, backward-data convs, MFMA weight gradients, Adam) vs the reference's autograd run."""
     from adaptivepnp_sci_amd import finetune
