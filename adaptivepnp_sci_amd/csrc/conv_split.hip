@@ -75,7 +75,7 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
     *(f16x4*)lo_ptr = l;
 }
 
-template <int COB, int TAG>
+template <int COB, int TAG, int DBG = 0>   // DBG: timing experiments (1: no pk_mul, 2: LDS fragments read once per group)
 __global__ void __launch_bounds__(CS_THREADS, 2)
 conv3x3_c8s_kernel(const SplitArgs a) {
     using Cfg = SplitCfg<COB>;
@@ -163,52 +163,68 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     //                    weights: CS_IN_BYTES + ((tap*2 + plane)*COUTP + co)*16
     const int px_base = ((2 * wv) * CS_TWP + li) * 16;                       // + ((pb+ky)*TWP + kx)*16
     const int co_base = CS_IN_BYTES + li * 16;                               // + ((tap*2+plane)*COUTP + cb*32)*16
+    // hi x hi tap pairs: lane half h handles tap 2p+h; per-lane offsets and scale (0 for the missing tap 9) hoisted
+    int pair_px[5], pair_co[5];
+    _Float16 pair_scale[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int tap_h = 2 * p + lh;
+        const bool live = tap_h < 9;
+        const int tp = live ? tap_h : 8;
+        const int ky = tp / 3, kx = tp - 3 * ky;
+        pair_px[p] = px_base + (ky * CS_TWP + kx) * 16;
+        pair_co[p] = co_base + (tp * 2 * Cfg::COUTP) * 16;
+        pair_scale[p] = (_Float16)(live ? CS_LO_SCALE : 0.f);
+    }
 
     for (int cig = 0; cig < a.CGin; ++cig) {
-        const char* buf = smem_s + (cig & 1) * Cfg::STAGE;
-        const bool more = (cig + 1 < a.CGin);
+        const char* buf = smem_s + ((a.flags & 0x1000) ? 0 : (cig & 1) * Cfg::STAGE);
+        const bool dbg_nostage = a.flags & 0x1000, dbg_late = a.flags & 0x2000;   // timing experiments only
+        const bool more = (cig + 1 < a.CGin) && !dbg_nostage;
         if (more) issue_loads();
-        // ---- hi x hi, taps paired along K: lane half h handles tap 2p+h (tap 9 does not exist -> zeros)
+        // 14 MFMA steps per group: 5 hi x hi tap pairs (lane half h handles tap 2p+h, tap 9 -> zero weights)
+        // then 9 cross-term taps (k 0..7 = w_lo' x_hi from lane half 0, k 8..15 = w_hi x_lo' from lane half 1).
+        // Fragments are software-pipelined: step s+1's LDS reads are issued before step s's MFMAs.
+        f16x8 bfA[2], afA[COB], bfB[2], afB[COB];
+        auto load_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
+            if ((DBG & 2) && s > 1) return;
+            if (s < 5) {
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
-            const int tap_h = 2 * p + lh;                                    // runtime (lane half), < 10
-            const bool live = tap_h < 9;
-            const int tp = live ? tap_h : 8;
-            const int ky = tp / 3, kx = tp - 3 * ky;
-            f16x8 bf[2], af[COB];
+                for (int pb = 0; pb < 2; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * CS_TWP * 16);
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-                bf[pb] = *(const f16x8*)(buf + px_base + ((pb + ky) * CS_TWP + kx) * 16);
+                for (int cb = 0; cb < COB; ++cb) af[cb] = *(const f16x8*)(buf + pair_co[s] + cb * 32 * 16);
+            } else {
+                const int tap = s - 5, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb) {
-                f16x8 t = *(const f16x8*)(buf + co_base + ((tp * 2 + 0) * Cfg::COUTP + cb * 32) * 16);
-                af[cb] = t * (f16x8)(_Float16)(live ? CS_LO_SCALE : 0.f);          // exact power-of-two scale (or 0)
+                for (int pb = 0; pb < 2; ++pb)
+                    bf[pb] = *(const f16x8*)(buf + lh * CS_IN_PLANE + px_base + ((pb + ky) * CS_TWP + kx) * 16);
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb)
+                    af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
+            }
+        };
+        auto mma_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
+            if (s < 5 && !(DBG & 1)) {
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb) af[cb] = af[cb] * (f16x8)pair_scale[s];     // exact 2^11 (or 0)
             }
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
                     acc1[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc1[pb][cb], 0, 0, 0);
-            if (p == 1 && more) write_lds(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+        };
+        load_step(0, bfA, afA);
+#pragma unroll
+        for (int s2 = 0; s2 < 14; s2 += 2) {
+            load_step(s2 + 1, bfB, afB);
+            mma_step(s2, bfA, afA);
+            if (s2 + 2 < 14) load_step(s2 + 2, bfA, afA);
+            mma_step(s2 + 1, bfB, afB);
+            // fill the other LDS buffer once the loads issued at the top of the group have had ~2000 cycles
+            if (s2 == (dbg_late ? 12 : 8) && more) write_lds(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
         }
-        // ---- cross terms: k 0..7 = w_lo' * x_hi (lane half 0), k 8..15 = w_hi * x_lo' (lane half 1)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            f16x8 bf[2], af[COB];
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-                bf[pb] = *(const f16x8*)(buf + lh * CS_IN_PLANE + px_base + ((pb + ky) * CS_TWP + kx) * 16);
-#pragma unroll
-            for (int cb = 0; cb < COB; ++cb)
-                af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int cb = 0; cb < COB; ++cb)
-                    acc1[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc1[pb][cb], 0, 0, 0);
-        }
-        __syncthreads();
+        if (!(a.flags & 0x4000)) __syncthreads();
     }
 
     // ---- epilogue
@@ -246,18 +262,18 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     }
 }
 
-template <int COB, int TAG>
+template <int COB, int TAG, int DBG = 0>
 static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
     using Cfg = SplitCfg<COB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, DBG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
         attr_set = true;
     }
     const dim3 grid((a.W + CS_TW - 1) / CS_TW, (a.H + CS_TH - 1) / CS_TH, n * a.nsplit);
-    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG>), grid, dim3(CS_THREADS), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, DBG>), grid, dim3(CS_THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_kernel");
 }
 
@@ -335,6 +351,9 @@ int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, 
     if (CoutP % 96 == 0) {
         a.nsplit = CoutP / 96;
         if (flags & 0x100) return launch_split<3, 1>(a, n, st);
+        if ((flags & 0x18000) == 0x8000) return launch_split<3, 0, 1>(a, n, st);
+        if ((flags & 0x18000) == 0x10000) return launch_split<3, 0, 2>(a, n, st);
+        if ((flags & 0x18000) == 0x18000) return launch_split<3, 0, 3>(a, n, st);
         return launch_split<3, 0>(a, n, st);
     }
     if (CoutP % 64 == 0) { a.nsplit = CoutP / 64; return launch_split<2, 0>(a, n, st); }
