@@ -44,6 +44,48 @@ __device__ __forceinline__ int reflect_plane(int mm, int d, int M) {
     return r >> 1;  // r keeps parity d
 }
 
+// shared tail of the two pre-denoiser kernels: store x_rgb, form x_rgb - inv_tau*w and emit it in the requested
+// layouts (planar rgb_w, fp32 c8 with the pixel-unshuffle + sigma map, split-fp16 c8s)
+__device__ __forceinline__ void emit_pre_outputs(const float (&rgb)[3][2][2], const float* __restrict__ w,
+                                                 float* __restrict__ x_rgb, float* __restrict__ rgb_w,
+                                                 float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N,
+                                                 int m, int n, int t, float inv_tau, float sigma) {
+    const size_t plane = (size_t)M * N;
+    const int W = 2 * N;
+    const size_t HW = 4 * plane;
+    float in[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const size_t o = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
+            *(float2*)(x_rgb + o) = make_float2(rgb[c][dy][0], rgb[c][dy][1]);
+            float2 wv = make_float2(0.f, 0.f);
+            if (w) wv = *(const float2*)(w + o);
+            in[c][dy][0] = w ? (rgb[c][dy][0] - inv_tau * wv.x) : rgb[c][dy][0];
+            in[c][dy][1] = w ? (rgb[c][dy][1] - inv_tau * wv.y) : rgb[c][dy][1];
+            if (rgb_w) *(float2*)(rgb_w + o) = make_float2(in[c][dy][0], in[c][dy][1]);
+        }
+    if (net_in) {
+        // c8 layout [t][2][M][N][8]; channel = c*4 + dy*2 + dx; 12 = sigma; 13..15 = 0
+        float4* dst0 = (float4*)(net_in + (((size_t)t * 2 + 0) * plane + (size_t)m * N + n) * 8);
+        float4* dst1 = (float4*)(net_in + (((size_t)t * 2 + 1) * plane + (size_t)m * N + n) * 8);
+        dst0[0] = make_float4(in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1]);
+        dst0[1] = make_float4(in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]);
+        dst1[0] = make_float4(in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1]);
+        dst1[1] = make_float4(sigma, 0.f, 0.f, 0.f);
+    }
+    if (net_in_s) {
+        // c8s layout [t][2 groups][2 planes (hi, lo')][M][N][8 fp16] for the split-fp16 convolutions
+        const float g0[8] = {in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1], in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]};
+        const float g1[8] = {in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1], sigma, 0.f, 0.f, 0.f};
+        const size_t pix = (size_t)m * N + n;
+        char* base = net_in_s + (size_t)t * 2 * (2 * plane * 16);
+        split8_store(g0, base + pix * 16, base + plane * 16 + pix * 16);
+        split8_store(g1, base + 2 * plane * 16 + pix * 16, base + 3 * plane * 16 + pix * 16);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
                       const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
@@ -88,39 +130,45 @@ pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
     rgb[1][1][1] = corr5<1, 1, false>(v, K_G);
     rgb[2][1][1] = v[3][3];
 
+    emit_pre_outputs(rgb, w, x_rgb, rgb_w, net_in, net_in_s, M, N, m, n, t, inv_tau, sigma);
+}
+
+// closed-form RGB update of the reference's `close_form_demosaic` branch (dvp...:175-182 / :224-230), k > 0:
+//   x_rgb = (rho*x3 + b3 + tau*out_prev + w) / (rho*mask + tau)   [clipped to [0,1] on the FFDNet branch]
+// with x3, b3 the Bayer planes scattered to their CFA sites (zero elsewhere) and mask the CFA site mask.
+__global__ void __launch_bounds__(256)
+pm_pre_closed_form_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ w,
+                          const float* __restrict__ out_prev, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
+                          float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N, int B, float rho,
+                          float tau, float inv_tau, int clip, float sigma) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    const int t = blockIdx.z;
+    if (n >= N) return;
+    const size_t plane = (size_t)M * N;
     const int W = 2 * N;
     const size_t HW = 4 * plane;
-    float in[3][2][2];
+    float rgb[3][2][2];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const size_t o = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
-            *(float2*)(x_rgb + o) = make_float2(rgb[c][dy][0], rgb[c][dy][1]);
-            float2 wv = make_float2(0.f, 0.f);
-            if (w) wv = *(const float2*)(w + o);
-            in[c][dy][0] = w ? (rgb[c][dy][0] - inv_tau * wv.x) : rgb[c][dy][0];
-            in[c][dy][1] = w ? (rgb[c][dy][1] - inv_tau * wv.y) : rgb[c][dy][1];
-            if (rgb_w) *(float2*)(rgb_w + o) = make_float2(in[c][dy][0], in[c][dy][1]);
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ib = dy * 2 + dx;
+            const int site = (ib == 0) ? 0 : (ib == 3 ? 2 : 1);
+            const size_t so = ((size_t)t * 4 + ib) * plane + (size_t)m * N + n;
+            const float xs = x[so], bs = b[so];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t o = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n + dx;
+                const float x3 = (c == site) ? xs : 0.f, b3 = (c == site) ? bs : 0.f;
+                const float num = ((rho * x3 + b3) + tau * out_prev[o]) + w[o];
+                const float den = ((c == site) ? rho : 0.f) + tau;
+                float v = num / den;
+                if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
+                rgb[c][dy][dx] = v;
+            }
         }
-    if (net_in) {
-        // c8 layout [t][2][M][N][8]; channel = c*4 + dy*2 + dx; 12 = sigma; 13..15 = 0
-        float4* dst0 = (float4*)(net_in + (((size_t)t * 2 + 0) * plane + (size_t)m * N + n) * 8);
-        float4* dst1 = (float4*)(net_in + (((size_t)t * 2 + 1) * plane + (size_t)m * N + n) * 8);
-        dst0[0] = make_float4(in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1]);
-        dst0[1] = make_float4(in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]);
-        dst1[0] = make_float4(in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1]);
-        dst1[1] = make_float4(sigma, 0.f, 0.f, 0.f);
-    }
-    if (net_in_s) {
-        // c8s layout [t][2 groups][2 planes (hi, lo')][M][N][8 fp16] for the split-fp16 convolutions
-        const float g0[8] = {in[0][0][0], in[0][0][1], in[0][1][0], in[0][1][1], in[1][0][0], in[1][0][1], in[1][1][0], in[1][1][1]};
-        const float g1[8] = {in[2][0][0], in[2][0][1], in[2][1][0], in[2][1][1], sigma, 0.f, 0.f, 0.f};
-        const size_t pix = (size_t)m * N + n;
-        char* base = net_in_s + (size_t)t * 2 * (2 * plane * 16);
-        split8_store(g0, base + pix * 16, base + plane * 16 + pix * 16);
-        split8_store(g1, base + 2 * plane * 16 + pix * 16, base + 3 * plane * 16 + pix * 16);
-    }
+    emit_pre_outputs(rgb, w, x_rgb, rgb_w, net_in, net_in_s, M, N, m, n, t, inv_tau, sigma);
 }
 
 constexpr int POST_THREADS = 256;
@@ -226,6 +274,22 @@ int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, flo
     hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, x_rgb, rgb_w,
                        net_in_c8, (char*)net_in_c8s, M, N, B, inv_rho, inv_tau, sigma);
     return launch_status("pm_pre_denoise_kernel");
+}
+
+int scipnp_pm_pre_closed_form(const float* x, const float* b, const float* w, const float* out_prev, float* x_rgb,
+                              float* rgb_w, float* net_in_c8, void* net_in_c8s, int M, int N, int B, float rho, float tau,
+                              float inv_tau, int clip, float sigma, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && b && w && out_prev && x_rgb, "null pointer");
+    SCIPNP_REQUIRE(M >= 1 && N >= 1 && B > 0 && B <= 65535 && M <= 65535, "bad shape M=%d N=%d B=%d", M, N, B);
+    SCIPNP_ALIGNED(x_rgb); SCIPNP_ALIGNED(w);
+    if (rgb_w) SCIPNP_ALIGNED(rgb_w);
+    if (net_in_c8) SCIPNP_ALIGNED(net_in_c8);
+    if (net_in_c8s) SCIPNP_ALIGNED(net_in_c8s);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    hipLaunchKernelGGL(pm_pre_closed_form_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, out_prev, x_rgb, rgb_w,
+                       net_in_c8, (char*)net_in_c8s, M, N, B, rho, tau, inv_tau, clip, sigma);
+    return launch_status("pm_pre_closed_form_kernel");
 }
 
 int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out_rgb_store, float* x,

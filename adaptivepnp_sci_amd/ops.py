@@ -175,6 +175,14 @@ def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma, ne
           float(np.float32(inv_rho)), float(np.float32(inv_tau)), float(np.float32(sigma)), _stream())
 
 
+def pm_pre_closed_form(x, b, w, out_prev, x_rgb, rgb_w, net_in_c8, rho, tau, clip, sigma, net_in_c8s=None):
+    B, _, M, N = x.shape
+    _call('scipnp_pm_pre_closed_form', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(out_prev, 'out_prev'), _p(x_rgb, 'x_rgb'),
+          _p(rgb_w, 'rgb_w'), _p(net_in_c8, 'net_in_c8'), _p(net_in_c8s, 'net_in_c8s', torch.float16), M, N, B,
+          float(np.float32(rho)), float(np.float32(tau)), float(np.float32(1 / tau)), int(bool(clip)),
+          float(np.float32(sigma)), _stream())
+
+
 def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first_iter_alias, orig=None,
                     sse_part=None):
     B, _, M, N = x.shape

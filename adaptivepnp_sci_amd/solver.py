@@ -66,7 +66,7 @@ class AdmmRun:
 
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
-                 update_per_iter=1, update_times=-1, logf=None):
+                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False):
         if denoiser not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         _lib.load()
@@ -101,10 +101,14 @@ class AdmmRun:
             self.alpha = 0.01 if denoiser == 'tv' else 1
             self.rou = 0.55 if denoiser == 'fastdvd_color' else 1
             self.tau = 100
+            if close_form_demosaic:          # reference :112-114: tau = 10, rho = 0.55 for both CNN denoisers
+                self.tau = 10
+                self.rou = 0.55
         else:
             self._lambda, self.gamma = _lambda, gamma
         self.lr_, self.inital_iter, self.interval_iter = lr_, inital_iter, interval_iter
         self.update_, self.update_per_iter, self.update_times = update_, update_per_iter, update_times
+        self.close_form = bool(close_form_demosaic and two_stage and denoiser != 'tv')
         self.update_i = 0
         self.k = 0
         self.out_rgb = None
@@ -157,11 +161,17 @@ class AdmmRun:
             # one-stage CNN branches (:439-496): demosaic(x - b), no w dual, b -= x - theta.  Run the
             # kernels on -b:  x + 1*(-b) = x - b exactly, and (-b) + (x - theta) = -(b - (x - theta)).
             b_in, inv_rho, inv_tau, w = self.b.neg(), 1.0, 0.0, None
+        closed = self.close_form and k > 0      # closed-form RGB update (reference :175-182 / :224-230), Malvar at k = 0
         if self.denoiser == 'ffdnet_color':
             split = self.eng.precision == 'f16x3'
             # the finetune (rare) runs on the fp32 kernels and needs the fp32 c8 input as well
-            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, self.eng.in_c8 if (gate or not split) else None,
-                               inv_rho, inv_tau, nsig, net_in_c8s=self.eng.in_c8s if split else None)
+            c8 = self.eng.in_c8 if (gate or not split) else None
+            c8s = self.eng.in_c8s if split else None
+            if closed:
+                ops.pm_pre_closed_form(self.x, self.b, w, self.out_store, self.x_rgb, None, c8, self.rou, self.tau, True,
+                                       nsig, net_in_c8s=c8s)
+            else:
+                ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s)
             if gate:
                 from .finetune import ffdnet_online_finetune
                 ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,
@@ -170,8 +180,12 @@ class AdmmRun:
             src_rgb, src_c8 = None, self.eng.out_c8
         else:
             net_in = self.rgb_w if self.two_stage else self.x_rgb
-            ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, self.rgb_w if self.two_stage else None, None,
-                               inv_rho, inv_tau, nsig)
+            if closed:
+                ops.pm_pre_closed_form(self.x, self.b, w, self.eng.out, self.x_rgb, self.rgb_w, None, self.rou, self.tau,
+                                       False, nsig)
+            else:
+                ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, self.rgb_w if self.two_stage else None, None,
+                                   inv_rho, inv_tau, nsig)
             if gate and self.two_stage and (self.update_i < self.update_times or self.update_times < 0):
                 from .finetune import fastdvdnet_online_finetune
                 fastdvdnet_online_finetune(self.model, self.eng, net_in, self.y, self.Phi, nsig, self.lr_,
@@ -180,7 +194,7 @@ class AdmmRun:
             src_rgb, src_c8 = self.eng.forward(net_in, nsig), None
         iqa_here = self.iqa and self.two_stage
         part = self._new_sse(ops.post_nblocks(M, N, B)) if iqa_here else None
-        ops.pm_post_denoise(src_rgb, src_c8, self.out_store if (last and src_c8 is not None) else None,
+        ops.pm_post_denoise(src_rgb, src_c8, self.out_store if ((last or self.close_form) and src_c8 is not None) else None,
                             self.x, self.x_rgb if self.two_stage else None, self.theta, b_in, w, k == 0,
                             self.orig if iqa_here else None, part)
         if not self.two_stage:
@@ -267,14 +281,13 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                large=False, update_times=-1, args=None):
     if denoiser not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
-    if close_form_demosaic:
-        raise NotImplementedError('close_form_demosaic is a "next" row of the scope table')
     _check_demosaic(denoiser, demosaic_method, model_demosaic)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
     run = AdmmRun(y_bayer, Phi_bayer, denoiser, True, x0_bayer, X_orig, model_denoise, show_iqa, lr_=lr_,
                   inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
-                  update_per_iter=update_per_iter, update_times=update_times, logf=logf)
+                  update_per_iter=update_per_iter, update_times=update_times, logf=logf,
+                  close_form_demosaic=close_form_demosaic)
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
     _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True)

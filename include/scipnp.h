@@ -126,6 +126,14 @@ int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, flo
                              float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho,
                              float inv_tau, float sigma, scipnp_stream_t s);
 
+/* closed-form RGB update of the reference's `close_form_demosaic=True` branch for iterations k > 0:
+ *   x_rgb = (rho*x3 + b3 + tau*out_prev + w) / (rho*cfa_mask + tau), clipped to [0,1] if clip != 0,
+ * x3/b3 = Bayer planes scattered to their CFA sites; then x_rgb - inv_tau*w in the same layouts as above.
+ * -- dvp...:175-182 (FFDNet branch, clipped) / :224-230 (FastDVDnet branch, not clipped) */
+int scipnp_pm_pre_closed_form(const float* x, const float* b, const float* w, const float* out_prev,
+                              float* x_rgb, float* rgb_w, float* net_in_c8, void* net_in_c8s, int M, int N, int B,
+                              float rho, float tau, float inv_tau, int clip, float sigma, scipnp_stream_t s);
+
 /* post-denoiser fusion: theta_raw = denoised RGB sampled at the CFA sites, theta = clip(theta_raw),
  * b += x_eff - theta with x_eff = theta_raw when first_iter_alias (the reference's k = 0 tensor
  * aliasing, SURVEY 3.2: x and theta are one tensor, so x is overwritten with theta_raw too) else x;

@@ -47,7 +47,7 @@ def _tv(planes_in):
 def two_stage_admm(y_bayer, Phi_bayer, denoiser='tv', iter_max=50, sigma=None, x0_bayer=None,
                    X_orig=None, model_denoise=None, lr=1e-6, inital_iter=1, interval_iter=5,
                    update=False, update_per_iter=1, update_times=-1, finetune_trace=None,
-                   denoiser_io=None):
+                   denoiser_io=None, close_form_demosaic=False):
     """Returns dict(theta_iterates=[(H,W,B) np], psnr_all, x_bayer, rgb (CNN branches), model)."""
     y_bayer = torch.as_tensor(y_bayer)
     Phi_bayer = torch.as_tensor(Phi_bayer)
@@ -62,6 +62,13 @@ def two_stage_admm(y_bayer, Phi_bayer, denoiser='tv', iter_max=50, sigma=None, x
     alpha = 0.01 if denoiser == 'tv' else 1
     rho = 0.55 if denoiser == 'fastdvd_color' else 1
     tau = 100
+    if close_form_demosaic:
+        # closed-form x_rgb update for k > 0 (reference :112-118): tau = 10, rho = 0.55 for BOTH denoisers
+        tau = 10
+        rho = 0.55
+        R_m, G_m, B_m = ops.cfa_masks((H, W))
+        bayer_mask = torch.cat([R_m.unsqueeze(2), G_m.unsqueeze(2), B_m.unsqueeze(2)], dim=2)
+        inv_3ch = torch.repeat_interleave((rho * bayer_mask + tau).unsqueeze(3), nB, dim=3)
     k = 0
     n_updates = 0
     iterates, psnr_all = [], []
@@ -74,8 +81,14 @@ def two_stage_admm(y_bayer, Phi_bayer, denoiser='tv', iter_max=50, sigma=None, x
                 is_tv = True
             elif denoiser in ('ffdnet_color', 'fastdvd_color'):
                 is_tv = False
-                mosaic = ops.bayer_merge(x + (1 / rho) * b)
-                x_rgb = malvar_demosaic_cube(mosaic)
+                if close_form_demosaic and k > 0:
+                    # reference :175-182 (FFDNet branch, clipped) / :224-230 (FastDVDnet branch, NOT clipped)
+                    x_rgb = (rho * ops.four_to_three_channel(x) + ops.four_to_three_channel(b) + tau * rgb_out + w) / inv_3ch
+                    if denoiser == 'ffdnet_color':
+                        x_rgb = x_rgb.clip(0, 1)
+                else:
+                    mosaic = ops.bayer_merge(x + (1 / rho) * b)
+                    x_rgb = malvar_demosaic_cube(mosaic)
                 x_rgb_w = x_rgb - (1 / tau) * w
                 gate = update and k > inital_iter and k % interval_iter == 0
                 if denoiser == 'ffdnet_color':

@@ -249,3 +249,27 @@ def test_fastdvdnet_online_finetune_matches_reference(solver):
             assert abs(dn - ref) <= 0.05 * ref, (k0, dn, ref)          # Adam steps ~ lr*sign(g): norms of the updates agree
         if k0.endswith('running_mean') or k0.endswith('running_var'):
             assert torch.equal(sd[k0], sd0[k0])                        # BatchNorm statistics stay frozen
+
+
+def test_closed_form_demosaic_branch(solver, ffdnet_state_dict):
+    """close_form_demosaic=True (reference :112-118, :175-182, :224-230): tau = 10, rho = 0.55, Malvar only at k = 0,
+    clipped on the FFDNet branch and not on the FastDVDnet branch."""
+    from oracle.nets import synth_fastdvdnet_weights
+    g = load_gold('closedform_64x64x8')
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
+                                            x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=make_ffdnet(ffdnet_state_dict),
+                                            logf=io.StringIO(), close_form_demosaic=True)
+    for k in range(4):
+        assert rel_l2(tr.it[k], g['theta_ffdnet'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_ffdnet'][k]))
+    assert rel_l2(res[0], g['rgb_ffdnet']) <= REL_TOL
+    assert np.abs(np.array(res[4]) - g['psnr_ffdnet']).max() <= PSNR_TOL
+    tr.it.clear()
+    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
+                                            x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, logf=io.StringIO(),
+                                            close_form_demosaic=True)
+    for k in range(3):
+        assert rel_l2(tr.it[k], g['theta_fastdvd'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_fastdvd'][k]))
+    assert rel_l2(res[0], g['rgb_fastdvd']) <= REL_TOL

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Secondary timings on the GPU box: ms per ADMM iteration for the BASELINE configs other than the bench's
+(config 0 ADMM-TV 256x256x8, config 2 FastDVDnet 512x512x8, config 4 tile 256x256x16), plus finetune events."""
+import io, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adaptivepnp_sci_amd import synth
+from adaptivepnp_sci_amd.solver import AdmmRun
+from adaptivepnp_sci_amd.nets import FFDNet
+
+
+def timeit(run, sig, n, warm=3):
+    for _ in range(warm):
+        run.step(sig)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run.step(sig)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+g = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'ffdnet_color_weights.npz'))
+sd = {k: torch.from_numpy(g[k]) for k in g.files}
+for (H, W, B) in ((256, 256, 8), (512, 512, 8)):
+    y, Phi, orig = synth.make_problem(H, W, B, 0)
+    for two in (False, True):
+        run = AdmmRun(y, Phi, 'tv', two, X_orig=orig)
+        print(f'ADMM-TV {"two" if two else "one"}-stage {H}x{W}x{B}: {timeit(run, 0, 50):.3f} ms/iteration')
+y, Phi, orig = synth.make_problem(512, 512, 8, 0)
+tv = AdmmRun(y, Phi, 'tv', False)
+for _ in range(20):
+    tv.step(0)
+warm = tv.result_mosaic()
+for prec in ('f32', 'f16x3'):
+    os.environ['SCIPNP_FFDNET_PRECISION'] = prec
+    net = FFDNet(); net.load_state_dict(sd)
+    run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net)
+    print(f'FFDNet {prec} 512x512x8: {timeit(run, 25/255, 20):.3f} ms/iteration')
+    run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net, update_=True, lr_=2e-6,
+                  update_per_iter=2, inital_iter=0, interval_iter=1)
+    run.step(25 / 255); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run.step(25 / 255); torch.cuda.synchronize()
+    print(f'FFDNet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
+from oracle.nets import synth_fastdvdnet_weights
+fnet = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet)
+print(f'FastDVDnet f32 512x512x8: {timeit(run, 8/255, 5, 1):.3f} ms/iteration')
+run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet, update_=True, lr_=2e-6,
+              update_per_iter=2, inital_iter=0, interval_iter=1)
+run.step(8 / 255); torch.cuda.synchronize()
+t0 = time.perf_counter(); run.step(8 / 255); torch.cuda.synchronize()
+print(f'FastDVDnet iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
+y, Phi, orig = synth.make_problem(256, 256, 16, 0)
+net = FFDNet(); net.load_state_dict(sd)
+run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net)
+print(f'FFDNet f16x3 tile 256x256x16: {timeit(run, 25/255, 20):.3f} ms/iteration')

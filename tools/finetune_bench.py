@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""GPU box: one FFDNet online-finetune event (2 Adam steps) at 512x512x8, for rocprofv3 kernel traces."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adaptivepnp_sci_amd import synth
+from adaptivepnp_sci_amd.solver import AdmmRun
+from adaptivepnp_sci_amd.nets import FFDNet
+g = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'ffdnet_color_weights.npz'))
+sd = {k: torch.from_numpy(g[k]) for k in g.files}
+y, Phi, orig = synth.make_problem(512, 512, 8, 0)
+net = FFDNet(); net.load_state_dict(sd)
+run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,
+              inital_iter=0, interval_iter=1)
+run.step(25 / 255)
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run.step(25 / 255)
+    torch.cuda.synchronize(); print(f'iteration with finetune: {(time.perf_counter() - t0) * 1e3:.1f} ms')

@@ -401,7 +401,39 @@ def g_fastdvd():
          losses=np.array(trace), **dn)
 
 
-GROUPS = dict(weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+def g_closedform():
+    """close_form_demosaic=True (reference :112-118, :175-182, :224-230): tau = 10, rho = 0.55, closed-form RGB update
+    for k > 0 (Malvar only at k = 0); clipped on the FFDNet branch, not on the FastDVDnet branch."""
+    net, sd = load_ref_ffdnet()
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=6)
+    warm = _tv_warm(y, Phi, 20)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=net,
+                                           show_iqa=True, demosaic_method='malvar2004', logf=logf,
+                                           close_form_demosaic=True)
+    ref_it = np.stack(cap.iterates)
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [4], [25 / 255], x0_bayer=warm, X_orig=orig,
+                          model_denoise=oracle_ffdnet(sd), close_form_demosaic=True)
+    check('closed-form FFDNet iterates', np.stack(o['theta_iterates']), ref_it)
+    rnet, onet, _ = _ref_fastdvd(0)
+    seed_all()
+    with Capture() as cap:
+        res2 = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
+                                            x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rnet,
+                                            show_iqa=True, demosaic_method='malvar2004', logf=logf,
+                                            close_form_demosaic=True)
+    ref_it2 = np.stack(cap.iterates)
+    o2 = OS.two_stage_admm(y, Phi, 'fastdvd_color', [3], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                           close_form_demosaic=True)
+    check('closed-form FastDVDnet iterates', np.stack(o2['theta_iterates']), ref_it2)
+    save('closedform_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta_ffdnet=ref_it, rgb_ffdnet=res[0],
+         psnr_ffdnet=res[4], theta_fastdvd=ref_it2, rgb_fastdvd=res2[0])
+
+
+GROUPS = dict(closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
