@@ -40,7 +40,7 @@ def gather_units(local, n_units, unit_shape, device, dtype=torch.float32, dst=0,
     buf = torch.zeros((slots,) + tuple(unit_shape), dtype=dtype, device=device)
     for s, u in enumerate(mine):
         buf[s].copy_(local[u])
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return [buf[s] for s in range(len(mine))]
     recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, recv, dst=dst, group=group)

@@ -113,9 +113,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SCIPNP_BENCH_FORCE_DIST'):       # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
@@ -159,6 +162,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):                           # measured in separate rocprofv3 --pmc passes, see the file's note
+        traffic = json.load(open(tpath)).get(run.eng.precision, {}).get('hbm_bytes_per_launch')
     body_ms = [a.elapsed_time(b) for a, b in events]
     body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
     psnr = run.psnr_all()
@@ -183,7 +190,8 @@ def main():
                                    'sigma=25/255, TV warm start, per-iteration PSNR on device', 'cube': [H, W, B],
                        'parallelism': f'{world} independent cube(s), one per GPU, one RCCL gather at the end'},
             'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None, 'kernel': kname,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_traffic.json)',
+                         'algorithmic_bytes_per_launch': 2.0 * B * NC * (H // 2) * (W // 2) * 4, 'kernel': kname,
                          'flop_per_launch': BODY_FLOP_PER_LAUNCH, 'avg_launch_ms': body_launch_s * 1e3,
                          'denoiser_flop_per_iter': FFDNET_FLOP_PER_ITER,
                          # honest bookkeeping for the split kernel: `achieved` counts ALGORITHMIC fp32-conv FLOPs; the

@@ -13,5 +13,5 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1
 done
-python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
