@@ -301,6 +301,13 @@ def c8_to_c8s(x):
     return out
 
 
+def split_overflow(reset=True):
+    """True if the split-fp16 kernels saw a value outside fp16's range since the last reset (synchronises)."""
+    flag = C.c_int(0)
+    _call('scipnp_split_overflow', int(bool(reset)), C.byref(flag), _stream())
+    return bool(flag.value)
+
+
 def c8s_to_float(x):
     """c8s (hi, lo') -> fp32 c8 values hi + lo'/2048 (test helper, torch arithmetic)"""
     return x[:, :, 0].float() + x[:, :, 1].float() / 2048.0

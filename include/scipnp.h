@@ -192,6 +192,10 @@ int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, i
                               void* packed);
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout,
                        int h, int w, int flags, scipnp_stream_t s);
+/* range guard of the split format: *flag_out = 1 if any value written to a c8s tensor by these kernels since the last
+ * reset was >= 65000 in magnitude or NaN (results invalid: rerun with the fp32 kernels).  SYNCHRONISES the stream;
+ * call once per reconstruction. */
+int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s);
 /* fp32 c8 -> c8s */
 int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s);
 

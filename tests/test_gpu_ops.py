@@ -491,3 +491,15 @@ def test_ffdnet_forward_split_precision(ffdnet_state_dict, monkeypatch):
     x = dev(g['in_128x128'])
     out = net(x, torch.full((1, 1, 1, 1), 25 / 255.)).cpu().numpy()
     assert rel_l2(out, g['out_128x128_s25']) < 5e-6
+
+
+def test_split_overflow_guard(ops):
+    x = torch.zeros(1, 8, 8, 32)
+    wt = torch.zeros(8, 8, 3, 3)
+    wt[:, :, 1, 1] = 30.0
+    packed = ops.pack_conv3x3_split(wt, None, Cin=8, Cout=8, device='cuda')
+    ops.split_overflow()                                           # clear
+    ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda() + 1.0)), packed, 8)
+    assert not ops.split_overflow()
+    ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda() + 400.0)), packed, 8)    # 8*30*400 = 96000 > fp16 max
+    assert ops.split_overflow() and not ops.split_overflow()       # reported once, then reset

@@ -31,12 +31,19 @@ def raw(flags):
 variants['f16x3 late-fill'] = raw(0x2000)
 variants['f16x3 no-stage'] = raw(0x1000)
 variants['f16x3 no-stage no-barrier'] = raw(0x1000 | 0x4000)
+variants['f16x3 register staging'] = raw(0x20000)
 variants['nostage nopkmul'] = raw(0x1000 | 0x8000)
 variants['nostage noldsread'] = raw(0x1000 | 0x10000)
 variants['nostage nopkmul noldsread'] = raw(0x1000 | 0x18000)
-for f in variants.values():
+variants['f16x3']()
+torch.cuda.synchronize()
+ref_out = os_.clone()
+for name, f in variants.items():
     for _ in range(3):
         f()
+    torch.cuda.synchronize()
+    if name.startswith('f16x3') and 'no-' not in name:
+        print(f'{name:26s} output identical to default: {bool(torch.equal(os_, ref_out))}')
 torch.cuda.synchronize()
 res = {k: [] for k in variants}
 for r in range(5):
