@@ -66,9 +66,12 @@ SIGNATURES = {
     'scipnp_fastdvd_unpack_bwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_conv3x3_split_packed_bytes': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_split': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_pack_conv3x3_split_bn': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_split_overflow': (_int, [_int, C.POINTER(_int), _vp]),
     'scipnp_c8_to_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_c8_add_to_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_fastdvd_pack_triplets_c8s': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),

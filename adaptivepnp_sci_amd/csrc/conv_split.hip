@@ -17,16 +17,20 @@
 //  packed fp16 multiply, |w| < 31.9 is checked when packing -- instead of scaling the cross terms down.)
 //
 // Layout "c8s": activations [n][C/8][2][h][w][8] fp16 -- per 8-channel group a hi plane and a lo' plane, 16 bytes
-// per pixel and plane: the same footprint as fp32 c8, lanes of a wave read/write 16 B at 16-B stride in both
-// global memory and LDS (bank-conflict free).  The epilogue splits the fp32 result again, or stores fp32 c8
-// for the network's last layer.  Workgroup / K-loop structure as conv.hip (8x32 pixels x 96 channels, 4 waves,
-// double-buffered LDS stages of one 8-channel group, one barrier per group), but the stages are filled by LDS-DMA
-// (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; lanes outside the image fetch zeros through
-// the buffer descriptor's bounds check): 168 VGPRs instead of 224 and 7 % less time than register staging.
+// per pixel and plane: the same footprint as fp32 c8; lanes of a wave read/write 16 B at 16-B stride in both
+// global memory and LDS (bank-conflict free).
+//
+// Structure (as conv.hip): workgroup = 4 waves = 8x32 output pixels x (32*COB) channels, wave = 2 rows; K loop over
+// the input channel groups; per group the input halo tile (both planes) and the weight slab are staged into one of
+// two LDS buffers by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; lanes outside the
+// image fetch zeros through the buffer descriptor's bounds check), issued one group ahead; fragments are read with
+// ds_read_b128; one s_waitcnt vmcnt(0) + barrier per group.  168 VGPRs, 80 KiB LDS -> 2 workgroups per CU.
+// Epilogues: split again to c8s (+ReLU), or fp32 c8 (network tails), or fp32 c8 with PixelShuffle(2) folded into the
+// store; stride 1 or 2.
 #include "common.hpp"
 #include <hip/hip_fp16.h>
-#include <cstring>
 #include <cmath>
+#include <cstring>
 
 namespace scipnp {
 
@@ -36,29 +40,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CS_TH = 8, CS_TW = 32;
-constexpr int CS_TWP = CS_TW + 2, CS_THP = CS_TH + 2;
 constexpr int CS_THREADS = 256;
-constexpr int CS_IN_PLANE = CS_THP * CS_TWP * 16;             // bytes of one plane of the input tile (5440)
-constexpr int CS_IN_BYTES = 2 * CS_IN_PLANE;
-constexpr int CS_IN_VEC = CS_IN_BYTES / 16;                   // 680
-constexpr int CS_IN_ITERS = (CS_IN_VEC + CS_THREADS - 1) / CS_THREADS;
 constexpr float CS_LO_SCALE = 2048.f, CS_LO_INV = 1.f / 2048.f;
 
-template <int COB>
+template <int COB, int STRIDE>
 struct SplitCfg {
+    static constexpr int TWP = (CS_TW - 1) * STRIDE + 3;      // input tile columns (34 / 65)
+    static constexpr int THP = (CS_TH - 1) * STRIDE + 3;      // input tile rows    (10 / 17)
+    static constexpr int IN_PLANE = THP * TWP * 16;           // bytes of one plane of the input tile
+    static constexpr int IN_VEC = 2 * THP * TWP;              // 16-byte units (both planes)
+    static constexpr int IN_ITERS = (IN_VEC + CS_THREADS - 1) / CS_THREADS;
     static constexpr int COUTP = 32 * COB;
-    static constexpr int W_PLANE = COUTP * 16;                // bytes of one (tap, plane)
-    static constexpr int W_BYTES = 9 * 2 * W_PLANE;
-    static constexpr int W_VEC = W_BYTES / 16;
+    static constexpr int W_VEC = 9 * 2 * COUTP;
     static constexpr int W_ITERS = (W_VEC + CS_THREADS - 1) / CS_THREADS;
-    static constexpr int STAGE = CS_IN_BYTES + W_BYTES;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
-    // LDS-DMA variant: every lane of every 64-lane load instruction writes 16 bytes, so both regions are padded
-    // to whole 256-unit rounds (out-of-range lanes fetch zeros through the buffer bounds check)
-    static constexpr int IN_PAD = CS_IN_ITERS * CS_THREADS * 16;
+    // every lane of every 64-lane LDS-DMA instruction writes 16 bytes: both regions are padded to whole 256-unit
+    // rounds (out-of-range lanes fetch zeros through the buffer bounds check)
+    static constexpr int IN_PAD = IN_ITERS * CS_THREADS * 16;
     static constexpr int W_PAD = W_ITERS * CS_THREADS * 16;
-    static constexpr int STAGE_DMA = IN_PAD + W_PAD;
-    static constexpr size_t LDS_BYTES_DMA = 2 * (size_t)STAGE_DMA;
+    static constexpr int STAGE = IN_PAD + W_PAD;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
+    static constexpr int WAVES_PER_SIMD = (LDS_BYTES * 2 <= 160 * 1024 && COB <= 3) ? 2 : 1;
 };
 
 struct SplitArgs {
@@ -66,8 +67,9 @@ struct SplitArgs {
     const char* wpk;     // packed split weights: [cig][tap][2][CoutP][8] fp16, then bias fp32 [CoutP]
     char* out;           // c8s (fp16 split) or fp32 c8
     int CGin, CGout, CoutP_total, nsplit;
-    int H, W;
-    int flags;           // bit0 ReLU, bit5 (32) = fp32 c8 output
+    int H, W;            // input size
+    int Ho, Wo;          // conv output size (before any pixel shuffle)
+    int flags;           // bit0 ReLU, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle store (fp32 output only)
 };
 
 // set when a value leaves fp16's finite range on its way into the c8s format (results are then invalid and the
@@ -88,14 +90,11 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
     *(f16x4*)lo_ptr = l;
 }
 
-template <int COB, int TAG, int DBG = 0>   // DBG: timing experiments (1: no pk_mul, 2: LDS fragments read once per group);
-                                          // DBG & 4: stage through LDS-DMA (buffer_load ... lds) instead of registers
-__global__ void __launch_bounds__(CS_THREADS, 2)
+// TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
+template <int COB, int TAG, int STRIDE, int SHUF>
+__global__ void __launch_bounds__(CS_THREADS, (SplitCfg<COB, STRIDE>::WAVES_PER_SIMD))
 conv3x3_c8s_kernel(const SplitArgs a) {
-    using Cfg = SplitCfg<COB>;
-    constexpr bool DMA = (DBG & 4) != 0;
-    constexpr int STAGE_B = DMA ? Cfg::STAGE_DMA : Cfg::STAGE;
-    constexpr int W_BASE = DMA ? Cfg::IN_PAD : CS_IN_BYTES;
+    using Cfg = SplitCfg<COB, STRIDE>;
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -104,109 +103,72 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
-    const size_t grp_bytes = 2 * HW * 16;                      // one channel group (both planes)
+    const size_t grp_bytes = 2 * HW * 16;                      // one input channel group (both planes)
 
-    // staging plan (byte offsets inside one channel group / one weight slab), -1 = zero fill
-    int in_off[CS_IN_ITERS];
+    // staging plan: unit e = tid + 256k of a region is lane (tid & 63) of the wave instruction that fills the
+    // 1 KiB at byte 16*(wave*64 + 256k).  Byte offsets inside one channel group / weight slab; OOB -> zeros.
+    const unsigned OOB = 0x80000000u;
+    unsigned in_off[Cfg::IN_ITERS];
 #pragma unroll
-    for (int k = 0; k < CS_IN_ITERS; ++k) {
+    for (int k = 0; k < Cfg::IN_ITERS; ++k) {
         const int e = tid + k * CS_THREADS;
-        in_off[k] = -1;
-        if (e < CS_IN_VEC) {
-            const int plane = e / (CS_THP * CS_TWP), pix = e - plane * (CS_THP * CS_TWP);
-            const int r = pix / CS_TWP, c = pix - r * CS_TWP;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[k] = (int)((plane * HW + (size_t)gy * W + gx) * 16);
+        in_off[k] = OOB;
+        if (e < Cfg::IN_VEC) {
+            const int plane = e / (Cfg::THP * Cfg::TWP), pix = e - plane * (Cfg::THP * Cfg::TWP);
+            const int r = pix / Cfg::TWP, c = pix - r * Cfg::TWP;
+            const int gy = y0 * STRIDE - 1 + r, gx = x0 * STRIDE - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[k] = (unsigned)((plane * HW + (size_t)gy * W + gx) * 16);
         }
     }
-    int w_off[Cfg::W_ITERS];
+    unsigned w_off[Cfg::W_ITERS];
 #pragma unroll
     for (int k = 0; k < Cfg::W_ITERS; ++k) {
         const int e = tid + k * CS_THREADS;
-        w_off[k] = -1;
+        w_off[k] = OOB;
         if (e < Cfg::W_VEC) {
             const int tp = e / Cfg::COUTP, co = e - tp * Cfg::COUTP;       // tp = tap*2 + plane
-            w_off[k] = (tp * a.CoutP_total + split * Cfg::COUTP + co) * 16;
+            w_off[k] = (unsigned)((tp * a.CoutP_total + split * Cfg::COUTP + co) * 16);
         }
     }
     const char* in_g = a.in + (size_t)n * a.CGin * grp_bytes;
     const char* w_g = a.wpk;
     const size_t w_step = (size_t)9 * 2 * a.CoutP_total * 16;
-
-    f32x4 st_in[CS_IN_ITERS];
-    f32x4 st_w[Cfg::W_ITERS];
-    auto issue_loads = [&]() {
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    (void)wvu;
+    auto dma_stage = [&](char* buf) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep them out of the host pass that only emits the launch stub
+        auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, (int)grp_bytes, 0x00020000);
+        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, (int)w_step, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < CS_IN_ITERS; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (in_off[k] >= 0) v = *(const f32x4*)(in_g + in_off[k]);
-            st_in[k] = v;
-        }
+        for (int k = 0; k < Cfg::IN_ITERS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_in, (__attribute__((address_space(3))) void*)(buf + 16 * (wvu * 64 + k * CS_THREADS)), 16, in_off[k], 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < Cfg::W_ITERS; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (w_off[k] >= 0) v = *(const f32x4*)(w_g + w_off[k]);
-            st_w[k] = v;
-        }
+        for (int k = 0; k < Cfg::W_ITERS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_w, (__attribute__((address_space(3))) void*)(buf + Cfg::IN_PAD + 16 * (wvu * 64 + k * CS_THREADS)), 16,
+                w_off[k], 0, 0, 0);
+#endif
         in_g += grp_bytes;
         w_g += w_step;
     };
-    auto write_lds = [&](char* buf) {
-#pragma unroll
-        for (int k = 0; k < CS_IN_ITERS; ++k) {
-            const int e = tid + k * CS_THREADS;
-            if (e < CS_IN_VEC) *(f32x4*)(buf + 16 * e) = st_in[k];
-        }
-#pragma unroll
-        for (int k = 0; k < Cfg::W_ITERS; ++k) {
-            const int e = tid + k * CS_THREADS;
-            if (e < Cfg::W_VEC) *(f32x4*)(buf + CS_IN_BYTES + 16 * e) = st_w[k];
-        }
-    };
 
-    f32x16 acc1[2][COB];
+    f32x16 acc[2][COB];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[pb][cb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
 
-    // LDS-DMA staging: unit e = tid + 256k of a region is lane (tid&63) of the wave instruction that fills the 1 KiB
-    // at byte 16*(wave*64 + 256k): the same unit->thread map as the register path, so in_off/w_off are reused
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    auto dma_stage = [&](char* buf) {
-#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep them out of the host pass that only emits the launch stub
-        const unsigned OOB = 0x80000000u;
-        auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, (int)grp_bytes, 0x00020000);
-        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, (int)w_step, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < CS_IN_ITERS; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_in, (__attribute__((address_space(3))) void*)(buf + 16 * (wvu * 64 + k * CS_THREADS)), 16,
-                in_off[k] >= 0 ? (unsigned)in_off[k] : OOB, 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < Cfg::W_ITERS; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_w, (__attribute__((address_space(3))) void*)(buf + Cfg::IN_PAD + 16 * (wvu * 64 + k * CS_THREADS)), 16,
-                w_off[k] >= 0 ? (unsigned)w_off[k] : OOB, 0, 0, 0);
-#endif
-        in_g += grp_bytes;
-        w_g += w_step;
-    };
-    if (DMA) {
-        dma_stage(smem_s);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        issue_loads();
-        write_lds(smem_s);
-    }
+    dma_stage(smem_s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // LDS byte offsets.  input: plane p at p*CS_IN_PLANE, pixel (r,c) at (r*TWP + c)*16
-    //                    weights: CS_IN_BYTES + ((tap*2 + plane)*COUTP + co)*16
-    const int px_base = ((2 * wv) * CS_TWP + li) * 16;                       // + ((pb+ky)*TWP + kx)*16
-    const int co_base = W_BASE + li * 16;                                    // + ((tap*2+plane)*COUTP + cb*32)*16
+    // LDS byte offsets.  input: plane p at p*IN_PLANE, pixel (r,c) at (r*TWP + c)*16
+    //                    weights: IN_PAD + ((tap*2 + plane)*COUTP + co)*16
+    const int px_base = ((2 * wv * STRIDE) * Cfg::TWP + li * STRIDE) * 16;   // + ((pb*S+ky)*TWP + kx)*16
+    const int co_base = Cfg::IN_PAD + li * 16;                               // + ((tap*2+plane)*COUTP + cb*32)*16
     // hi x hi tap pairs: lane half h handles tap 2p+h; per-lane offsets and scale (0 for the missing tap 9) hoisted
     int pair_px[5], pair_co[5];
     _Float16 pair_scale[5];
@@ -216,42 +178,35 @@ conv3x3_c8s_kernel(const SplitArgs a) {
         const bool live = tap_h < 9;
         const int tp = live ? tap_h : 8;
         const int ky = tp / 3, kx = tp - 3 * ky;
-        pair_px[p] = px_base + (ky * CS_TWP + kx) * 16;
+        pair_px[p] = px_base + (ky * Cfg::TWP + kx) * 16;
         pair_co[p] = co_base + (tp * 2 * Cfg::COUTP) * 16;
         pair_scale[p] = (_Float16)(live ? CS_LO_SCALE : 0.f);
     }
 
     for (int cig = 0; cig < a.CGin; ++cig) {
-        const char* buf = smem_s + ((a.flags & 0x1000) ? 0 : (cig & 1) * STAGE_B);
-        const bool dbg_nostage = a.flags & 0x1000, dbg_late = a.flags & 0x2000;   // timing experiments only
-        const bool more = (cig + 1 < a.CGin) && !dbg_nostage;
-        if (more) {
-            if (DMA) dma_stage(smem_s + ((cig + 1) & 1) * STAGE_B);
-            else issue_loads();
-        }
+        const char* buf = smem_s + (cig & 1) * Cfg::STAGE;
+        if (cig + 1 < a.CGin) dma_stage(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
         // 14 MFMA steps per group: 5 hi x hi tap pairs (lane half h handles tap 2p+h, tap 9 -> zero weights)
         // then 9 cross-term taps (k 0..7 = w_lo' x_hi from lane half 0, k 8..15 = w_hi x_lo' from lane half 1).
-        // Fragments are software-pipelined: step s+1's LDS reads are issued before step s's MFMAs.
         f16x8 bfA[2], afA[COB], bfB[2], afB[COB];
         auto load_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
-            if ((DBG & 2) && s > 1) return;
             if (s < 5) {
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * CS_TWP * 16);
+                for (int pb = 0; pb < 2; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * STRIDE * Cfg::TWP * 16);
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb) af[cb] = *(const f16x8*)(buf + pair_co[s] + cb * 32 * 16);
             } else {
                 const int tap = s - 5, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
-                    bf[pb] = *(const f16x8*)(buf + lh * CS_IN_PLANE + px_base + ((pb + ky) * CS_TWP + kx) * 16);
+                    bf[pb] = *(const f16x8*)(buf + lh * Cfg::IN_PLANE + px_base + ((pb * STRIDE + ky) * Cfg::TWP + kx) * 16);
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
                     af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
             }
         };
         auto mma_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
-            if (s < 5 && !(DBG & 1)) {
+            if (s < 5) {
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb) af[cb] = af[cb] * (f16x8)pair_scale[s];     // exact 2^11 (or 0)
             }
@@ -259,7 +214,7 @@ conv3x3_c8s_kernel(const SplitArgs a) {
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
-                    acc1[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc1[pb][cb], 0, 0, 0);
+                    acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc[pb][cb], 0, 0, 0);
         };
         load_step(0, bfA, afA);
 #pragma unroll
@@ -268,21 +223,21 @@ conv3x3_c8s_kernel(const SplitArgs a) {
             mma_step(s2, bfA, afA);
             if (s2 + 2 < 14) load_step(s2 + 2, bfA, afA);
             mma_step(s2 + 1, bfB, afB);
-            // fill the other LDS buffer once the loads issued at the top of the group have had ~2000 cycles
-            if (!DMA && s2 == (dbg_late ? 12 : 8) && more) write_lds(smem_s + ((cig + 1) & 1) * STAGE_B);
         }
-        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(a.flags & 0x4000)) __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next group's LDS-DMA has landed
+        __syncthreads();
     }
 
     // ---- epilogue
     const float* bias = (const float*)(a.wpk + (size_t)a.CGin * w_step);
-    const bool relu = a.flags & 1, f32out = a.flags & 32;
+    const bool relu = a.flags & 1, f32out = (a.flags & 32) || SHUF;
+    const int Ho = a.Ho, Wo = a.Wo;
+    const size_t HWo = (size_t)Ho * Wo;
     const int x = x0 + li;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         const int y = y0 + 2 * wv + pb;
-        if (y < H && x < W) {
+        if (y < Ho && x < Wo) {
 #pragma unroll
             for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
@@ -293,16 +248,25 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = acc1[pb][cb][4 * g + e] * CS_LO_INV + bs[e];
+                            v[e] = acc[pb][cb][4 * g + e] * CS_LO_INV + bs[e];
                             if (relu) v[e] = fmaxf(v[e], 0.f);
                         }
-                        const size_t pix = (size_t)y * W + x;
-                        if (f32out) {
+                        const size_t pix = (size_t)y * Wo + x;
+                        if (SHUF) {
+                            // PixelShuffle(2): conv channel 8*cog + 4*lh + e -> channel c = 2*cog + lh of pixel
+                            // (2y + (e>>1), 2x + (e&1)); fp32 c8 tensor [n][CGout/4][2Ho][2Wo][8]
+                            const int CGs = a.CGout >> 2;
+                            float* o32 = (float*)a.out;
+                            const size_t base = (((size_t)n * CGs + (cog >> 2)) * (2 * Ho) + 2 * y) * (size_t)(2 * Wo) * 8 +
+                                                (size_t)(2 * x) * 8 + (cog & 3) * 2 + lh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o32[base + (size_t)(e >> 1) * (2 * Wo) * 8 + (e & 1) * 8] = v[e];
+                        } else if (f32out) {
                             f32x4 o = {v[0], v[1], v[2], v[3]};
-                            *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HW + pix) * 8 + 4 * lh) * 4) = o;
+                            *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HWo + pix) * 8 + 4 * lh) * 4) = o;
                         } else {
-                            char* grp = a.out + ((size_t)n * a.CGout + cog) * grp_bytes;
-                            split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 8 * lh, grp + HW * 16 + pix * 16 + 8 * lh);
+                            char* grp = a.out + ((size_t)n * a.CGout + cog) * (2 * HWo * 16);
+                            split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 8 * lh, grp + HWo * 16 + pix * 16 + 8 * lh);
                         }
                     }
                 }
@@ -310,21 +274,33 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     }
 }
 
-template <int COB, int TAG, int DBG = 0>
+template <int COB, int TAG, int STRIDE, int SHUF>
 static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
-    using Cfg = SplitCfg<COB>;
+    using Cfg = SplitCfg<COB, STRIDE>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, DBG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((DBG & 4) ? Cfg::LDS_BYTES_DMA : Cfg::LDS_BYTES));
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const dim3 grid((a.W + CS_TW - 1) / CS_TW, (a.H + CS_TH - 1) / CS_TH, n * a.nsplit);
-    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, DBG>), grid, dim3(CS_THREADS),
-                       (DBG & 4) ? Cfg::LDS_BYTES_DMA : Cfg::LDS_BYTES, st, a);
+    const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + CS_TH - 1) / CS_TH, n * a.nsplit);
+    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF>), grid, dim3(CS_THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_kernel");
+}
+
+template <int STRIDE, int SHUF>
+static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
+    const int CoutP = a.CoutP_total;
+    if (CoutP % 96 == 0) {
+        a.nsplit = CoutP / 96;
+        if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return launch_split<3, 1, 1, 0>(a, n, st);
+        return launch_split<3, 0, STRIDE, SHUF>(a, n, st);
+    }
+    if (CoutP % 128 == 0) { a.nsplit = CoutP / 128; return launch_split<4, 0, STRIDE, SHUF>(a, n, st); }
+    if (CoutP % 64 == 0) { a.nsplit = CoutP / 64; return launch_split<2, 0, STRIDE, SHUF>(a, n, st); }
+    a.nsplit = CoutP / 32;
+    return launch_split<1, 0, STRIDE, SHUF>(a, n, st);
 }
 
 static inline int round_up_s(int v, int m) { return (v + m - 1) / m * m; }
@@ -336,14 +312,24 @@ static inline void split_host(float v, _Float16* hi, _Float16* lo) {
     *lo = (_Float16)((v - (float)h) * CS_LO_SCALE);
 }
 
-// fp32 c8 -> c8s (test / entry helper)
+// fp32 c8 (+ optional c8s residual) -> c8s
 __global__ void __launch_bounds__(256)
-c8_to_c8s_kernel(const float* __restrict__ in, char* __restrict__ out, size_t HW, size_t total /* n*CG*HW */) {
+c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, char* __restrict__ out, size_t HW,
+                 size_t total /* n*CG*HW */) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t grp = i / HW, pix = i - grp * HW;
-    const f32x4 a = *(const f32x4*)(in + i * 8), b = *(const f32x4*)(in + i * 8 + 4);
+    f32x4 a = *(const f32x4*)(in + i * 8), b = *(const f32x4*)(in + i * 8 + 4);
     char* g = out + grp * (2 * HW * 16);
+    if (res) {
+        const f16x8 rh = *(const f16x8*)(res + grp * (2 * HW * 16) + pix * 16);
+        const f16x8 rl = *(const f16x8*)(res + grp * (2 * HW * 16) + HW * 16 + pix * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = a[e] + ((float)rh[e] + (float)rl[e] * CS_LO_INV);
+            b[e] = b[e] + ((float)rh[4 + e] + (float)rl[4 + e] * CS_LO_INV);
+        }
+    }
     split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16);
     split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
 }
@@ -354,14 +340,17 @@ using namespace scipnp;
 
 extern "C" {
 
+int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
+                         scipnp_stream_t s);
+
 size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
     const int CoutP = round_up_s(Cout, 32);
     return (size_t)(Cin / 8) * 9 * 2 * CoutP * 16 + (size_t)CoutP * 4;
 }
 
-int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
-                              void* packed) {
+int scipnp_pack_conv3x3_split_bn(const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
+                                 int Cin_real, int Cout_real, int Cin, int Cout, void* packed) {
     SCIPNP_REQUIRE(w && packed, "null pointer");
     SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
                    "bad channel counts");
@@ -369,20 +358,33 @@ int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, i
     const size_t nw_bytes = (size_t)(Cin / 8) * 9 * 2 * CoutP * 16;
     memset(packed, 0, nw_bytes + (size_t)CoutP * 4);
     _Float16* p = (_Float16*)packed;
-    for (int co = 0; co < Cout_real; ++co)
+    for (int co = 0; co < Cout_real; ++co) {
+        const float sc = bn_scale ? bn_scale[co] : 1.f;
         for (int ci = 0; ci < Cin_real; ++ci)
             for (int tap = 0; tap < 9; ++tap) {
                 _Float16 hi, lo;
-                const float wv_ = w[((size_t)co * Cin_real + ci) * 9 + tap];
+                float wv_ = w[((size_t)co * Cin_real + ci) * 9 + tap];
+                if (bn_scale) wv_ = wv_ * sc;
                 if (!(fabsf(wv_) < 31.9f)) return fail(SCIPNP_EINVAL, "split-fp16 conv needs |w| < 31.9 (got %g)", (double)wv_);
                 split_host(wv_, &hi, &lo);
                 const size_t base = ((size_t)(ci / 8) * 9 + tap) * 2;
                 p[((base + 0) * CoutP + co) * 8 + (ci % 8)] = hi;
                 p[((base + 1) * CoutP + co) * 8 + (ci % 8)] = lo;
             }
+    }
     float* b = (float*)((char*)packed + nw_bytes);
-    for (int co = 0; co < Cout_real; ++co) b[co] = bias ? bias[co] : 0.f;
+    for (int co = 0; co < Cout_real; ++co) {
+        float bv = bias ? bias[co] : 0.f;
+        if (bn_scale) bv = bv * bn_scale[co];
+        if (bn_shift) bv = bv + bn_shift[co];
+        b[co] = bv;
+    }
     return SCIPNP_OK;
+}
+
+int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
+                              void* packed) {
+    return scipnp_pack_conv3x3_split_bn(w, bias, nullptr, nullptr, Cin_real, Cout_real, Cin, Cout, packed);
 }
 
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout, int h, int w,
@@ -391,26 +393,21 @@ int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, 
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
     SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(packed_split); SCIPNP_ALIGNED(out);
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 31), "image too large for 32-bit tile offsets");
+    const bool stride2 = flags & 4, shuf = flags & 8;
+    SCIPNP_REQUIRE(!(stride2 && shuf), "stride-2 and pixel-shuffle epilogue cannot be combined");
+    SCIPNP_REQUIRE(!shuf || Cout % 32 == 0, "pixel-shuffle epilogue needs Cout %% 32 == 0 (got %d)", Cout);
     SplitArgs a;
     a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out;
-    a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up_s(Cout, 32);
-    a.H = h; a.W = w; a.flags = flags;
+    a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up_s(Cout, 32); a.nsplit = 1;
+    a.H = h; a.W = w;
+    a.Ho = stride2 ? (h - 1) / 2 + 1 : h;
+    a.Wo = stride2 ? (w - 1) / 2 + 1 : w;
+    a.flags = flags;
     hipStream_t st = (hipStream_t)s;
-    const int CoutP = a.CoutP_total;
-    SCIPNP_REQUIRE((long long)n * (CoutP / 32) <= 65535, "grid too large");
-    if (CoutP % 96 == 0) {
-        a.nsplit = CoutP / 96;
-        if (flags & 0x100) return launch_split<3, 1, 4>(a, n, st);
-        // timing experiments (tools/conv_bench.py): register staging, no pk_mul, fragments read once
-        if ((flags & 0x18000) == 0x8000) return launch_split<3, 0, 1>(a, n, st);
-        if ((flags & 0x18000) == 0x10000) return launch_split<3, 0, 2>(a, n, st);
-        if ((flags & 0x18000) == 0x18000) return launch_split<3, 0, 3>(a, n, st);
-        if (flags & 0x20000) return launch_split<3, 0, 0>(a, n, st);
-        return launch_split<3, 0, 4>(a, n, st);          // default: LDS-DMA staging
-    }
-    if (CoutP % 64 == 0) { a.nsplit = CoutP / 64; return launch_split<2, 0, 4>(a, n, st); }
-    a.nsplit = CoutP / 32;
-    return launch_split<1, 0, 4>(a, n, st);
+    SCIPNP_REQUIRE((long long)n * (a.CoutP_total / 32) <= 65535, "grid too large");
+    if (stride2) return dispatch_split<2, 0>(a, n, st);
+    if (shuf) return dispatch_split<1, 1>(a, n, st);
+    return dispatch_split<1, 0>(a, n, st);
 }
 
 int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s) {
@@ -430,11 +427,17 @@ int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s) {
 }
 
 int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s) {
+    return scipnp_c8_add_to_c8s(in_c8, nullptr, out_c8s, n, C, h, w, s);
+}
+
+int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
+                         scipnp_stream_t s) {
     SCIPNP_REQUIRE(in_c8 && out_c8s && n > 0 && C % 8 == 0 && h > 0 && w > 0, "bad arguments");
     SCIPNP_ALIGNED(in_c8); SCIPNP_ALIGNED(out_c8s);
+    if (residual_c8s) SCIPNP_ALIGNED(residual_c8s);
     const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
     hipLaunchKernelGGL(c8_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
-                       (char*)out_c8s, HW, total);
+                       (const char*)residual_c8s, (char*)out_c8s, HW, total);
     return launch_status("c8_to_c8s_kernel");
 }
 

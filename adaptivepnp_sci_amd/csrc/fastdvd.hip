@@ -25,6 +25,23 @@ fastdvd_pack_kernel(const float* __restrict__ frames, float* __restrict__ out, i
     d1[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// same, written in the split-fp16 c8s layout [B][2][2 planes][HW][8 fp16] of conv_split.hip
+__global__ void __launch_bounds__(256)
+fastdvd_pack_c8s_kernel(const float* __restrict__ frames, char* __restrict__ out, int B, size_t HW, float sigma) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (p >= HW) return;
+    const int f0 = (n + B - 1) % B, f2 = (n + 1) % B;
+    const float* a = frames + (size_t)f0 * 3 * HW + p;
+    const float* b = frames + (size_t)n * 3 * HW + p;
+    const float* c = frames + (size_t)f2 * 3 * HW + p;
+    const float g0[8] = {a[0], a[HW], a[2 * HW], sigma, b[0], b[HW], b[2 * HW], sigma};
+    const float g1[8] = {c[0], c[HW], c[2 * HW], sigma, 0.f, 0.f, 0.f, 0.f};
+    char* base = out + (size_t)n * 2 * (2 * HW * 16);
+    split8_store(g0, base + p * 16, base + HW * 16 + p * 16);
+    split8_store(g1, base + 2 * HW * 16 + p * 16, base + 3 * HW * 16 + p * 16);
+}
+
 // out[n][c][p] = center[n][c][p] - x_c8[n][0][p][c]   (c < 3)
 __global__ void __launch_bounds__(256)
 fastdvd_finish_kernel(const float* __restrict__ center, const float* __restrict__ x_c8, float* __restrict__ out,
@@ -170,6 +187,16 @@ int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int 
     hipLaunchKernelGGL(fastdvd_pack_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, frames,
                        out_c8, B, HW, sigma);
     return launch_status("fastdvd_pack_kernel");
+}
+
+int scipnp_fastdvd_pack_triplets_c8s(const float* frames, void* out_c8s, int B, int H, int W, float sigma,
+                                     scipnp_stream_t s) {
+    SCIPNP_REQUIRE(frames && out_c8s && B > 0 && B <= 65535 && H > 0 && W > 0, "bad arguments");
+    SCIPNP_ALIGNED(out_c8s);
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(fastdvd_pack_c8s_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, frames,
+                       (char*)out_c8s, B, HW, sigma);
+    return launch_status("fastdvd_pack_c8s_kernel");
 }
 
 int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,

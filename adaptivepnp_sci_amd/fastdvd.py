@@ -103,9 +103,10 @@ def _strip(sd):
     return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
 
 
-def pack_denblock(sd, prefix, device):
+def pack_denblock(sd, prefix, device, split=False):
     """Packed weights of one DenBlock from a (stripped) state dict; eval-mode BatchNorm folded:
-    y = conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps))."""
+    y = conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps)).  split=True packs for the
+    error-compensated split-fp16 kernels (conv_split.hip)."""
     packed = []
     for key, bn, cin, cout, _relu, _s2, _shuf in _LAYERS:
         w = sd[f'{prefix}.{key}.weight'].detach().float().cpu()
@@ -117,7 +118,10 @@ def pack_denblock(sd, prefix, device):
             mu, var = sd[f'{prefix}.{bn}.running_mean'].float().cpu(), sd[f'{prefix}.{bn}.running_var'].float().cpu()
             scale = g / torch.sqrt(var + _BN_EPS)
             shift = b_ - mu * scale
-        packed.append(ops.pack_conv3x3(w, None, scale, shift, Cin=cin, Cout=cout, device=device))
+        if split:
+            packed.append(ops.pack_conv3x3_split(w, None, Cin=cin, Cout=cout, device=device, bn_scale=scale, bn_shift=shift))
+        else:
+            packed.append(ops.pack_conv3x3(w, None, scale, shift, Cin=cin, Cout=cout, device=device))
     return packed
 
 
@@ -166,22 +170,65 @@ def denblock_forward(pk, frames, sigma, out, b):
     return ops.fastdvd_finish(frames, b['x8'], out)
 
 
+def alloc_denblock_buffers_split(B, H, W, device):
+    """buffers of the split-fp16 DenBlock: c8s activations (float16, same bytes as fp32 c8) plus the two fp32
+    PixelShuffle outputs and the fp32 8-channel tail."""
+    h16 = lambda c, h, w: torch.empty(B, c // 8, 2, h, w, 8, dtype=torch.float16, device=device)  # noqa: E731
+    f32 = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
+    H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+    a = [h16(64, H2, W2) for _ in range(3)]
+    d = [h16(128, H4, W4) for _ in range(3)]
+    return dict(t_in=h16(16, H, W), t96=h16(96, H, W), x0=h16(32, H, W), s32=h16(32, H, W), o32=h16(32, H, W),
+                x8=f32(8, H, W), sh64=f32(64, H2, W2), sh32=f32(32, H, W),
+                a0=a[0], a1=a[1], x1=a[0], d0=d[0], d1=d[1], x2=d[0], u0=d[1], u1=d[2], s64=a[1], c0=a[2], c1=a[1])
+
+
+def denblock_forward_split(pk, frames, sigma, out, b):
+    """denblock_forward on the split-fp16 kernels: c8s activations, the two UpBlock convs write their PixelShuffle-d
+    result in fp32 and one element-wise pass adds the skip tensor and converts back to c8s."""
+    c = ops.conv3x3_c8s
+    ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'])
+    c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
+    c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
+    c(b['x0'], pk[2], 64, relu=True, stride2=True, out=b['a0'])
+    c(b['a0'], pk[3], 64, relu=True, out=b['a1'])
+    c(b['a1'], pk[4], 64, relu=True, out=b['x1'])
+    c(b['x1'], pk[5], 128, relu=True, stride2=True, out=b['d0'])
+    c(b['d0'], pk[6], 128, relu=True, out=b['d1'])
+    c(b['d1'], pk[7], 128, relu=True, out=b['x2'])
+    c(b['x2'], pk[8], 128, relu=True, out=b['u0'])
+    c(b['u0'], pk[9], 128, relu=True, out=b['u1'])
+    c(b['u1'], pk[10], 256, shuffle=True, out=b['sh64'])
+    ops.c8_add_to_c8s(b['sh64'], b['x1'], b['s64'])                 # x1 + upc2(x2)
+    c(b['s64'], pk[11], 64, relu=True, out=b['c0'])
+    c(b['c0'], pk[12], 64, relu=True, out=b['c1'])
+    c(b['c1'], pk[13], 128, shuffle=True, out=b['sh32'])
+    ops.c8_add_to_c8s(b['sh32'], b['x0'], b['s32'])                 # x0 + upc1(.)
+    c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
+    c(b['o32'], pk[15], 8, out=b['x8'], f32_out=True)
+    return ops.fastdvd_finish(frames, b['x8'], out)
+
+
 class FastDVDEngine:
-    def __init__(self, model, B, H, W, device):
+    def __init__(self, model, B, H, W, device, precision=None):
         if H % 4 or W % 4:
             raise ValueError('FastDVDnet needs H and W to be multiples of 4 (the reference reflect-pads otherwise; '
                              'its padding of the noise map breaks for more than one frame, fastdvdnet.py:126)')
+        from .nets import default_precision
         self.B, self.H, self.W, self.device = B, H, W, device
+        self.precision = precision or default_precision()
         self.refresh(model)
-        self.bufs = alloc_denblock_buffers(B, H, W, device, alias=True)
+        self.bufs = (alloc_denblock_buffers_split(B, H, W, device) if self.precision == 'f16x3' else
+                     alloc_denblock_buffers(B, H, W, device, alias=True))
         self.s1 = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
         self.out = torch.empty_like(self.s1)
 
     def refresh(self, model):
         sd = _strip(model.state_dict())
-        self.packed = {p: pack_denblock(sd, p, self.device) for p in ('temp1', 'temp2')}
+        self.packed = {p: pack_denblock(sd, p, self.device, split=self.precision == 'f16x3') for p in ('temp1', 'temp2')}
 
     def forward(self, frames, sigma):
         """frames planar (B,3,H,W) -> denoised planar (B,3,H,W) (owned by the engine, overwritten per call)."""
-        denblock_forward(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
-        return denblock_forward(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)
+        fwd = denblock_forward_split if self.precision == 'f16x3' else denblock_forward
+        fwd(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
+        return fwd(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)

@@ -399,5 +399,5 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
             if trace is not None:
                 trace.append(val)
     tr.write_back()
-    eng.packed = {p: b.fwd for p, b in tr.blocks.items()}
+    eng.refresh(model)            # repack (fp32 or split-fp16) from the updated parameters
     return model

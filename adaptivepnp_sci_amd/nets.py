@@ -53,11 +53,12 @@ def ffdnet_layers(model):
 
 def default_precision():
     """'f16x3' (error-compensated split-fp16 MFMA, csrc/conv_split.hip) or 'f32' (fp32 MFMA, csrc/conv.hip);
-    override with SCIPNP_FFDNET_PRECISION."""
+    override with SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION).  Applies to the FFDNet and FastDVDnet
+    forward passes; the online finetune always runs on the fp32 kernels."""
     import os
-    p = os.environ.get('SCIPNP_FFDNET_PRECISION', 'f16x3')
+    p = os.environ.get('SCIPNP_CONV_PRECISION', os.environ.get('SCIPNP_FFDNET_PRECISION', 'f16x3'))
     if p not in ('f32', 'f16x3'):
-        raise ValueError("SCIPNP_FFDNET_PRECISION must be 'f32' or 'f16x3'")
+        raise ValueError("SCIPNP_CONV_PRECISION must be 'f32' or 'f16x3'")
     return p
 
 

@@ -268,29 +268,48 @@ def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False,
     return out
 
 
-def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None):
-    """OIHW fp32 weights -> packed split-fp16 buffer (uint8 tensor) for scipnp_conv3x3_c8s."""
+def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_scale=None, bn_shift=None):
+    """OIHW fp32 weights (+ optional folded eval-mode BatchNorm) -> packed split-fp16 buffer (uint8 tensor)."""
     w = weight.detach().to('cpu', F32).contiguous()
     co, ci = w.shape[0], w.shape[1]
     Cin = Cin or (ci + 7) // 8 * 8
     Cout = Cout or (co + 7) // 8 * 8
     lib = _lib.load()
     packed = torch.empty(lib.scipnp_conv3x3_split_packed_bytes(Cin, Cout), dtype=torch.uint8)
-    b = None if bias is None else bias.detach().to('cpu', F32).contiguous()
-    _lib.check(lib.scipnp_pack_conv3x3_split(C.c_void_p(w.data_ptr()), C.c_void_p(0 if b is None else b.data_ptr()), ci, co,
-                                             Cin, Cout, C.c_void_p(packed.data_ptr())), 'scipnp_pack_conv3x3_split')
+    keep = [None if t is None else t.detach().to('cpu', F32).contiguous() for t in (bias, bn_scale, bn_shift)]
+    ptr = [C.c_void_p(0 if t is None else t.data_ptr()) for t in keep]
+    _lib.check(lib.scipnp_pack_conv3x3_split_bn(C.c_void_p(w.data_ptr()), ptr[0], ptr[1], ptr[2], ci, co, Cin, Cout,
+                                                C.c_void_p(packed.data_ptr())), 'scipnp_pack_conv3x3_split_bn')
     return packed.to(device) if device is not None else packed
 
 
-def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False):
-    """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s (or fp32 c8 [n][Cout/8][h][w][8] if f32_out)."""
+def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False, stride2=False, shuffle=False):
+    """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s, or fp32 c8 if f32_out / shuffle
+    (shuffle: PixelShuffle(2)-ed fp32 c8 [n][Cout/32][2h][2w][8])."""
     n, cg, _two, h, w, _ = x.shape
+    ho, wo = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if stride2 else (h, w)
     if out is None:
-        out = (torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32) if f32_out else
-               torch.empty(n, Cout // 8, 2, h, w, 8, device=x.device, dtype=torch.float16))
-    flags = (1 if relu else 0) | (32 if f32_out else 0) | (0x100 if head else 0)
+        if shuffle:
+            out = torch.empty(n, Cout // 32, 2 * h, 2 * w, 8, device=x.device, dtype=F32)
+        elif f32_out:
+            out = torch.empty(n, Cout // 8, ho, wo, 8, device=x.device, dtype=F32)
+        else:
+            out = torch.empty(n, Cout // 8, 2, ho, wo, 8, device=x.device, dtype=torch.float16)
+    fp32 = f32_out or shuffle
+    flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
+             (0x100 if head else 0))
     _call('scipnp_conv3x3_c8s', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
-          _p(out, 'out', F32 if f32_out else torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
+          _p(out, 'out', F32 if fp32 else torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
+    return out
+
+
+def c8_add_to_c8s(x, residual_c8s, out=None):
+    """c8s(x_fp32_c8 + residual_c8s)"""
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, cg, 2, h, w, 8, device=x.device, dtype=torch.float16)
+    _call('scipnp_c8_add_to_c8s', _p(x, 'x'), _p(residual_c8s, 'residual', torch.float16), _p(out, 'out', torch.float16),
+          n, cg * 8, h, w, _stream())
     return out
 
 
@@ -319,6 +338,15 @@ def fastdvd_pack_triplets(frames, sigma, out=None):
         out = torch.empty(B, 2, H, W, 8, device=frames.device, dtype=F32)
     _call('scipnp_fastdvd_pack_triplets', _p(frames, 'frames'), _p(out, 'out'), B, H, W, float(np.float32(sigma)),
           _stream())
+    return out
+
+
+def fastdvd_pack_triplets_c8s(frames, sigma, out=None):
+    B, _, H, W = frames.shape
+    if out is None:
+        out = torch.empty(B, 2, 2, H, W, 8, device=frames.device, dtype=torch.float16)
+    _call('scipnp_fastdvd_pack_triplets_c8s', _p(frames, 'frames'), _p(out, 'out', torch.float16), B, H, W,
+          float(np.float32(sigma)), _stream())
     return out
 
 

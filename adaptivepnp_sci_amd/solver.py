@@ -233,9 +233,9 @@ def _run_schedule(run, sigma, iter_max):
     for idx, nsig in enumerate(sigma):
         for _ in range(iter_max[idx]):
             run.step(nsig, last=(run.k == total - 1))
-    if run.denoiser == 'ffdnet_color' and run.eng.precision == 'f16x3' and ops.split_overflow():
-        raise _lib.ScipnpError('FFDNet activations left fp16 range in the split-fp16 convolution path; rerun with '
-                               'SCIPNP_FFDNET_PRECISION=f32 (inputs are expected in [0,1] units like the reference)')
+    if run.denoiser != 'tv' and run.eng.precision == 'f16x3' and ops.split_overflow():
+        raise _lib.ScipnpError('denoiser activations left fp16 range in the split-fp16 convolution path; rerun with '
+                               'SCIPNP_CONV_PRECISION=f32 (inputs are expected in [0,1] units like the reference)')
 
 
 def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, two_stage):

@@ -184,20 +184,26 @@ int scipnp_conv3x3_c8_ex(const float* in, const float* packed_w, float* out, con
 /* ---- error-compensated split-fp16 variant (csrc/conv_split.hip): every fp32 operand v = hi + lo'*2^-11 as two
  * fp16 numbers, three exact fp16 products per fp32 product on v_mfma_f32_32x32x16_f16 (fp32 accumulate).
  * Activations in layout c8s [n][C/8][2][h][w][8] fp16 (hi plane, lo' plane; same bytes as fp32 c8).
- * stride 1, zero pad 1; flags: bit0 ReLU, bit5 (32) = write fp32 c8 instead of c8s (network tail), bit8 head tag.
+ * zero pad 1; flags: bit0 ReLU, bit2 stride 2, bit3 PixelShuffle(2) store (output is then fp32 c8
+ * [n][Cout/32][2h][2w][8]), bit5 (32) = write fp32 c8 instead of c8s (network tails), bit8 head tag.
  * Per-iterate error in the PnP loop <= 3.4e-6 (bar 1e-5); needs |w| < 31.9 and activations inside fp16 range. */
 size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout);
-/* HOST pointers: w OIHW fp32, bias or NULL -> packed split weights */
+/* HOST pointers: w OIHW fp32, bias or NULL -> packed split weights; _bn folds an eval-mode BatchNorm
+ * (w*scale[co], bias*scale + shift) before splitting */
 int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
                               void* packed);
+int scipnp_pack_conv3x3_split_bn(const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
+                                 int Cin_real, int Cout_real, int Cin, int Cout, void* packed);
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout,
                        int h, int w, int flags, scipnp_stream_t s);
 /* range guard of the split format: *flag_out = 1 if any value written to a c8s tensor by these kernels since the last
  * reset was >= 65000 in magnitude or NaN (results invalid: rerun with the fp32 kernels).  SYNCHRONISES the stream;
  * call once per reconstruction. */
 int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s);
-/* fp32 c8 -> c8s */
+/* fp32 c8 -> c8s; _add adds a c8s residual first (skip connections behind a PixelShuffle conv) */
 int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s);
+int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
+                         scipnp_stream_t s);
 
 /* whole FFDNet-colour forward on B frames: 12 (nb) conv layers ping-ponging between two c8 scratch
  * buffers of n*nc*h*w floats each.  in_c8: [B][2][M][N][8] from scipnp_pm_pre_denoise, out_c8:
@@ -251,6 +257,9 @@ int scipnp_bn_fold_grads(const float* W, const float* G, const float* sdy, const
  * -- packages/fastdvdnet/models.py:187 (torch.cat), packages/fastdvdnet/fastdvdnet.py:113-116 */
 int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int H, int W, float sigma,
                                  scipnp_stream_t s);
+/* same in the split-fp16 c8s layout */
+int scipnp_fastdvd_pack_triplets_c8s(const float* frames, void* out_c8s, int B, int H, int W, float sigma,
+                                     scipnp_stream_t s);
 /* DenBlock residual: out[n][c] = center[n][c] - x_c8[n][0][..][c], c < 3  -- models.py:196 (in1 - x) */
 int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,
                           scipnp_stream_t s);

@@ -70,7 +70,9 @@ def test_config1_ffdnet_512x512x8(solver, ffdnet_state_dict, precision, monkeypa
     assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
 
 
-def test_config2_fastdvdnet_512x512x8(solver):
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_config2_fastdvdnet_512x512x8(solver, precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
     """configs[2]: two-stage ADMM + FastDVDnet (5-frame temporal window), 512x512x8, rho = 0.55; 2 iterations."""
     from adaptivepnp_sci_amd import synth
     from oracle import solver as OS

@@ -303,7 +303,9 @@ def test_conv3x3_stride2_and_pixelshuffle(ops):
     assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 1e-6
 
 
-def test_fastdvdnet_forward_vs_reference_golden():
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_fastdvdnet_forward_vs_reference_golden(precision, monkeypatch):
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
     """Synthetic seeded weights (the reference's model.pth is not in the snapshot); circular-window edge frames
     0,1,6,7 included (B = 8); golden produced by the reference's fastdvdnet_denoiser_full_tensor_v2."""
     from adaptivepnp_sci_amd import fastdvdnet_denoiser_full_tensor_v2
@@ -503,3 +505,25 @@ def test_split_overflow_guard(ops):
     assert not ops.split_overflow()
     ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda() + 400.0)), packed, 8)    # 8*30*400 = 96000 > fp16 max
     assert ops.split_overflow() and not ops.split_overflow()       # reported once, then reset
+
+
+def test_conv3x3_split_stride2_shuffle_bn(ops):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 32, 12, 36, generator=g)
+    wt = torch.randn(64, 32, 3, 3, generator=g) * 0.06
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride=2, padding=1) * sc.double()[None, :, None, None] \
+        + sh.double()[None, :, None, None]
+    pk = ops.pack_conv3x3_split(wt, None, Cin=32, Cout=64, device='cuda', bn_scale=sc, bn_shift=sh)
+    xs = ops.c8_to_c8s(ops.to_c8(x.cuda()))
+    got = ops.from_c8(ops.c8s_to_float(ops.conv3x3_c8s(xs, pk, 64, stride2=True))).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 2e-6
+    # 128 output channels (COB = 4), PixelShuffle store in fp32 + skip connection added by c8_add_to_c8s
+    x = torch.randn(1, 64, 10, 33, generator=g)
+    wt = torch.randn(128, 64, 3, 3, generator=g) * 0.04
+    res = torch.randn(1, 32, 20, 66, generator=g)
+    ref = torch.nn.functional.pixel_shuffle(torch.nn.functional.conv2d(x.double(), wt.double(), None, padding=1), 2) + res.double()
+    pk = ops.pack_conv3x3_split(wt, None, Cin=64, Cout=128, device='cuda')
+    sh32 = ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda())), pk, 128, shuffle=True)
+    got = ops.from_c8(ops.c8s_to_float(ops.c8_add_to_c8s(sh32, ops.c8_to_c8s(ops.to_c8(res.cuda()))))).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 2e-6
