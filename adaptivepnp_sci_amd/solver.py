@@ -113,6 +113,7 @@ class AdmmRun:
         self.k = 0
         self.out_rgb = None
         self.profile_events = None       # bench.py: list receiving (start,end) events around the body convs
+        self.phi_events = None           # bench.py: list receiving (start,end) events around the projection launch
         # ---- prior workspaces
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
@@ -132,6 +133,9 @@ class AdmmRun:
     def step(self, nsig, last=False):
         B, M, N = self.B, self.M, self.N
         k = self.k
+        if self.phi_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if self.two_stage:
             inv_rho = 1 / self.rou
             ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 0, inv_rho, self.alpha * self.rou,
@@ -140,6 +144,9 @@ class AdmmRun:
         else:
             ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x)
             coef, sign, which = -1.0, -1.0, 1
+        if self.phi_events is not None:
+            ev[1].record()
+            self.phi_events.append(ev)
         if self.denoiser == 'tv':
             ops.tv_chambolle(self.x.view(4 * B, M, N), self.b.view(4 * B, M, N), coef,
                              self.theta_raw.view(4 * B, M, N), self.plan, 0.1)

@@ -2,7 +2,7 @@
 """Headline benchmark: ADMM iterations/s (and reconstructed frames/s) of the two-stage PnP-ADMM +
 FFDNet-colour solver on a 512x512x8 Bayer cube per GPU (BASELINE.json configs[1]).  The FFDNet convolutions run
 on the error-compensated split-fp16 MFMA kernels by default (per-iterate parity <= 1e-5 verified by the GPU tests);
-SCIPNP_FFDNET_PRECISION=f32 selects the fp32 MFMA kernels.
+SCIPNP_CONV_PRECISION=f32 selects the fp32 MFMA kernels.
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
@@ -13,8 +13,9 @@ rank reconstructs its own cube (weak scaling, no collective inside the solve) an
 mosaics are gathered to rank 0 with ONE RCCL gather at the end of the timed region.
 
 The JSON line also carries
-  roofline     : the dominant kernel (FFDNet body layer conv3x3, fp32 MFMA), FLOP/s measured with
+  roofline     : the dominant kernel (FFDNet body layer conv3x3), ALGORITHMIC FLOP/s measured with
                  HIP events around the body-layer launches inside the timed region;
+  phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch (events inside the timed region);
   cpu_baseline : the CPU oracle (bit-exact restatement of the reference) timed on this host on a
                  bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -146,6 +147,8 @@ def main():
         run.step(SIGMA)
     events = []
     run.profile_events = events
+    phi_events = []
+    run.phi_events = phi_events
     from adaptivepnp_sci_amd import shard
     barrier()
     t0 = time.perf_counter()
@@ -169,6 +172,8 @@ def main():
     body_ms = [a.elapsed_time(b) for a, b in events]
     body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
     psnr = run.psnr_all()
+    phi_s = float(np.median([a.elapsed_time(b) for a, b in phi_events])) / 1e3
+    phi_bytes = 16.0 * H * W * B + 8.0 * H * W        # theta, b, Phi read + x written (4 E) + y, Phi_sum (2 HW)
     precision = run.eng.precision
     if rank == 0:
         iters_per_s = world * args.steps / dt
@@ -199,6 +204,12 @@ def main():
                          'mfma_flop_executed_over_algorithmic': SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0,
                          'matrix_pipe_frac_of_peak': achieved * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) / peak,
                          'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA},
+            # the Phi / Phi^T Phi projection step (north_star: HBM fraction), one launch per iteration, HIP events
+            'phi_step': {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
+                         'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
+                         'achieved': phi_bytes / phi_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': phi_bytes / phi_s / 8e12,
+                         'note': 'event pair around one ~10 us launch includes ~2-3 us of event/launch overhead; rocprofv3 '
+                                 'kernel time is in profiles/'},
             'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -33,7 +33,7 @@ for _ in range(20):
     tv.step(0)
 warm = tv.result_mosaic()
 for prec in ('f32', 'f16x3'):
-    os.environ['SCIPNP_FFDNET_PRECISION'] = prec
+    os.environ['SCIPNP_CONV_PRECISION'] = prec
     net = FFDNet(); net.load_state_dict(sd)
     run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net)
     print(f'FFDNet {prec} 512x512x8: {timeit(run, 25/255, 20):.3f} ms/iteration')
@@ -44,13 +44,15 @@ for prec in ('f32', 'f16x3'):
     print(f'FFDNet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
 from oracle.nets import synth_fastdvdnet_weights
 fnet = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
-run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet)
-print(f'FastDVDnet f32 512x512x8: {timeit(run, 8/255, 5, 1):.3f} ms/iteration')
-run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet, update_=True, lr_=2e-6,
-              update_per_iter=2, inital_iter=0, interval_iter=1)
-run.step(8 / 255); torch.cuda.synchronize()
-t0 = time.perf_counter(); run.step(8 / 255); torch.cuda.synchronize()
-print(f'FastDVDnet iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
+for prec in ('f32', 'f16x3'):
+    os.environ['SCIPNP_CONV_PRECISION'] = prec
+    run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet)
+    print(f'FastDVDnet {prec} 512x512x8: {timeit(run, 8/255, 5, 1):.3f} ms/iteration')
+    run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet, update_=True, lr_=2e-6,
+                  update_per_iter=2, inital_iter=0, interval_iter=1)
+    run.step(8 / 255); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run.step(8 / 255); torch.cuda.synchronize()
+    print(f'FastDVDnet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
 y, Phi, orig = synth.make_problem(256, 256, 16, 0)
 net = FFDNet(); net.load_state_dict(sd)
 run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net)

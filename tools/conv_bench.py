@@ -20,30 +20,12 @@ o8 = torch.empty_like(x8)
 os_ = torch.empty_like(xs)
 variants = {'fp32': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
             'f16x3': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_)}
-import ctypes as C
-from adaptivepnp_sci_amd import _lib
-lib = _lib.load()
-def raw(flags):
-    def f():
-        _lib.check(lib.scipnp_conv3x3_c8s(C.c_void_p(xs.data_ptr()), C.c_void_p(pks.data_ptr()), C.c_void_p(os_.data_ptr()),
-                                          n, c, c, h, w, 1 | flags, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'x')
-    return f
-variants['f16x3 late-fill'] = raw(0x2000)
-variants['f16x3 no-stage'] = raw(0x1000)
-variants['f16x3 no-stage no-barrier'] = raw(0x1000 | 0x4000)
-variants['f16x3 register staging'] = raw(0x20000)
-variants['nostage nopkmul'] = raw(0x1000 | 0x8000)
-variants['nostage noldsread'] = raw(0x1000 | 0x10000)
-variants['nostage nopkmul noldsread'] = raw(0x1000 | 0x18000)
 variants['f16x3']()
 torch.cuda.synchronize()
-ref_out = os_.clone()
 for name, f in variants.items():
     for _ in range(3):
         f()
     torch.cuda.synchronize()
-    if name.startswith('f16x3') and 'no-' not in name:
-        print(f'{name:26s} output identical to default: {bool(torch.equal(os_, ref_out))}')
 torch.cuda.synchronize()
 res = {k: [] for k in variants}
 for r in range(5):
@@ -58,3 +40,28 @@ for r in range(5):
 for k, v in res.items():
     us = sorted(v)[len(v) // 2]
     print(f'{k:26s} median {us:8.1f} us  min {min(v):8.1f} us   {flop / us / 1e6:7.1f} TFLOP/s (algorithmic)')
+
+# FastDVDnet DenBlock layer shapes (512x512 frames): 64 ch at 256x256, 128 ch at 128x128, stride-2 and PixelShuffle layers
+def layer(cin, cout, hh, ww, **kw):
+    xx = ops.c8_to_c8s(ops.to_c8(torch.randn(n, cin, hh, ww, generator=g).cuda()))
+    pp = ops.pack_conv3x3_split(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, None, Cin=cin, Cout=cout, device='cuda')
+    out = ops.conv3x3_c8s(xx, pp, cout, relu=not kw.get('shuffle'), **kw)
+    ho, wo = (hh // 2, ww // 2) if kw.get('stride2') else (hh, ww)
+    return (lambda: ops.conv3x3_c8s(xx, pp, cout, relu=not kw.get('shuffle'), out=out, **kw)), 2.0 * 9 * cin * cout * ho * wo * n
+for name, args, kw in [('96->32 512^2', (96, 32, 512, 512), {}), ('32->64 s2 512^2', (32, 64, 512, 512), dict(stride2=True)),
+                       ('64->64 256^2', (64, 64, 256, 256), {}), ('64->128 s2 256^2', (64, 128, 256, 256), dict(stride2=True)),
+                       ('128->128 128^2', (128, 128, 128, 128), {}), ('128->256 shuf 128^2', (128, 256, 128, 128), dict(shuffle=True)),
+                       ('64->128 shuf 256^2', (64, 128, 256, 256), dict(shuffle=True)), ('32->32 512^2', (32, 32, 512, 512), {})]:
+    f, fl = layer(*args, **kw)
+    for _ in range(3):
+        f()
+    ts = []
+    for r in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+    us = sorted(ts)[2]
+    print(f'f16x3 {name:22s} median {us:8.1f} us   {fl / us / 1e6:7.1f} TFLOP/s (algorithmic)')
