@@ -9,7 +9,8 @@ raises if the library or the device is missing (there is no CPU fallback).
 """
 from .solver import (admm_denoise, admm_denoise_bayer_demosaic_pre, gap_denoise,  # noqa: F401
                      twoStageAdmm_denoise_bayer)
-from .denoisers import fastdvdnet_denoiser_full_tensor_v2, ffdnet_rgb_denoise_full_tensor  # noqa: F401
+from .denoisers import fastdvdnet_denoiser_full_tensor_v2, ffdnet_rgb_denoise_full_tensor, test_ddnet  # noqa: F401
+from .ddnet import DDnet  # noqa: F401
 from .fastdvd import FastDVDnet  # noqa: F401
 from .nets import FFDNet  # noqa: F401
 

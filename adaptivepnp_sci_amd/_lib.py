@@ -74,6 +74,12 @@ SIGNATURES = {
     'scipnp_fastdvd_pack_triplets_c8s': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_pm_pre_rgb': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _flt, _flt, _vp]),
+    'scipnp_pm_ddnet_inputs': (_int, [_vp, _vp, _flt, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_ddnet_gather': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_ddnet_finish': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_bilinear_up2_c8': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_ddnet_mix': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
 }
 

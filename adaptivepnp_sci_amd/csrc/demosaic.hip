@@ -171,6 +171,28 @@ pm_pre_closed_form_kernel(const float* __restrict__ x, const float* __restrict__
     emit_pre_outputs(rgb, w, x_rgb, rgb_w, net_in, net_in_s, M, N, m, n, t, inv_tau, sigma);
 }
 
+// x_rgb produced elsewhere (deep demosaicking, reference :192-194 / :242-244): only the `x_rgb - w/tau` fusion and
+// the denoiser-input layouts of the two kernels above
+__global__ void __launch_bounds__(256)
+pm_pre_rgb_kernel(const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
+                  float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N, int B, float inv_tau, float sigma) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    const int t = blockIdx.z;
+    if (n >= N) return;
+    const int W = 2 * N;
+    const size_t HW = (size_t)4 * M * N;
+    float rgb[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float2 q = *(const float2*)(x_rgb + ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n);
+            rgb[c][dy][0] = q.x; rgb[c][dy][1] = q.y;
+        }
+    emit_pre_outputs(rgb, w, x_rgb, rgb_w, net_in, net_in_s, M, N, m, n, t, inv_tau, sigma);
+}
+
 constexpr int POST_THREADS = 256;
 
 __global__ void __launch_bounds__(POST_THREADS)
@@ -290,6 +312,22 @@ int scipnp_pm_pre_closed_form(const float* x, const float* b, const float* w, co
     hipLaunchKernelGGL(pm_pre_closed_form_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, out_prev, x_rgb, rgb_w,
                        net_in_c8, (char*)net_in_c8s, M, N, B, rho, tau, inv_tau, clip, sigma);
     return launch_status("pm_pre_closed_form_kernel");
+}
+
+int scipnp_pm_pre_rgb(const float* w, float* x_rgb, float* rgb_w, float* net_in_c8, void* net_in_c8s, int M, int N, int B,
+                      float inv_tau, float sigma, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x_rgb && (rgb_w || net_in_c8 || net_in_c8s), "null pointer");
+    SCIPNP_REQUIRE(M >= 1 && N >= 1 && B > 0 && B <= 65535 && M <= 65535, "bad shape M=%d N=%d B=%d", M, N, B);
+    SCIPNP_ALIGNED(x_rgb);
+    if (w) SCIPNP_ALIGNED(w);
+    if (rgb_w) SCIPNP_ALIGNED(rgb_w);
+    if (net_in_c8) SCIPNP_ALIGNED(net_in_c8);
+    if (net_in_c8s) SCIPNP_ALIGNED(net_in_c8s);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    hipLaunchKernelGGL(pm_pre_rgb_kernel, grid, dim3(threads), 0, (hipStream_t)s, w, x_rgb, rgb_w, net_in_c8,
+                       (char*)net_in_c8s, M, N, B, inv_tau, sigma);
+    return launch_status("pm_pre_rgb_kernel");
 }
 
 int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out_rgb_store, float* x,

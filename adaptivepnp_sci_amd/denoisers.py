@@ -2,6 +2,7 @@
 
 ffdnet_rgb_denoise_full_tensor      <- packages/ffdnet/test_ffdnet_ipol.py:240-359
 fastdvdnet_denoiser_full_tensor_v2  <- packages/fastdvdnet/test_fastdvdnet.py:325-500
+test_ddnet                          <- packages/DDnet/DDnet_test.py:218-321 (deep demosaicking)
 
 Both take / return the reference's (H, W, 3, B) colour cube as a CUDA(ROCm) tensor.  The solver
 itself does not go through these wrappers (it keeps everything plane-major and fuses the layout
@@ -86,3 +87,24 @@ def fastdvdnet_denoiser_full_tensor_v2(vnoisy, sigma, y_bayer=None, Phi=None, mo
         fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter)
         return ops.rgb_to_cube(eng.forward(frames, sigma)), model
     return ops.rgb_to_cube(eng.forward(frames, sigma))
+
+
+def test_ddnet(vnoisy, yall=None, Phiall=None, model=None, useGPU=True, args=None, gray=False):
+    """Deep demosaicking plug-in: vnoisy (H,W,3,B) CUDA tensor holding the mosaic at its CFA sites (`oneCh2ThreeCh`)
+    -> demosaicked (H,W,3,B).  The network only sees the channel sum (network_demosaicking.py:425-429), i.e. the
+    mosaic.  `args` with dm_update (online finetune of the demosaicker) is never passed by the solver and is not
+    supported."""
+    from .ddnet import DDnetEngine
+    if gray or (args is not None and getattr(args, 'dm_update', False)):
+        raise NotImplementedError('grayscale / online-finetuned DDnet is outside the hot path (the solver never uses it)')
+    H, W, _, B = vnoisy.shape
+    mosaic3 = vnoisy.float().sum(dim=2).contiguous()                       # (H,W,B): one non-zero term per pixel
+    planes = ops.mosaic_to_state(mosaic3)
+    mosaic = torch.empty(B, H, W, dtype=torch.float32, device=vnoisy.device)
+    ops.pm_ddnet_inputs(planes, None, 0.0, torch.empty_like(planes), mosaic)
+    eng = DDnetEngine(model, B, H, W, vnoisy.device)
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=vnoisy.device)
+    return ops.rgb_to_cube(eng.forward(planes, mosaic, out))
+
+
+test_ddnet.__test__ = False        # not a pytest test (the name is the reference's)

@@ -183,6 +183,14 @@ def pm_pre_closed_form(x, b, w, out_prev, x_rgb, rgb_w, net_in_c8, rho, tau, cli
           float(np.float32(sigma)), _stream())
 
 
+def pm_pre_rgb(w, x_rgb, rgb_w, net_in_c8, inv_tau, sigma, net_in_c8s=None):
+    """x_rgb (B,3,H,W) given (deep demosaicking): rgb_w = x_rgb - inv_tau*w and/or the FFDNet input layouts."""
+    B, _, H, W = x_rgb.shape
+    _call('scipnp_pm_pre_rgb', _p(w, 'w'), _p(x_rgb, 'x_rgb'), _p(rgb_w, 'rgb_w'), _p(net_in_c8, 'net_in_c8'),
+          _p(net_in_c8s, 'net_in_c8s', torch.float16), H // 2, W // 2, B, float(np.float32(inv_tau)),
+          float(np.float32(sigma)), _stream())
+
+
 def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first_iter_alias, orig=None,
                     sse_part=None):
     B, _, M, N = x.shape
@@ -355,6 +363,44 @@ def fastdvd_finish(center, x_c8, out=None):
     if out is None:
         out = torch.empty_like(center)
     _call('scipnp_fastdvd_finish', _p(center, 'center'), _p(x_c8, 'x_c8'), _p(out, 'out'), B, H, W, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ DDnet glue (csrc/ddnet.hip)
+def pm_ddnet_inputs(x, b, coef, planes, mosaic):
+    B, _, M, N = x.shape
+    _call('scipnp_pm_ddnet_inputs', _p(x, 'x'), _p(b, 'b'), float(np.float32(coef)), _p(planes, 'planes'),
+          _p(mosaic, 'mosaic'), M, N, B, _stream())
+
+
+def ddnet_gather(src, idx, scale, out, C_, h, w):
+    """out: fp32 c8 or float16 c8s tensor [E][G][...]; idx int32 [E][3]; scale float32 [E][3][C] or None."""
+    E = idx.shape[0]
+    split = out.dtype == torch.float16
+    _call('scipnp_ddnet_gather', _p(src, 'src'), _p(idx, 'idx', torch.int32), _p(scale, 'scale'),
+          _p(None if split else out, 'out'), _p(out if split else None, 'out', torch.float16), E, C_, h, w, _stream())
+    return out
+
+
+def ddnet_finish(src, idx, scale, x_c8, out, C_, Cout, h, w):
+    E = x_c8.shape[0]
+    _call('scipnp_ddnet_finish', _p(src, 'src'), _p(idx, 'idx', torch.int32), _p(scale, 'scale'), _p(x_c8, 'x_c8'),
+          _p(out, 'out'), E, C_, Cout, h, w, _stream())
+    return out
+
+
+def bilinear_up2_c8(planar, out):
+    """planar [E][4][h][w] -> out c8 [E][1][2h][2w][8] (float32) or c8s [E][1][2][2h][2w][8] (float16)."""
+    E, _, h, w = planar.shape
+    split = out.dtype == torch.float16
+    _call('scipnp_bilinear_up2_c8', _p(planar, 'planar'), _p(None if split else out, 'out'),
+          _p(out if split else None, 'out', torch.float16), E, h, w, _stream())
+    return out
+
+
+def ddnet_mix(branches, gates, out):
+    B, _, H, W = out.shape
+    _call('scipnp_ddnet_mix', _p(branches, 'branches'), _p(gates, 'gates'), _p(out, 'out'), B, H, W, _stream())
     return out
 
 

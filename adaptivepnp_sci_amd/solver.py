@@ -66,7 +66,7 @@ class AdmmRun:
 
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
-                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False):
+                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None):
         if denoiser not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         _lib.load()
@@ -128,6 +128,14 @@ class AdmmRun:
                 from .fastdvd import FastDVDEngine
                 self.eng = FastDVDEngine(model, B, H, W, self.device)
                 self.rgb_w = torch.empty_like(self.x_rgb)
+            self.dd = None
+            if model_demosaic is not None:       # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
+                if not two_stage:
+                    raise ValueError('model_demosaic is an argument of the two-stage solver only (as in the reference)')
+                from .ddnet import DDnetEngine
+                self.dd = DDnetEngine(model_demosaic, B, H, W, self.device)
+                self.dd_planes = torch.empty_like(x0)
+                self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
 
     # ------------------------------------------------------------------ one ADMM iteration
     def step(self, nsig, last=False):
@@ -177,6 +185,9 @@ class AdmmRun:
             if closed:
                 ops.pm_pre_closed_form(self.x, self.b, w, self.out_store, self.x_rgb, None, c8, self.rou, self.tau, True,
                                        nsig, net_in_c8s=c8s)
+            elif self.dd is not None:
+                self._deep_demosaic(b_in, inv_rho)
+                ops.pm_pre_rgb(w, self.x_rgb, None, c8, inv_tau, nsig, net_in_c8s=c8s)
             else:
                 ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s)
             if gate:
@@ -190,6 +201,9 @@ class AdmmRun:
             if closed:
                 ops.pm_pre_closed_form(self.x, self.b, w, self.eng.out, self.x_rgb, self.rgb_w, None, self.rou, self.tau,
                                        False, nsig)
+            elif self.dd is not None:
+                self._deep_demosaic(b_in, inv_rho)
+                ops.pm_pre_rgb(w, self.x_rgb, self.rgb_w, None, inv_tau, nsig)
             else:
                 ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, self.rgb_w if self.two_stage else None, None,
                                    inv_rho, inv_tau, nsig)
@@ -210,6 +224,11 @@ class AdmmRun:
                 ops.sse_partials(self.orig, self.x, self._new_sse(ops.sse_nblocks(self.x.numel())))
         if last:
             self.out_rgb = self.out_store if src_c8 is not None else src_rgb
+
+    def _deep_demosaic(self, b_in, inv_rho):
+        """x_rgb = DDnet(mosaic of x + b/rho)  (reference :168-171, :192-194)"""
+        ops.pm_ddnet_inputs(self.x, b_in, inv_rho, self.dd_planes, self.dd_mosaic)
+        self.dd.forward(self.dd_planes, self.dd_mosaic, self.x_rgb)
 
     # ------------------------------------------------------------------ reporting
     def _new_sse(self, nblocks):
@@ -276,7 +295,7 @@ def _check_demosaic(denoiser, demosaic_method, model_demosaic=None):
     if denoiser == 'tv':
         return
     if model_demosaic is not None:
-        raise NotImplementedError('deep demosaicking (DDnet) is a "next" row of the scope table; pass model_demosaic=None')
+        return                                  # deep demosaicking: demosaic_method is not consulted (reference :185/:192)
     if demosaic_method != 'malvar2004':
         raise ValueError("demosaic_method must be 'malvar2004' (the reference's other branches are dead code)")
 
@@ -297,7 +316,7 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     run = AdmmRun(y_bayer, Phi_bayer, denoiser, True, x0_bayer, X_orig, model_denoise, show_iqa, lr_=lr_,
                   inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
                   update_per_iter=update_per_iter, update_times=update_times, logf=logf,
-                  close_form_demosaic=close_form_demosaic)
+                  close_form_demosaic=close_form_demosaic, model_demosaic=model_demosaic)
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
     _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True)

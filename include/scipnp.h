@@ -134,6 +134,11 @@ int scipnp_pm_pre_closed_form(const float* x, const float* b, const float* w, co
                               float* x_rgb, float* rgb_w, float* net_in_c8, void* net_in_c8s, int M, int N, int B,
                               float rho, float tau, float inv_tau, int clip, float sigma, scipnp_stream_t s);
 
+/* x_rgb already holds the demosaicked frames (deep demosaicking, dvp...:192-194 / :242-244): form x_rgb - inv_tau*w
+ * (dvp...:198 / :246) and emit it as planar rgb_w and/or the FFDNet input layouts (c8 with sigma map, c8s). */
+int scipnp_pm_pre_rgb(const float* w, float* x_rgb, float* rgb_w, float* net_in_c8, void* net_in_c8s, int M, int N,
+                      int B, float inv_tau, float sigma, scipnp_stream_t s);
+
 /* post-denoiser fusion: theta_raw = denoised RGB sampled at the CFA sites, theta = clip(theta_raw),
  * b += x_eff - theta with x_eff = theta_raw when first_iter_alias (the reference's k = 0 tensor
  * aliasing, SURVEY 3.2: x and theta are one tensor, so x is overwritten with theta_raw too) else x;
@@ -279,6 +284,34 @@ int scipnp_fastdvd_finish_bwd(const float* dout, float* dx_c8, int B, int H, int
 /* gradient w.r.t. the planar frames behind scipnp_fastdvd_pack_triplets, plus `extra` (may be NULL) */
 int scipnp_fastdvd_unpack_bwd(const float* dtin_c8, const float* extra, float* dframes, int B, int H, int W,
                               scipnp_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * DDnet deep demosaicking -- glue around scipnp_conv3x3_c8 / _c8s.
+ * reference: models/network_demosaicking.py:381-463 (DDnet.forward), :186-244, :310-379 (DenBlocks),
+ *            packages/DDnet/DDnet_test.py:166-216 (circular 5-frame window), dvp...:192-194, :242-244 (call sites)
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* v = x + coef*b of the plane-major state -> Bayer planes [B][4][M][N] and mosaic [B][2M][2N] (dvp...:168-171) */
+int scipnp_pm_ddnet_inputs(const float* x, const float* b, float coef, float* planes, float* mosaic, int M, int N,
+                           int B, scipnp_stream_t s);
+
+/* DenBlock input of E evaluations: out[e] = cat_i( src[idx[e][i]] * scale[e][i] ), i = 0..2, src planar [F][C][h*w]
+ * (C = 1, 3, 4), idx int32 [E][3] and scale float [E][3][C] in device memory (scale NULL = no multiply), zero-padded
+ * to 8*ceil(3C/8) channels, written as fp32 c8 and/or c8s.  -- network_demosaicking.py:441-449 + torch.cat :228 */
+int scipnp_ddnet_gather(const float* src, const int* idx, const float* scale, float* out_c8, void* out_c8s, int E,
+                        int C, int h, int w, scipnp_stream_t s);
+
+/* DenBlock residual `x = in1 + x` (network_demosaicking.py:241, :374): out planar [E][Cout][h*w] =
+ * src[idx[e][1]][c or 0]*scale[e][1][.] + x_c8[e][.][c]; src NULL = plain c8 -> planar copy. */
+int scipnp_ddnet_finish(const float* src, const int* idx, const float* scale, const float* x_c8, float* out, int E,
+                        int C, int Cout, int h, int w, scipnp_stream_t s);
+
+/* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True) of planar [E][4][h][w] into the 8-channel c8 / c8s
+ * input of the fusion block at [E][1][2h][2w]  -- network_demosaicking.py:375 */
+int scipnp_bilinear_up2_c8(const float* in, float* out_c8, void* out_c8s, int E, int h, int w, scipnp_stream_t s);
+
+/* x_out = gates[0][c]*branches[n] + gates[1][c]*branches[B+n], planar [2B][3][H*W] -> [B][3][H*W]  -- :461 */
+int scipnp_ddnet_mix(const float* branches, const float* gates, float* out, int B, int H, int W, scipnp_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -129,3 +129,20 @@ def fastdvdnet_pass(vnoisy, sigma, y_planes=None, Phi_planes=None, model=None, l
         planes = ops.bayer_split(_rgb_cube_to_mosaic(out))
         trace.append(float(mse(torch.sum(planes * Phi_planes, dim=2), y_planes)))
     return out, model
+
+
+def ddnet_pass(x_bayer_3ch, model):
+    """Deep demosaicking of a (H,W,3,B) CFA-site cube (`oneCh2ThreeCh` of the mosaic): sliding 5-frame window with
+    circular temporal indexing, reflect-pad to multiples of 4, no finetune on this call path (the solver passes no
+    `args`).  reference packages/DDnet/DDnet_test.py:166-216 (ddnet_seqdenoise), :218-321 (test_ddnet)."""
+    model.eval()
+    seq = x_bayer_3ch.permute(3, 2, 0, 1)
+    N, C, H, W = seq.shape
+    out = torch.empty((N, C, H, W))
+    wpad, hpad = (-W) % 4, (-H) % 4
+    with torch.no_grad():
+        for n in range(N):
+            idx = (torch.arange(n, n + NUM_IN_FR_EXT) - 2) % N
+            win = F.pad(seq[idx].reshape((1, -1, H, W)), (0, wpad, 0, hpad), mode='reflect')
+            out[n] = model(win)[:, :, :H, :W]
+    return out.permute(2, 3, 1, 0)

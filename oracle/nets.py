@@ -122,3 +122,101 @@ def synth_fastdvdnet_weights(seed=0):
             sd[k] = 0.05 * torch.randn(v.shape, generator=g)
     net.load_state_dict(sd)
     return net
+
+
+# ----------------------------------------------------------------------------- DDnet (deep demosaicking)
+def _cr(cin, cout, stride=1, groups=1):
+    return [nn.Conv2d(cin, cout, 3, stride=stride, padding=1, groups=groups, bias=False), nn.ReLU(inplace=True)]
+
+
+class OracleDDDenBlock(nn.Module):
+    """DenBlock of the demosaicking network: the FastDVDnet U-Net without BatchNorm, base width 20, residual ADDED
+    (reference models/network_demosaicking.py:186-244; 4-channel Bayer variant :310-379 when `bayer4`).  The
+    unused `inc` block (noise-map input) is kept so that state-dict keys match the reference."""
+    BASE = 20
+
+    def __init__(self, num_input_frames=3, ch_each_frame=3, bayer4=False):
+        super().__init__()
+        f, c0 = num_input_frames, self.BASE
+        c1, c2 = 2 * c0, 4 * c0
+        self.inc = _Wrap(*_cr(f * 4, f * 30, groups=f), *_cr(f * 30, c0))
+        self.inc_1 = _Wrap(*_cr(f * ch_each_frame, f * 30, groups=f), *_cr(f * 30, c0))
+        self.downc0 = _Wrap(*_cr(c0, c1, stride=2), _Wrap(*_cr(c1, c1), *_cr(c1, c1)))
+        self.downc1 = _Wrap(*_cr(c1, c2, stride=2), _Wrap(*_cr(c2, c2), *_cr(c2, c2)))
+        self.upc2 = _Wrap(_Wrap(*_cr(c2, c2), *_cr(c2, c2)), nn.Conv2d(c2, c1 * 4, 3, padding=1, bias=False),
+                          nn.PixelShuffle(2))
+        self.upc1 = _Wrap(_Wrap(*_cr(c1, c1), *_cr(c1, c1)), nn.Conv2d(c1, c0 * 4, 3, padding=1, bias=False),
+                          nn.PixelShuffle(2))
+        self.bayer4 = bayer4
+        self.outc = _Wrap(*_cr(c0, c0), nn.Conv2d(c0, 4 if bayer4 else 3, 3, padding=1, bias=False))
+        if bayer4:
+            self.upscale = nn.UpsamplingBilinear2d(scale_factor=2)
+            self.fusion = _Wrap(*_cr(4, 4), nn.Conv2d(4, 3, 3, padding=1, bias=False))
+
+    def forward(self, in0, in1, in2):
+        x0 = self.inc_1(torch.cat((in0, in1, in2), dim=1))
+        x1 = self.downc0(x0)
+        x2 = self.downc1(x1)
+        x2 = self.upc2(x2)
+        x1 = self.upc1(x1 + x2)
+        x = in1 + self.outc(x0 + x1)
+        if self.bayer4:
+            x = self.fusion(self.upscale(x))
+        return x
+
+
+class OracleDDnet(nn.Module):
+    """reference models/network_demosaicking.py:381-463: per output frame, three mosaic-domain DenBlocks (temp1) and
+    three Bayer-plane DenBlocks at half resolution (temp11, bilinear x2 + fusion), each on learnable-scalar-weighted
+    frame triplets, then the shared second stage (temp2) on both triples, mixed by weight_tensor_out."""
+
+    def __init__(self, num_input_frames=5):
+        super().__init__()
+        self.num_input_frames = num_input_frames
+        self.temp1 = OracleDDDenBlock(3, 1)
+        self.temp2 = OracleDDDenBlock(3, 3)
+        self.temp11 = OracleDDDenBlock(3, 4, bayer4=True)
+        self.weight_tensor_in = nn.Parameter(torch.ones((9, 1, 1, 1, 1)))
+        self.weight_tensor_in2 = nn.Parameter(torch.ones((9, 1, 4, 1, 1)))
+        self.weight_tensor_out = nn.Parameter(torch.ones((2, 1, 3, 1, 1)))
+
+    def forward(self, x, noise_map=None):
+        from .sci_ops import bayer_split
+        a, a2, a3 = self.weight_tensor_in, self.weight_tensor_in2, self.weight_tensor_out
+        fr = [torch.sum(x[:, 3 * m:3 * m + 3], dim=1) for m in range(self.num_input_frames)]      # (N,H,W) mosaics
+        four = [bayer_split(f.permute(1, 2, 0)).permute(2, 3, 0, 1) for f in fr]                    # (N,4,H/2,W/2)
+        one = [f.unsqueeze(1) for f in fr]
+        s1 = [self.temp1(one[j] * a[3 * j], one[j + 1] * a[3 * j + 1], one[j + 2] * a[3 * j + 2]) for j in range(3)]
+        s1b = [self.temp11(four[j] * a2[3 * j], four[j + 1] * a2[3 * j + 1], four[j + 2] * a2[3 * j + 2])
+               for j in range(3)]
+        return a3[0] * self.temp2(*s1) + a3[1] * self.temp2(*s1b)
+
+
+def synth_ddnet_weights(seed=0):
+    """Seeded synthetic DDnet weights (the reference's checkpoint is not in the snapshot): Kaiming-normal convs, the
+    last conv of each DenBlock scaled down so that the residual stays small, and NON-trivial learnable gate scalars
+    (the checkpoint initialises them to 1) so that every weight_tensor_* entry is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    net = OracleDDnet()
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if v.dim() == 4:
+            fan_in = v.shape[1] * 9
+            last = 0.05 if k.endswith('outc.convblock.2.weight') else 1.0
+            sd[k] = torch.randn(v.shape, generator=g) * (last * (2.0 / fan_in) ** 0.5)
+        elif k == 'weight_tensor_out':
+            sd[k] = 0.5 + 0.05 * torch.randn(v.shape, generator=g)           # the two branches are averaged
+        else:
+            sd[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+    # the fusion block is not residual: give it "identity, then (R, (G1+G2)/2, B)" centre taps plus noise so that the
+    # Bayer-plane branch behaves like a (crude) demosaicker and the PnP loop stays in a meaningful regime
+    f0, f2 = sd['temp11.fusion.convblock.0.weight'] * 0.1, sd['temp11.fusion.convblock.2.weight'] * 0.1
+    for c in range(4):
+        f0[c, c, 1, 1] += 1.0
+    f2[0, 0, 1, 1] += 1.0
+    f2[1, 1, 1, 1] += 0.5
+    f2[1, 2, 1, 1] += 0.5
+    f2[2, 3, 1, 1] += 1.0
+    sd['temp11.fusion.convblock.0.weight'], sd['temp11.fusion.convblock.2.weight'] = f0, f2
+    net.load_state_dict(sd)
+    return net

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import sci_ops as ops
-from .denoisers import fastdvdnet_pass, ffdnet_pass
+from .denoisers import ddnet_pass, fastdvdnet_pass, ffdnet_pass
 from .malvar import malvar_demosaic_cube
 from .tv_chambolle import tv_chambolle_multichannel
 
@@ -47,7 +47,7 @@ def _tv(planes_in):
 def two_stage_admm(y_bayer, Phi_bayer, denoiser='tv', iter_max=50, sigma=None, x0_bayer=None,
                    X_orig=None, model_denoise=None, lr=1e-6, inital_iter=1, interval_iter=5,
                    update=False, update_per_iter=1, update_times=-1, finetune_trace=None,
-                   denoiser_io=None, close_form_demosaic=False):
+                   denoiser_io=None, close_form_demosaic=False, model_demosaic=None):
     """Returns dict(theta_iterates=[(H,W,B) np], psnr_all, x_bayer, rgb (CNN branches), model)."""
     y_bayer = torch.as_tensor(y_bayer)
     Phi_bayer = torch.as_tensor(Phi_bayer)
@@ -86,9 +86,12 @@ def two_stage_admm(y_bayer, Phi_bayer, denoiser='tv', iter_max=50, sigma=None, x
                     x_rgb = (rho * ops.four_to_three_channel(x) + ops.four_to_three_channel(b) + tau * rgb_out + w) / inv_3ch
                     if denoiser == 'ffdnet_color':
                         x_rgb = x_rgb.clip(0, 1)
-                else:
+                elif model_demosaic is None:
                     mosaic = ops.bayer_merge(x + (1 / rho) * b)
                     x_rgb = malvar_demosaic_cube(mosaic)
+                else:
+                    # deep demosaicking (reference :192-194 / :242-244)
+                    x_rgb = ddnet_pass(ops.one_to_three_channel(ops.bayer_merge(x + (1 / rho) * b)), model_demosaic)
                 x_rgb_w = x_rgb - (1 / tau) * w
                 gate = update and k > inital_iter and k % interval_iter == 0
                 if denoiser == 'ffdnet_color':

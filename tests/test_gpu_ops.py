@@ -527,3 +527,52 @@ def test_conv3x3_split_stride2_shuffle_bn(ops):
     sh32 = ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda())), pk, 128, shuffle=True)
     got = ops.from_c8(ops.c8s_to_float(ops.c8_add_to_c8s(sh32, ops.c8_to_c8s(ops.to_c8(res.cuda()))))).cpu()
     assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 2e-6
+
+
+# ------------------------------------------------------------------ DDnet (deep demosaicking) glue and forward
+def test_ddnet_glue_kernels_vs_torch(ops):
+    g = torch.Generator().manual_seed(5)
+    F_, C_, h, w, E = 5, 4, 10, 14, 7
+    src = torch.randn(F_, C_, h, w, generator=g).cuda()
+    idx = torch.randint(0, F_, (E, 3), generator=g).to(torch.int32).cuda()
+    scale = (1 + 0.1 * torch.randn(E, 3, C_, generator=g)).cuda()
+    ref = torch.stack([torch.cat([src[idx[e, i]] * scale[e, i][:, None, None] for i in range(3)]) for e in range(E)])
+    out = torch.empty(E, 2, h, w, 8, device='cuda')
+    ops.ddnet_gather(src, idx, scale, out, C_, h, w)
+    got = ops.from_c8(out)
+    assert torch.equal(got[:, :12], ref) and not got[:, 12:].any()
+    outs = torch.empty(E, 2, 2, h, w, 8, dtype=torch.float16, device='cuda')
+    ops.ddnet_gather(src, idx, scale, outs, C_, h, w)
+    assert rel_l2(ops.from_c8(ops.c8s_to_float(outs))[:, :12].cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    # finish: in1 + x, with the one-channel centre frame broadcast over three outputs
+    src1 = torch.randn(F_, 1, h, w, generator=g).cuda()
+    sc1 = (1 + 0.1 * torch.randn(E, 3, 1, generator=g)).cuda()
+    x8 = torch.randn(E, 1, h, w, 8, generator=g).cuda()
+    fin = ops.ddnet_finish(src1, idx, sc1, x8, torch.empty(E, 3, h, w, device='cuda'), 1, 3, h, w)
+    ref = torch.stack([src1[idx[e, 1]] * sc1[e, 1, 0] + ops.from_c8(x8)[e, :3] for e in range(E)])
+    assert torch.equal(fin, ref)
+    # bilinear x2, align_corners=True
+    p4 = torch.randn(E, 4, h, w, generator=g).cuda()
+    up = ops.from_c8(ops.bilinear_up2_c8(p4, torch.empty(E, 1, 2 * h, 2 * w, 8, device='cuda')))
+    ref = torch.nn.functional.interpolate(p4.cpu(), scale_factor=2, mode='bilinear', align_corners=True)
+    assert rel_l2(up[:, :4].cpu().numpy(), ref.numpy()) < 1e-6 and not up[:, 4:].any()
+    # mix
+    br = torch.randn(6, 3, h, w, generator=g).cuda()
+    gates = torch.randn(2, 3, generator=g).cuda()
+    mix = ops.ddnet_mix(br, gates, torch.empty(3, 3, h, w, device='cuda'))
+    assert torch.equal(mix, gates[0][None, :, None, None] * br[:3] + gates[1][None, :, None, None] * br[3:])
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_ddnet_forward_vs_reference_golden(precision, monkeypatch):
+    """all frames of a 32x48x8 cube through the three-branch demosaicker; golden produced by the reference's
+    test_ddnet on the same synthetic weights (non-trivial gate scalars)."""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from adaptivepnp_sci_amd import test_ddnet as ddnet_plugin
+    from oracle.nets import synth_ddnet_weights
+    from oracle.sci_ops import one_to_three_channel
+    g = load_gold('ddnet_forward')
+    net = torch.nn.DataParallel(synth_ddnet_weights(0))
+    out = ddnet_plugin(dev(one_to_three_channel(torch.from_numpy(g['mosaic']))), None, None, net)
+    err = rel_l2(out.cpu().numpy(), g['out'])
+    assert err <= 2e-6, err

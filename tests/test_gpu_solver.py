@@ -277,3 +277,32 @@ def test_closed_form_demosaic_branch(solver, ffdnet_state_dict):
     for k in range(3):
         assert rel_l2(tr.it[k], g['theta_fastdvd'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_fastdvd'][k]))
     assert rel_l2(res[0], g['rgb_fastdvd']) <= REL_TOL
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_deep_demosaicking_iterates(solver, ffdnet_state_dict, precision, monkeypatch):
+    """model_demosaic=DDnet (reference :192-194 / :242-244) with both CNN denoisers, per-iterate
+    parity against the reference run captured in the golden file (synthetic DDnet / FastDVDnet weights)."""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from oracle.nets import synth_ddnet_weights, synth_fastdvdnet_weights
+    g = load_gold('ddnetadmm_64x64x8')
+    dd = torch.nn.DataParallel(synth_ddnet_weights(0))
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'ffdnet_color', [2, 2], False, [25 / 255, 12 / 255],
+                                            x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=make_ffdnet(ffdnet_state_dict),
+                                            model_demosaic=dd, show_iqa=True, logf=io.StringIO())
+    for k in range(4):
+        assert rel_l2(tr.it[k], g['theta_ffdnet'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_ffdnet'][k]))
+    assert rel_l2(res[0], g['rgb_ffdnet']) <= REL_TOL
+    assert np.abs(np.array(res[4]) - g['psnr_ffdnet']).max() <= PSNR_TOL
+    assert res[6] is dd
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    fd = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
+                                            x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=fd, model_demosaic=dd,
+                                            show_iqa=True, logf=io.StringIO())
+    for k in range(3):
+        assert rel_l2(tr.it[k], g['theta_fastdvd'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_fastdvd'][k]))
+    assert rel_l2(res[0], g['rgb_fastdvd']) <= REL_TOL

@@ -148,6 +148,25 @@ def test_fastdvdnet_forward_golden():
     assert rel_l2(out, g['out']) == 0
 
 
+def test_ddnet_forward_golden():
+    """deep demosaicking: oracle DDnet vs the output of the reference's test_ddnet (synthetic weights, B = 8 so that
+    the circular-window edge frames are covered)"""
+    g = load_gold('ddnet_forward')
+    net = ON.synth_ddnet_weights(0)
+    out = OD.ddnet_pass(OO.one_to_three_channel(T(g['mosaic'])), net)
+    assert rel_l2(out, g['out']) == 0
+
+
+def test_ddnet_solver_golden(ffdnet_state_dict):
+    g = load_gold('ddnetadmm_64x64x8')
+    net = ON.OracleFFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    net.eval()
+    o = OS.two_stage_admm(g['y'], g['Phi'], 'ffdnet_color', [2], [25 / 255], x0_bayer=g['warm'], X_orig=g['orig'],
+                          model_denoise=net, model_demosaic=ON.synth_ddnet_weights(0))
+    assert rel_l2(np.stack(o['theta_iterates']), g['theta_ffdnet'][:2]) == 0
+
+
 def test_ffdnet_finetune_golden(ffdnet_state_dict):
     g = load_gold('ffdnet_finetune_64x64x8')
     net = ON.OracleFFDNet()

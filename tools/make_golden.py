@@ -433,7 +433,49 @@ def g_closedform():
          psnr_ffdnet=res[4], theta_fastdvd=ref_it2, rgb_fastdvd=res2[0])
 
 
-GROUPS = dict(closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+def g_ddnet():
+    """Deep demosaicking (model_demosaic=DDnet, reference :192-194 / :242-244) on seeded synthetic weights."""
+    from models.network_demosaicking import DDnet as RefDDnet
+    onet = ON.synth_ddnet_weights(0)
+    rnet = RefDDnet()
+    rnet.load_state_dict(onet.state_dict(), strict=True)
+    rnet.eval()
+    onet.eval()
+    rng = np.random.default_rng(23)
+    mosaic = torch.from_numpy(rng.uniform(0, 1, (32, 48, 8)).astype(np.float32))
+    v = R.oneCh2ThreeCh(mosaic)
+    ref = R.test_ddnet(v, None, None, rnet)
+    mine = OD.ddnet_pass(OO.one_to_three_channel(mosaic), onet)
+    check('ddnet forward cube', mine, ref)
+    save('ddnet_forward', mosaic=mosaic, out=ref)
+    net, sd = load_ref_ffdnet()
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=7)
+    warm = _tv_warm(y, Phi, 20)
+    logf = io.StringIO()
+    seed_all()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2, 2], False, [25 / 255, 12 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=net,
+                                           model_demosaic=rnet, show_iqa=True, demosaic_method='malvar2004', logf=logf)
+    ref_it = np.stack(cap.iterates)
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2, 2], [25 / 255, 12 / 255], x0_bayer=warm, X_orig=orig,
+                          model_denoise=oracle_ffdnet(sd), model_demosaic=onet)
+    check('DDnet + FFDNet iterates', np.stack(o['theta_iterates']), ref_it)
+    rfd, ofd, _ = _ref_fastdvd(0)
+    seed_all()
+    with Capture() as cap:
+        res2 = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
+                                            x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rfd,
+                                            model_demosaic=rnet, show_iqa=True, demosaic_method='malvar2004', logf=logf)
+    ref_it2 = np.stack(cap.iterates)
+    o2 = OS.two_stage_admm(y, Phi, 'fastdvd_color', [3], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=ofd,
+                           model_demosaic=onet)
+    check('DDnet + FastDVDnet iterates', np.stack(o2['theta_iterates']), ref_it2)
+    save('ddnetadmm_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta_ffdnet=ref_it, rgb_ffdnet=res[0],
+         psnr_ffdnet=res[4], theta_fastdvd=ref_it2, rgb_fastdvd=res2[0])
+
+
+GROUPS = dict(ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
