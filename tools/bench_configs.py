@@ -53,6 +53,12 @@ for prec in ('f32', 'f16x3'):
     run.step(8 / 255); torch.cuda.synchronize()
     t0 = time.perf_counter(); run.step(8 / 255); torch.cuda.synchronize()
     print(f'FastDVDnet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
+from oracle.nets import synth_ddnet_weights
+dd = synth_ddnet_weights(0)
+os.environ['SCIPNP_CONV_PRECISION'] = 'f16x3'
+net = FFDNet(); net.load_state_dict(sd)
+run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net, model_demosaic=dd)
+print(f'FFDNet f16x3 + DDnet deep demosaicking 512x512x8: {timeit(run, 25/255, 10):.3f} ms/iteration')
 y, Phi, orig = synth.make_problem(256, 256, 16, 0)
 net = FFDNet(); net.load_state_dict(sd)
 run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net)
