@@ -74,6 +74,7 @@ SIGNATURES = {
     'scipnp_fastdvd_pack_triplets_c8s': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_frame_metrics': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, C.c_double, C.POINTER(_int), _vp]),
     'scipnp_pm_pre_rgb': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _flt, _flt, _vp]),
     'scipnp_pm_ddnet_inputs': (_int, [_vp, _vp, _flt, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ddnet_gather': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),

@@ -1,36 +1,23 @@
-"""Final-report image quality metrics (host side, outside the hot loop), restating what the
-reference obtains from scikit-image 0.18 at dvp_linear_inv_2_stage_ADMM_tensor_online.py:316-321 / :542-547:
-`peak_signal_noise_ratio(X, x, data_range=1.)` and `structural_similarity(X, x, data_range=1.)`
-(7x7 uniform window, sample covariance, K1=0.01, K2=0.03, border of 3 px cropped) per frame."""
+"""Final-report image quality metrics on the device (csrc/metrics.hip): per-frame PSNR and SSIM of the mosaic cube,
+what the reference obtains from scikit-image 0.18 at dvp_linear_inv_2_stage_ADMM_tensor_online.py:316-321 / :542-547
+(`peak_signal_noise_ratio(X, x, data_range=1.)`, `structural_similarity(X, x, data_range=1.)`: 7x7 uniform window,
+sample covariance, K1 = 0.01, K2 = 0.03, 3-pixel border cropped)."""
 import numpy as np
-from scipy.ndimage import uniform_filter
+import torch
+
+from . import ops
 
 
-def psnr(ref, img, data_range=1.0):
-    ft = np.result_type(ref.dtype, img.dtype, np.float32)
-    err = np.mean((ref.astype(ft) - img.astype(ft)) ** 2, dtype=np.float64)
-    return float(10 * np.log10((data_range ** 2) / err))
-
-
-def ssim(ref, img, data_range=1.0, win=7, K1=0.01, K2=0.03):
-    a = ref.astype(np.float64)
-    b = img.astype(np.float64)
-    npx = win ** a.ndim
-    cov_norm = npx / (npx - 1)
-    ux, uy = uniform_filter(a, size=win), uniform_filter(b, size=win)
-    uxx, uyy, uxy = uniform_filter(a * a, size=win), uniform_filter(b * b, size=win), uniform_filter(a * b, size=win)
-    vx = cov_norm * (uxx - ux * ux)
-    vy = cov_norm * (uyy - uy * uy)
-    vxy = cov_norm * (uxy - ux * uy)
-    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
-    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
-    pad = (win - 1) // 2
-    return float(S[tuple(slice(pad, -pad) for _ in range(a.ndim))].mean())
-
-
-def psnr_frames(orig, recon):
-    return [psnr(orig[:, :, t], recon[:, :, t]) for t in range(orig.shape[2])]
-
-
-def ssim_frames(orig, recon):
-    return [ssim(orig[:, :, t], recon[:, :, t]) for t in range(orig.shape[2])]
+def frame_metrics(ref_state, img_state, data_range=1.0, win=7):
+    """plane-major states [B][4][M][N] of the ground truth and the reconstruction -> (psnr [B], ssim [B]) lists."""
+    B, _, M, N = ref_state.shape
+    H, W = 2 * M, 2 * N
+    if min(H, W) < win:
+        raise ValueError('win_size exceeds image extent')
+    part = torch.empty(B, ops.frame_metrics_nblocks(M, N, B, win), 2, dtype=torch.float64, device=ref_state.device)
+    ops.frame_metrics(ref_state, img_state, part, win, data_range)
+    s = part.sum(1).cpu().numpy()
+    mse = s[:, 0] / (H * W)
+    psnr = [float(10 * np.log10((data_range ** 2) / e)) for e in mse]
+    ssim = [float(v / ((H - win + 1) * (W - win + 1))) for v in s[:, 1]]
+    return psnr, ssim

@@ -203,6 +203,23 @@ def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first
     return nb.value
 
 
+def frame_metrics_nblocks(M, N, B, win=7):
+    nb = C.c_int(0)
+    lib = _lib.load()
+    _lib.check(lib.scipnp_frame_metrics(C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), M, N, B, win, 1.0, C.byref(nb),
+                                        C.c_void_p(0)), 'scipnp_frame_metrics')
+    return nb.value
+
+
+def frame_metrics(ref_state, img_state, part, win=7, data_range=1.0):
+    B, _, M, N = ref_state.shape
+    nb = C.c_int(0)
+    _call('scipnp_frame_metrics', _p(ref_state, 'ref_state'), _p(img_state, 'img_state'), _p(part, 'part', torch.float64),
+          M, N, B, win, float(data_range), C.byref(nb), _stream())
+    if nb.value * B * 2 != part.numel():
+        raise _lib.ScipnpError('frame-metrics partial buffer has the wrong size')
+
+
 def sse_nblocks(n):
     nb = C.c_int(0)
     lib = _lib.load()

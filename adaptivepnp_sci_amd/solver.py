@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .metrics import psnr_frames, ssim_frames
+from .metrics import frame_metrics
 from .nets import FFDNetEngine
 
 F32 = torch.float32
@@ -248,10 +248,11 @@ class AdmmRun:
         """(H,W,B) CUDA tensor of the reported iterate (theta two-stage, x one-stage; reference :312-315 / :538-541)."""
         return ops.state_to_mosaic(self.theta if self.two_stage else self.x)
 
-    def final_report(self, mosaic_np):
-        if self.orig_np is None:
+    def final_report(self, mosaic_np=None):
+        """per-frame PSNR / SSIM of the final reconstruction (reference :316-321 / :542-547), computed on the device"""
+        if self.orig is None:
             return [], []
-        return psnr_frames(self.orig_np, mosaic_np), ssim_frames(self.orig_np, mosaic_np)
+        return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
 
 
 def _run_schedule(run, sigma, iter_max):

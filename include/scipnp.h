@@ -285,6 +285,14 @@ int scipnp_fastdvd_finish_bwd(const float* dout, float* dx_c8, int B, int H, int
 int scipnp_fastdvd_unpack_bwd(const float* dtin_c8, const float* extra, float* dframes, int B, int H, int W,
                               scipnp_stream_t s);
 
+/* Final-report metrics per frame of the mosaic cube (plane-major states [B][4][M][N]): part[t][blk] = {sum of squared
+ * error (fp32 squares, fp64 sum), sum of the SSIM map over the image minus a (win-1)/2 border} -- PSNR_t =
+ * 10 log10(range^2 / (sum0 / HW)), SSIM_t = sum1 / ((H-win+1)(W-win+1)).  scikit-image 0.18 semantics (win x win uniform
+ * window, sample covariance, K1 = 0.01, K2 = 0.03, fp64).  part == NULL only returns the block count per frame.
+ * -- dvp...:316-321 / :542-547 */
+int scipnp_frame_metrics(const float* ref_state, const float* img_state, double* part, int M, int N, int B, int win,
+                         double data_range, int* nblocks, scipnp_stream_t s);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * DDnet deep demosaicking -- glue around scipnp_conv3x3_c8 / _c8s.
  * reference: models/network_demosaicking.py:381-463 (DDnet.forward), :186-244, :310-379 (DenBlocks),

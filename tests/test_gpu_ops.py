@@ -576,3 +576,18 @@ def test_ddnet_forward_vs_reference_golden(precision, monkeypatch):
     out = ddnet_plugin(dev(one_to_three_channel(torch.from_numpy(g['mosaic']))), None, None, net)
     err = rel_l2(out.cpu().numpy(), g['out'])
     assert err <= 2e-6, err
+
+
+def test_frame_metrics_vs_skimage_restatement(ops):
+    """device PSNR / SSIM per frame vs the host restatement of scikit-image (itself pinned to the real skimage 0.18.3
+    golden in tests/test_oracle_golden.py)"""
+    from adaptivepnp_sci_amd.metrics import frame_metrics
+    from oracle.metrics import psnr_frames, ssim_frames
+    rng = np.random.default_rng(2)
+    a = rng.random((40, 52, 5)).astype(np.float32)
+    b = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1).astype(np.float32)
+    p, s = frame_metrics(ops.mosaic_to_state(dev(a)), ops.mosaic_to_state(dev(b)))
+    assert np.abs(np.array(p) - np.array(psnr_frames(a, b))).max() < 1e-9
+    assert np.abs(np.array(s) - np.array(ssim_frames(a, b))).max() < 1e-12
+    with pytest.raises(Exception):
+        frame_metrics(ops.mosaic_to_state(dev(a[:4, :4])), ops.mosaic_to_state(dev(b[:4, :4])))

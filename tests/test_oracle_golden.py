@@ -101,7 +101,7 @@ def test_tv_admm_iterates_golden():
 
 
 def test_final_report_metrics_vs_skimage_golden():
-    from adaptivepnp_sci_amd.metrics import psnr_frames, ssim_frames
+    from oracle.metrics import psnr_frames, ssim_frames
     g = load_gold('tvadmm_64x64x8')
     assert np.allclose(psnr_frames(g['orig'], g['one_stage_final']), g['one_stage_psnr_frames'], atol=1e-10)
     assert np.allclose(ssim_frames(g['orig'], g['one_stage_final']), g['one_stage_ssim_frames'], atol=1e-9)
