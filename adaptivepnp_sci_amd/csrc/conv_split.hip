@@ -66,10 +66,11 @@ struct SplitArgs {
     const char* in;      // c8s activations
     const char* wpk;     // packed split weights: [cig][tap][2][CoutP][8] fp16, then bias fp32 [CoutP]
     char* out;           // c8s (fp16 split) or fp32 c8
+    const char* mask;    // c8s tensor of the output's shape: output zeroed where it is <= 0 (flag bit4; backward-data conv)
     int CGin, CGout, CoutP_total, nsplit;
     int H, W;            // input size
     int Ho, Wo;          // conv output size (before any pixel shuffle)
-    int flags;           // bit0 ReLU, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle store (fp32 output only)
+    int flags;           // bit0 ReLU, bit4 (16) ReLU-mask, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle store (fp32 only)
 };
 
 // set when a value leaves fp16's finite range on its way into the c8s format (results are then invalid and the
@@ -252,6 +253,14 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                             if (relu) v[e] = fmaxf(v[e], 0.f);
                         }
                         const size_t pix = (size_t)y * Wo + x;
+                        if (a.flags & 16) {
+                            // ReLU'(activation): the stashed activation is >= 0, positive iff one of its halves is
+                            const char* mg = a.mask + ((size_t)n * a.CGout + cog) * (2 * HWo * 16) + pix * 16 + 8 * lh;
+                            const f16x4 mh = *(const f16x4*)mg, ml = *(const f16x4*)(mg + HWo * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!((float)mh[e] > 0.f || (float)ml[e] > 0.f)) v[e] = 0.f;
+                        }
                         if (SHUF) {
                             // PixelShuffle(2): conv channel 8*cog + 4*lh + e -> channel c = 2*cog + lh of pixel
                             // (2y + (e>>1), 2x + (e&1)); fp32 c8 tensor [n][CGout/4][2Ho][2Wo][8]
@@ -334,7 +343,70 @@ c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, cha
     split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
 }
 
+// device-side packing of (updated) fp32 master weights for the online finetune: forward layout, or the backward-data
+// convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (no bias).  One thread per (cig, tap, co, c8) element pair.
+__global__ void __launch_bounds__(256)
+pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, char* __restrict__ packed,
+                         int Cin_real, int Cout_real, int Kin, int KoutP, int transpose) {
+    const size_t nw = (size_t)(Kin / 8) * 9 * KoutP * 8;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw + KoutP) return;
+    if (i >= nw) {
+        const int o = (int)(i - nw);
+        ((float*)(packed + nw * 4))[o] = (!transpose && bias && o < Cout_real) ? bias[o] : 0.f;
+        return;
+    }
+    const int c8 = i & 7;
+    const int o = (int)((i >> 3) % KoutP);
+    const int tap = (int)((i / ((size_t)8 * KoutP)) % 9);
+    const int ig = (int)(i / ((size_t)8 * KoutP * 9));
+    const int in_ch = ig * 8 + c8;
+    float val = 0.f;
+    if (!transpose) {
+        if (o < Cout_real && in_ch < Cin_real) val = w[((size_t)o * Cin_real + in_ch) * 9 + tap];
+    } else {
+        if (o < Cin_real && in_ch < Cout_real) val = w[((size_t)in_ch * Cin_real + o) * 9 + (8 - tap)];
+    }
+    if (!(fabsf(val) < 31.9f)) g_split_overflow = 1;
+    const _Float16 hi = (_Float16)val;
+    const _Float16 lo = (_Float16)((val - (float)hi) * CS_LO_SCALE);
+    _Float16* p = (_Float16*)packed;
+    const size_t base = ((size_t)ig * 9 + tap) * 2;
+    p[((base + 0) * KoutP + o) * 8 + c8] = hi;
+    p[((base + 1) * KoutP + o) * 8 + c8] = lo;
+}
+
+// c8s -> fp32 c8 with an exact power-of-two rescale (gradients travel through the split kernels pre-scaled)
+__global__ void __launch_bounds__(256)
+c8s_to_c8_kernel(const char* __restrict__ in, float* __restrict__ out, size_t HW, size_t total, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t grp = i / HW, pix = i - grp * HW;
+    const f16x8 h = *(const f16x8*)(in + grp * (2 * HW * 16) + pix * 16);
+    const f16x8 l = *(const f16x8*)(in + grp * (2 * HW * 16) + HW * 16 + pix * 16);
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = ((float)h[e] + (float)l[e] * CS_LO_INV) * scale;
+        b[e] = ((float)h[4 + e] + (float)l[4 + e] * CS_LO_INV) * scale;
+    }
+    *(f32x4*)(out + i * 8) = a;
+    *(f32x4*)(out + i * 8 + 4) = b;
+}
+
+__global__ void __launch_bounds__(256)
+c8_scale_to_c8s_kernel(const float* __restrict__ in, char* __restrict__ out, size_t HW, size_t total, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t grp = i / HW, pix = i - grp * HW;
+    const f32x4 a = *(const f32x4*)(in + i * 8) * scale, b = *(const f32x4*)(in + i * 8 + 4) * scale;
+    char* g = out + grp * (2 * HW * 16);
+    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16);
+    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
+}
+
 }  // namespace scipnp
+
 
 using namespace scipnp;
 
@@ -342,6 +414,8 @@ extern "C" {
 
 int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
                          scipnp_stream_t s);
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
+                          int Cout, int h, int w, int flags, scipnp_stream_t s);
 
 size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
@@ -389,7 +463,14 @@ int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, i
 
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout, int h, int w,
                        int flags, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(!(flags & 16), "ReLU-mask epilogue needs scipnp_conv3x3_c8s_ex");
+    return scipnp_conv3x3_c8s_ex(in_c8s, packed_split, out, nullptr, n, Cin, Cout, h, w, flags, s);
+}
+
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
+                          int Cout, int h, int w, int flags, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in_c8s && packed_split && out, "null pointer");
+    SCIPNP_REQUIRE(!(flags & 16) || (mask_c8s && !(flags & (4 | 8 | 32))), "flag bit4 needs mask_c8s and a c8s stride-1 output");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
     SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(packed_split); SCIPNP_ALIGNED(out);
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 31), "image too large for 32-bit tile offsets");
@@ -397,7 +478,7 @@ int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, 
     SCIPNP_REQUIRE(!(stride2 && shuf), "stride-2 and pixel-shuffle epilogue cannot be combined");
     SCIPNP_REQUIRE(!shuf || Cout % 32 == 0, "pixel-shuffle epilogue needs Cout %% 32 == 0 (got %d)", Cout);
     SplitArgs a;
-    a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out;
+    a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out; a.mask = (const char*)mask_c8s;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up_s(Cout, 32); a.nsplit = 1;
     a.H = h; a.W = w;
     a.Ho = stride2 ? (h - 1) / 2 + 1 : h;
@@ -439,6 +520,37 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
     hipLaunchKernelGGL(c8_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
                        (const char*)residual_c8s, (char*)out_c8s, HW, total);
     return launch_status("c8_to_c8s_kernel");
+}
+
+int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* packed, int Cin_real, int Cout_real, int Cin,
+                                     int Cout, int transpose_flip, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(w && packed, "null pointer");
+    SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
+                   "bad channel counts");
+    const int Kin = transpose_flip ? Cout : Cin;
+    const int KoutP = round_up_s(transpose_flip ? Cin : Cout, 32);
+    const size_t total = (size_t)(Kin / 8) * 9 * KoutP * 8 + KoutP;
+    hipLaunchKernelGGL(pack_split_device_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, bias,
+                       (char*)packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
+    return launch_status("pack_split_device_kernel");
+}
+
+int scipnp_c8s_to_c8(const void* in_c8s, float* out_c8, float scale, int n, int C, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8s && out_c8 && n > 0 && C % 8 == 0 && C > 0 && h > 0 && w > 0, "bad arguments");
+    SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(out_c8);
+    const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
+    hipLaunchKernelGGL(c8s_to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       (const char*)in_c8s, out_c8, HW, total, scale);
+    return launch_status("c8s_to_c8_kernel");
+}
+
+int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n, int C, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8s && n > 0 && C % 8 == 0 && C > 0 && h > 0 && w > 0, "bad arguments");
+    SCIPNP_ALIGNED(in_c8); SCIPNP_ALIGNED(out_c8s);
+    const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
+    hipLaunchKernelGGL(c8_scale_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
+                       (char*)out_c8s, HW, total, scale);
+    return launch_status("c8_scale_to_c8s_kernel");
 }
 
 }  // extern "C"

@@ -62,6 +62,8 @@ def ffdnet_rgb_denoise_full_tensor(x, yall, Phiall, sigma, model, useGPU=True, l
         in_c8, h, w = _unshuffle_to_c8(rgb, sigma)
         eng = _engine_for(model, B, h, w, x.device)
         eng.in_c8.copy_(in_c8)
+        if eng.in_c8s is not None:
+            eng.in_c8s.copy_(ops.c8_to_c8s(in_c8))
         ffdnet_online_finetune(model, eng, yall.permute(2, 0, 1).contiguous(), Phiall.permute(2, 3, 0, 1).contiguous(),
                                sigma, lr_, update_per_iter)
         out = F.pixel_shuffle(ops.from_c8(eng.forward(eng.in_c8), 12), 2)[..., :H, :W].contiguous()

@@ -64,12 +64,34 @@ class _FFDNetTrainer:
         _lib.check(lib.scipnp_ffdnet_loss_grad(None, None, None, None, None, M, N, B, C.byref(nb_), None), 'loss size')
         self.loss_part = torch.empty(nb_.value, dtype=torch.float64, device=dev)
         self.step = 0
+        # split-fp16 path (engine precision 'f16x3'): forward stash and backward-data convolutions on the fp16 MFMA with
+        # error-compensated operands; gradients travel pre-scaled by the power of two nearest 2*M*N (the measurement
+        # loss carries 1/(2MN), so the scaled output gradient is O(residual)) and are un-scaled, exactly, on their way
+        # into the fp32 weight / bias gradient kernels
+        self.split = eng.precision == 'f16x3'
+        if self.split:
+            f16 = torch.float16
+            self.fwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(ci, co), dtype=torch.uint8, device=dev)
+                          for ci, co in zip(self.cin, self.cout)]
+            self.bwd_s = [None] + [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(co, ci), dtype=torch.uint8, device=dev)
+                                   for ci, co in list(zip(self.cin, self.cout))[1:]]
+            self.acts_s = [a.view(f16).view(B, nc // 8, 2, M, N, 8) for a in self.acts]      # same bytes as fp32 c8
+            self.dz_s = [torch.empty(B, nc // 8, 2, M, N, 8, dtype=f16, device=dev) for _ in range(2)]
+            self.gout_s = torch.empty(B, 2, 2, M, N, 8, dtype=f16, device=dev)
+            self.a32 = torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev)
+            self.gscale = float(2.0 ** round(np.log2(2.0 * M * N)))
 
     def _real(self, l):
         w = self.w[l]
         return w.shape[1], w.shape[0]      # Cin_real, Cout_real
 
     def pack(self):
+        if self.split:
+            for l in range(self.nb):
+                ops.pack_conv3x3_split_device(self.w[l], self.b[l], self.fwd_s[l], self.cin[l], self.cout[l])
+                if l > 0:
+                    ops.pack_conv3x3_split_device(self.w[l], None, self.bwd_s[l], self.cin[l], self.cout[l], transpose=True)
+            return
         for l in range(self.nb):
             ci_r, co_r = self._real(l)
             _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), _ptr(self.b[l]), _ptr(self.fwd[l]), ci_r, co_r,
@@ -80,6 +102,13 @@ class _FFDNetTrainer:
 
     def forward_keep(self):
         eng = self.eng
+        if self.split:
+            x = eng.in_c8s
+            for l in range(self.nb - 1):
+                ops.conv3x3_c8s(x, self.fwd_s[l], self.nc, relu=True, out=self.acts_s[l], head=(l == 0))
+                x = self.acts_s[l]
+            ops.conv3x3_c8s(x, self.fwd_s[-1], 16, out=eng.out_c8, f32_out=True)
+            return
         x = eng.in_c8
         for l in range(self.nb - 1):
             ops.conv3x3_c8(x, self.fwd[l], self.nc, relu=True, out=self.acts[l], head=(l == 0))
@@ -95,6 +124,8 @@ class _FFDNetTrainer:
         return self.loss_part.sum() / (4.0 * eng.M * eng.N)        # device scalar (float64)
 
     def backward(self):
+        if self.split:
+            return self._backward_split()
         eng = self.eng
         B, M, N = eng.B, eng.M, eng.N
         dz = self.gout
@@ -111,6 +142,24 @@ class _FFDNetTrainer:
                 _lib.check(self.lib.scipnp_conv3x3_c8(_ptr(dz), _ptr(self.bwd[l]), _ptr(nxt), _ptr(self.acts[l - 1]), B,
                                                       self.cout[l], self.cin[l], M, N, 16, _s()), 'backward-data conv')
                 dz = nxt
+
+    def _backward_split(self):
+        eng = self.eng
+        B, M, N = eng.B, eng.M, eng.N
+        dz_s = ops.c8_scale_to_c8s(self.gout, self.gout_s, self.gscale)
+        dz32 = self.gout
+        for l in range(self.nb - 1, -1, -1):
+            a_in = eng.in_c8 if l == 0 else ops.c8s_to_c8(self.acts_s[l - 1], self.a32)
+            ci_r, co_r = self._real(l)
+            _lib.check(self.lib.scipnp_conv3x3_wgrad(_ptr(a_in), _ptr(dz32), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB, B,
+                                                     ci_r, co_r, self.cin[l], self.cout[l], M, N, _s()), 'wgrad')
+            _lib.check(self.lib.scipnp_conv_bias_grad(_ptr(dz32), _ptr(self.db[l]), _ptr(self.bws), B, co_r, self.cout[l],
+                                                      M, N, _s()), 'bgrad')
+            if l > 0:
+                nxt = self.dz_s[l & 1]
+                ops.conv3x3_c8s(dz_s, self.bwd_s[l], self.cin[l], out=nxt, mask=self.acts_s[l - 1])
+                dz_s = nxt
+                dz32 = ops.c8s_to_c8(dz_s, self.dz[0], 1.0 / self.gscale)
 
     def adam(self, lr):
         self.step += 1

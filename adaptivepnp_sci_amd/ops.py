@@ -308,9 +308,11 @@ def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_s
     return packed.to(device) if device is not None else packed
 
 
-def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False, stride2=False, shuffle=False):
+def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False, stride2=False, shuffle=False,
+                mask=None):
     """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s, or fp32 c8 if f32_out / shuffle
-    (shuffle: PixelShuffle(2)-ed fp32 c8 [n][Cout/32][2h][2w][8])."""
+    (shuffle: PixelShuffle(2)-ed fp32 c8 [n][Cout/32][2h][2w][8]).  mask: c8s tensor of the output's shape, output
+    zeroed where it is not positive (backward-data convolution of the finetune)."""
     n, cg, _two, h, w, _ = x.shape
     ho, wo = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if stride2 else (h, w)
     if out is None:
@@ -322,9 +324,35 @@ def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False
             out = torch.empty(n, Cout // 8, 2, ho, wo, 8, device=x.device, dtype=torch.float16)
     fp32 = f32_out or shuffle
     flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
-             (0x100 if head else 0))
-    _call('scipnp_conv3x3_c8s', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
-          _p(out, 'out', F32 if fp32 else torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
+             (0x100 if head else 0) | (16 if mask is not None else 0))
+    _call('scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
+          _p(out, 'out', F32 if fp32 else torch.float16), _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags,
+          _stream())
+    return out
+
+
+def pack_conv3x3_split_device(w, bias, packed, Cin, Cout, transpose=False):
+    """device fp32 OIHW weights (+bias) -> `packed` (uint8 device buffer of scipnp_conv3x3_split_packed_bytes);
+    transpose=True packs the backward-data convolution (buffer sized for (Cout, Cin))."""
+    co, ci = w.shape[0], w.shape[1]
+    _call('scipnp_pack_conv3x3_split_device', _p(w, 'w'), _p(bias, 'bias'), _p(packed, 'packed', torch.uint8), ci, co, Cin,
+          Cout, int(bool(transpose)), _stream())
+    return packed
+
+
+def c8s_to_c8(x, out=None, scale=1.0):
+    n, cg, _two, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, cg, h, w, 8, device=x.device, dtype=F32)
+    _call('scipnp_c8s_to_c8', _p(x, 'x', torch.float16), _p(out, 'out'), float(scale), n, cg * 8, h, w, _stream())
+    return out
+
+
+def c8_scale_to_c8s(x, out=None, scale=1.0):
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, cg, 2, h, w, 8, device=x.device, dtype=torch.float16)
+    _call('scipnp_c8_scale_to_c8s', _p(x, 'x'), _p(out, 'out', torch.float16), float(scale), n, cg * 8, h, w, _stream())
     return out
 
 

@@ -179,7 +179,7 @@ class AdmmRun:
         closed = self.close_form and k > 0      # closed-form RGB update (reference :175-182 / :224-230), Malvar at k = 0
         if self.denoiser == 'ffdnet_color':
             split = self.eng.precision == 'f16x3'
-            # the finetune (rare) runs on the fp32 kernels and needs the fp32 c8 input as well
+            # the finetune's weight-gradient kernel (fp32 MFMA) needs the fp32 c8 input as well
             c8 = self.eng.in_c8 if (gate or not split) else None
             c8s = self.eng.in_c8s if split else None
             if closed:

@@ -210,6 +210,25 @@ int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int
 int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
                          scipnp_stream_t s);
 
+/* split-fp16 conv with a ReLU-mask epilogue (flag bit4 = 16): out = conv(in) where mask_c8s (a c8s tensor of the
+ * output's shape, the stashed forward activation) is positive, else 0 -- the backward-data convolution of the online
+ * finetune on the fp16 MFMA (packages/ffdnet/test_ffdnet_ipol.py:296 `loss.backward()`).  Other flags as
+ * scipnp_conv3x3_c8s; mask_c8s may be NULL when bit4 is clear. */
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
+                          int Cout, int h, int w, int flags, scipnp_stream_t s);
+
+/* device-side packing of fp32 master weights (device pointers) into the split layout: transpose_flip = 0 forward
+ * (with bias), 1 the backward-data convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (Cin/Cout are the FORWARD
+ * conv's padded channel counts; no bias).  Raises the split-overflow flag if |w| >= 31.9. */
+int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* packed, int Cin_real, int Cout_real,
+                                     int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
+
+/* c8s -> fp32 c8 and fp32 c8 -> c8s with an exact power-of-two rescale (gradients travel through the split kernels
+ * pre-scaled into fp16 range) */
+int scipnp_c8s_to_c8(const void* in_c8s, float* out_c8, float scale, int n, int C, int h, int w, scipnp_stream_t s);
+int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n, int C, int h, int w,
+                           scipnp_stream_t s);
+
 /* whole FFDNet-colour forward on B frames: 12 (nb) conv layers ping-ponging between two c8 scratch
  * buffers of n*nc*h*w floats each.  in_c8: [B][2][M][N][8] from scipnp_pm_pre_denoise, out_c8:
  * [B][2][M][N][8] (12 valid channels, pixel-shuffle is folded into scipnp_pm_post_denoise).
