@@ -85,12 +85,18 @@ class _FFDNetTrainer:
         w = self.w[l]
         return w.shape[1], w.shape[0]      # Cin_real, Cout_real
 
-    def pack(self):
+    def pack(self, final=False):
+        """pack the master weights on the device; final=True (after the last Adam step) skips the backward-data packs
+        and also refreshes the fp32 forward packs the engine keeps next to the split ones"""
         if self.split:
             for l in range(self.nb):
                 ops.pack_conv3x3_split_device(self.w[l], self.b[l], self.fwd_s[l], self.cin[l], self.cout[l])
-                if l > 0:
+                if l > 0 and not final:
                     ops.pack_conv3x3_split_device(self.w[l], None, self.bwd_s[l], self.cin[l], self.cout[l], transpose=True)
+                if final:
+                    ci_r, co_r = self._real(l)
+                    _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), _ptr(self.b[l]), _ptr(self.fwd[l]), ci_r,
+                                                                   co_r, self.cin[l], self.cout[l], 0, _s()), 'pack fwd')
             return
         for l in range(self.nb):
             ci_r, co_r = self._real(l)
@@ -185,18 +191,18 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
     _lib.require_gpu()
     tr = _FFDNetTrainer(model, eng)
     tr.pack()
-    for _ in range(update_per_iter):
+    for it in range(update_per_iter):
         tr.forward_keep()
         loss = tr.loss_and_grad(y_pm, Phi_pm)
         tr.backward()
         tr.adam(lr_)
-        tr.pack()
+        tr.pack(final=(it == update_per_iter - 1))
         val = float(loss.item())
         print('loss:', val)                                   # the reference prints the loss tensor (:298-299)
         if trace is not None:
             trace.append(val)
     tr.write_back()
-    eng.refresh(model)            # repack (fp32 and, if enabled, split-fp16) from the updated parameters
+    eng.adopt(tr.fwd, tr.fwd_s if tr.split else None)     # the engine continues on the device-packed updated weights
     return model
 
 

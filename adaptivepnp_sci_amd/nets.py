@@ -54,7 +54,8 @@ def ffdnet_layers(model):
 def default_precision():
     """'f16x3' (error-compensated split-fp16 MFMA, csrc/conv_split.hip) or 'f32' (fp32 MFMA, csrc/conv.hip);
     override with SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION).  Applies to the FFDNet and FastDVDnet
-    forward passes; the online finetune always runs on the fp32 kernels."""
+    forward passes and to the forward / backward-data convolutions of the FFDNet online finetune (its weight-gradient
+    kernel and the FastDVDnet finetune run on the fp32 MFMA)."""
     import os
     p = os.environ.get('SCIPNP_CONV_PRECISION', os.environ.get('SCIPNP_FFDNET_PRECISION', 'f16x3'))
     if p not in ('f32', 'f16x3'):
@@ -97,6 +98,14 @@ class FFDNetEngine:
                 cin = 16 if i == 0 else self.nc
                 cout = 16 if i == self.nb - 1 else self.nc
                 self.packed_split.append(ops.pack_conv3x3_split(w, b, Cin=cin, Cout=cout, device=self.device))
+
+    def adopt(self, packed_f32, packed_split=None):
+        """Take over device-packed weights (the online finetune packs its updated master weights on the GPU,
+        scipnp_pack_conv3x3_device / _split_device) instead of re-packing on the host."""
+        self.packed = list(packed_f32)
+        self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
+        if self.precision == 'f16x3':
+            self.packed_split = list(packed_split)
 
     def forward(self, in_c8=None, out_c8=None, events=None):
         """12 conv launches on the current stream (same sequence as the C entry scipnp_ffdnet_forward).
