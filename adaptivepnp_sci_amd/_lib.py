@@ -73,6 +73,8 @@ SIGNATURES = {
     'scipnp_c8_add_to_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8s_ex': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_pack_conv3x3_split_device': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_wgrad_split': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _flt, _vp]),
+    'scipnp_conv_bias_grad_split': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _flt, _vp]),
     'scipnp_c8s_to_c8': (_int, [_vp, _vp, _flt, _int, _int, _int, _int, _vp]),
     'scipnp_c8_scale_to_c8s': (_int, [_vp, _vp, _flt, _int, _int, _int, _int, _vp]),
     'scipnp_fastdvd_pack_triplets_c8s': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),

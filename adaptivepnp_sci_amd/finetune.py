@@ -78,7 +78,6 @@ class _FFDNetTrainer:
             self.acts_s = [a.view(f16).view(B, nc // 8, 2, M, N, 8) for a in self.acts]      # same bytes as fp32 c8
             self.dz_s = [torch.empty(B, nc // 8, 2, M, N, 8, dtype=f16, device=dev) for _ in range(2)]
             self.gout_s = torch.empty(B, 2, 2, M, N, 8, dtype=f16, device=dev)
-            self.a32 = torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev)
             self.gscale = float(2.0 ** round(np.log2(2.0 * M * N)))
 
     def _real(self, l):
@@ -152,20 +151,20 @@ class _FFDNetTrainer:
     def _backward_split(self):
         eng = self.eng
         B, M, N = eng.B, eng.M, eng.N
+        inv = 1.0 / self.gscale
         dz_s = ops.c8_scale_to_c8s(self.gout, self.gout_s, self.gscale)
-        dz32 = self.gout
         for l in range(self.nb - 1, -1, -1):
-            a_in = eng.in_c8 if l == 0 else ops.c8s_to_c8(self.acts_s[l - 1], self.a32)
+            a_in = eng.in_c8s if l == 0 else self.acts_s[l - 1]
             ci_r, co_r = self._real(l)
-            _lib.check(self.lib.scipnp_conv3x3_wgrad(_ptr(a_in), _ptr(dz32), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB, B,
-                                                     ci_r, co_r, self.cin[l], self.cout[l], M, N, _s()), 'wgrad')
-            _lib.check(self.lib.scipnp_conv_bias_grad(_ptr(dz32), _ptr(self.db[l]), _ptr(self.bws), B, co_r, self.cout[l],
-                                                      M, N, _s()), 'bgrad')
+            _lib.check(self.lib.scipnp_conv3x3_wgrad_split(_ptr(a_in), _ptr(dz_s), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB,
+                                                           B, ci_r, co_r, self.cin[l], self.cout[l], M, N, inv, _s()),
+                       'wgrad split')
+            _lib.check(self.lib.scipnp_conv_bias_grad_split(_ptr(dz_s), _ptr(self.db[l]), _ptr(self.bws), B, co_r,
+                                                            self.cout[l], M, N, inv, _s()), 'bgrad split')
             if l > 0:
                 nxt = self.dz_s[l & 1]
                 ops.conv3x3_c8s(dz_s, self.bwd_s[l], self.cin[l], out=nxt, mask=self.acts_s[l - 1])
                 dz_s = nxt
-                dz32 = ops.c8s_to_c8(dz_s, self.dz[0], 1.0 / self.gscale)
 
     def adam(self, lr):
         self.step += 1

@@ -223,6 +223,16 @@ int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* ou
 int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* packed, int Cin_real, int Cout_real,
                                      int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
 
+/* weight / bias gradients from c8s operands on the fp16 MFMA (error-compensated, transposing LDS reads); same
+ * workspace and slab scheme as scipnp_conv3x3_wgrad / scipnp_conv_bias_grad.  dz_c8s carries the gradient
+ * pre-scaled by a power of two, `scale` (its reciprocal) is applied to the result.
+ * -- packages/ffdnet/test_ffdnet_ipol.py:296 (loss.backward()) */
+int scipnp_conv3x3_wgrad_split(const void* act_c8s, const void* dz_c8s, float* dW, float* workspace, int nslab, int n,
+                               int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, float scale,
+                               scipnp_stream_t s);
+int scipnp_conv_bias_grad_split(const void* dz_c8s, float* db, float* workspace, int n, int Cout_real, int Cout, int h,
+                                int w, float scale, scipnp_stream_t s);
+
 /* c8s -> fp32 c8 and fp32 c8 -> c8s with an exact power-of-two rescale (gradients travel through the split kernels
  * pre-scaled into fp16 range) */
 int scipnp_c8s_to_c8(const void* in_c8s, float* out_c8, float scale, int n, int C, int h, int w, scipnp_stream_t s);

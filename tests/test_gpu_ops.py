@@ -591,3 +591,40 @@ def test_frame_metrics_vs_skimage_restatement(ops):
     assert np.abs(np.array(s) - np.array(ssim_frames(a, b))).max() < 1e-12
     with pytest.raises(Exception):
         frame_metrics(ops.mosaic_to_state(dev(a[:4, :4])), ops.mosaic_to_state(dev(b[:4, :4])))
+
+
+def test_split_wgrad_bgrad_backward_data_vs_autograd(ops):
+    """the finetune's split-fp16 kernels: weight / bias gradients from c8s operands (transposing LDS reads, pre-scaled
+    dZ) and the backward-data conv with the ReLU-mask epilogue, against PyTorch autograd in float64"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(12)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    n, h, w, nslab, S = 2, 11, 37, 16, 1024.0
+    for ci_r, co_r, ci, co in ((96, 96, 96, 96), (13, 96, 16, 96), (96, 12, 96, 16), (64, 128, 64, 128)):
+        x = torch.relu(torch.randn(n, ci_r, h, w, generator=g))
+        wt = (torch.randn(co_r, ci_r, 3, 3, generator=g) * 0.05).double().requires_grad_()
+        bias = torch.zeros(co_r, dtype=torch.float64, requires_grad=True)
+        dz = torch.randn(n, co_r, h, w, generator=g) * 1e-3
+        xd = x.double().requires_grad_()
+        torch.nn.functional.conv2d(xd, wt, bias, padding=1).backward(dz.double())
+        xs = ops.c8_to_c8s(ops.to_c8(x.cuda()))
+        dzs = ops.c8_scale_to_c8s(ops.to_c8(dz.cuda()), scale=S)
+        ws = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, nslab), device='cuda')
+        dW = torch.empty(co_r, ci_r, 3, 3, device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad_split(p(xs), p(dzs), p(dW), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, 1 / S, s),
+                   'wgrad split')
+        assert rel_l2(dW.cpu().numpy(), wt.grad.numpy()) < 2e-6, (ci_r, co_r, rel_l2(dW.cpu().numpy(), wt.grad.numpy()))
+        db = torch.empty(co_r, device='cuda')
+        bws = torch.empty((co // 8) * 64 * 8, device='cuda')
+        _lib.check(lib.scipnp_conv_bias_grad_split(p(dzs), p(db), p(bws), n, co_r, co, h, w, 1 / S, s), 'bgrad split')
+        assert rel_l2(db.cpu().numpy(), bias.grad.numpy()) < 2e-6
+        # backward-data: conv of dZ with the transposed / flipped weights (packed on the device), masked by x > 0
+        pk = torch.empty(lib.scipnp_conv3x3_split_packed_bytes(co, ci), dtype=torch.uint8, device='cuda')
+        ops.pack_conv3x3_split_device(wt.detach().float().cuda().contiguous(), None, pk, ci, co, transpose=True)
+        dx = ops.conv3x3_c8s(dzs, pk, ci, mask=xs)
+        got = ops.from_c8(ops.c8s_to_c8(dx, scale=1 / S))[:, :ci_r].cpu()
+        ref = xd.grad * (x > 0)
+        assert rel_l2(got.numpy(), ref.numpy()) < 2e-6, (ci_r, co_r)
