@@ -37,6 +37,9 @@ class _FFDNetTrainer:
     def __init__(self, model, eng):
         self.eng = eng
         dev = eng.device
+        self.split = eng.precision == 'f16x3'
+        if self.split:
+            self.NSLAB = 85          # x 3 input-channel blocks = 255 persistent workgroups, one round on 256 CUs
         self.layers = ffdnet_layers(model)                # [(weight, bias)] tensors of the module (any device)
         self.w = [w.detach().to(dev, F32).contiguous().clone() for w, _ in self.layers]
         self.b = [b.detach().to(dev, F32).contiguous().clone() for _, b in self.layers]
@@ -68,7 +71,6 @@ class _FFDNetTrainer:
         # error-compensated operands; gradients travel pre-scaled by the power of two nearest 2*M*N (the measurement
         # loss carries 1/(2MN), so the scaled output gradient is O(residual)) and are un-scaled, exactly, on their way
         # into the fp32 weight / bias gradient kernels
-        self.split = eng.precision == 'f16x3'
         if self.split:
             f16 = torch.float16
             self.fwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(ci, co), dtype=torch.uint8, device=dev)

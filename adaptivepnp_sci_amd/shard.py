@@ -59,3 +59,44 @@ def reconstruct_sharded(units, solve, unit_shape, device, model=None, dst=0, gro
     for u in partition(len(units), world, rank):
         local[u] = solve(units[u], copy.deepcopy(model) if model is not None else None)
     return gather_units(local, len(units), unit_shape, device, dst=dst, group=group)
+
+
+# ---------------------------------------------------------------------------------------------- spatial tiles
+def tile_grid(H, W, tile):
+    """Origins (r, c) of the Bayer-aligned `tile` x `tile` patches covering an (H, W) frame, row-major
+    (BASELINE configs[4]: a 1024 x 1024 x 16 cube as 16 patches of 256 x 256)."""
+    if tile % 2 or H % tile or W % tile:
+        raise ValueError(f'tile {tile} must be even and divide the frame {H}x{W} (patches keep the RGGB phase)')
+    return [(r, c) for r in range(0, H, tile) for c in range(0, W, tile)]
+
+
+def tile_cube(y, Phi, tile, x0=None, orig=None):
+    """Cut measurement (H,W), masks (H,W,B) and optional warm start / ground truth (H,W,B) into per-tile argument
+    tuples (y_t, Phi_t, x0_t, orig_t); the forward operator is per-pixel, so every patch is an independent SCI problem
+    (SURVEY 8e).  Works on NumPy arrays and torch tensors alike."""
+    H, W = y.shape[:2]
+    units = []
+    for r, c in tile_grid(H, W, tile):
+        sl = (slice(r, r + tile), slice(c, c + tile))
+        units.append((y[sl], Phi[sl], None if x0 is None else x0[sl], None if orig is None else orig[sl]))
+    return units
+
+
+def stitch_tiles(tiles, H, W, tile):
+    """Inverse of tile_cube for a list of (tile, tile, ...) tensors in tile_grid order -> (H, W, ...)."""
+    first = tiles[0]
+    out = first.new_empty((H, W) + tuple(first.shape[2:]))
+    for t, (r, c) in zip(tiles, tile_grid(H, W, tile)):
+        out[r:r + tile, c:c + tile] = t
+    return out
+
+
+def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None):
+    """Tile a large cube, reconstruct the patches independently on the ranks of `group` (tile j on rank j % world, each
+    with its own deep copy of `model`), gather them with ONE collective and stitch on rank `dst`.
+    solve((y_t, Phi_t, x0_t, orig_t), model_copy) -> (tile, tile, B) tensor on `device`.
+    Returns the (H, W, B) mosaic on rank dst, None elsewhere."""
+    H, W, B = Phi.shape
+    units = tile_cube(y, Phi, tile, x0, orig)
+    got = reconstruct_sharded(units, solve, (tile, tile, B), device, model=model, dst=dst, group=group)
+    return None if got is None else stitch_tiles(got, H, W, tile)

@@ -114,3 +114,37 @@ def test_config4_tile_256x256x16_with_online_finetune(solver, ffdnet_state_dict)
     for k in range(3):
         assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, k
     assert res[1].shape == (256, 256, 16)
+
+
+def test_config4_tiled_cube_matches_per_tile_oracle(solver, ffdnet_state_dict):
+    """configs[4] end to end at reduced size: a 128x128x8 cube cut into four 64x64 patches, every patch reconstructed
+    independently (own model copy, online finetune firing once), gathered and stitched; oracle = the reference solver
+    called per patch."""
+    from adaptivepnp_sci_amd import shard, synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(128, 128, 8, seed=4)
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    kw = dict(lr_=2e-6, inital_iter=0, interval_iter=2, update_=True, update_per_iter=1)
+
+    def solve(args, model):
+        y_t, Phi_t, _x0, orig_t = args
+        res = solver.twoStageAdmm_denoise_bayer(np.ascontiguousarray(y_t), np.ascontiguousarray(Phi_t), 1, 0.01,
+                                                'ffdnet_color', [3], False, [25 / 255], X_orig=np.ascontiguousarray(orig_t),
+                                                model_denoise=model, logf=io.StringIO(), **kw)
+        return torch.from_numpy(res[1]).cuda()
+
+    out = shard.reconstruct_tiled(y, Phi, 64, solve, torch.device('cuda'), orig=orig, model=net).cpu().numpy()
+    assert out.shape == (128, 128, 8)
+    for k0, w0 in ffdnet_state_dict.items():                      # the caller's model is untouched (per-tile copies)
+        assert torch.equal(net.state_dict()[k0], w0)
+    for (r, c), (y_t, Phi_t, _x0, orig_t) in zip(shard.tile_grid(128, 128, 64), shard.tile_cube(y, Phi, 64, orig=orig)):
+        onet = ON.OracleFFDNet()
+        onet.load_state_dict(ffdnet_state_dict)
+        onet.eval()
+        o = OS.two_stage_admm(np.ascontiguousarray(y_t), np.ascontiguousarray(Phi_t), 'ffdnet_color', [3], [25 / 255],
+                              X_orig=np.ascontiguousarray(orig_t), model_denoise=onet, lr=2e-6, inital_iter=0,
+                              interval_iter=2, update=True, update_per_iter=1)
+        assert rel_l2(out[r:r + 64, c:c + 64], o['x_bayer']) <= REL_TOL, (r, c)
