@@ -39,7 +39,8 @@ class _FFDNetTrainer:
         dev = eng.device
         self.split = eng.precision == 'f16x3'
         if self.split:
-            self.NSLAB = 85          # x 3 input-channel blocks = 255 persistent workgroups, one round on 256 CUs
+            import os
+            self.NSLAB = int(os.environ.get('SCIPNP_WGRAD_SLABS', 85))   # x 3 input-channel blocks = 255 persistent workgroups
         self.layers = ffdnet_layers(model)                # [(weight, bias)] tensors of the module (any device)
         self.w = [w.detach().to(dev, F32).contiguous().clone() for w, _ in self.layers]
         self.b = [b.detach().to(dev, F32).contiguous().clone() for _, b in self.layers]
