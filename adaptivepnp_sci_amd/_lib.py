@@ -71,7 +71,10 @@ SIGNATURES = {
     'scipnp_split_overflow': (_int, [_int, C.POINTER(_int), _vp]),
     'scipnp_c8_to_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_c8_add_to_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8s_ex': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8s_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_pack_conv3x3_split_device_scaled': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_upsample_zero_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_pixel_shuffle_bwd_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_pack_conv3x3_split_device': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_wgrad_split': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _flt, _vp]),
     'scipnp_conv_bias_grad_split': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _flt, _vp]),

@@ -67,6 +67,7 @@ struct SplitArgs {
     const char* wpk;     // packed split weights: [cig][tap][2][CoutP][8] fp16, then bias fp32 [CoutP]
     char* out;           // c8s (fp16 split) or fp32 c8
     const char* mask;    // c8s tensor of the output's shape: output zeroed where it is <= 0 (flag bit4; backward-data conv)
+    const char* res;     // c8s tensor of the output's shape added before the mask (flag bit1; skip-connection gradient)
     int CGin, CGout, CoutP_total, nsplit;
     int H, W;            // input size
     int Ho, Wo;          // conv output size (before any pixel shuffle)
@@ -253,6 +254,12 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                             if (relu) v[e] = fmaxf(v[e], 0.f);
                         }
                         const size_t pix = (size_t)y * Wo + x;
+                        if (a.flags & 2) {
+                            const char* rg = a.res + ((size_t)n * a.CGout + cog) * (2 * HWo * 16) + pix * 16 + 8 * lh;
+                            const f16x4 rh = *(const f16x4*)rg, rl = *(const f16x4*)(rg + HWo * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] + ((float)rh[e] + (float)rl[e] * CS_LO_INV);
+                        }
                         if (a.flags & 16) {
                             // ReLU'(activation): the stashed activation is >= 0, positive iff one of its halves is
                             const char* mg = a.mask + ((size_t)n * a.CGout + cog) * (2 * HWo * 16) + pix * 16 + 8 * lh;
@@ -346,8 +353,8 @@ c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, cha
 // device-side packing of (updated) fp32 master weights for the online finetune: forward layout, or the backward-data
 // convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (no bias).  One thread per (cig, tap, co, c8) element pair.
 __global__ void __launch_bounds__(256)
-pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, char* __restrict__ packed,
-                         int Cin_real, int Cout_real, int Kin, int KoutP, int transpose) {
+pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                         char* __restrict__ packed, int Cin_real, int Cout_real, int Kin, int KoutP, int transpose) {
     const size_t nw = (size_t)(Kin / 8) * 9 * KoutP * 8;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + KoutP) return;
@@ -363,9 +370,15 @@ pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ 
     const int in_ch = ig * 8 + c8;
     float val = 0.f;
     if (!transpose) {
-        if (o < Cout_real && in_ch < Cin_real) val = w[((size_t)o * Cin_real + in_ch) * 9 + tap];
+        if (o < Cout_real && in_ch < Cin_real) {
+            val = w[((size_t)o * Cin_real + in_ch) * 9 + tap];
+            if (scale) val = val * scale[o];
+        }
     } else {
-        if (o < Cin_real && in_ch < Cout_real) val = w[((size_t)in_ch * Cin_real + o) * 9 + (8 - tap)];
+        if (o < Cin_real && in_ch < Cout_real) {
+            val = w[((size_t)in_ch * Cin_real + o) * 9 + (8 - tap)];
+            if (scale) val = val * scale[in_ch];
+        }
     }
     if (!(fabsf(val) < 31.9f)) g_split_overflow = 1;
     const _Float16 hi = (_Float16)val;
@@ -414,8 +427,10 @@ extern "C" {
 
 int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out_c8s, int n, int C, int h, int w,
                          scipnp_stream_t s);
-int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
-                          int Cout, int h, int w, int flags, scipnp_stream_t s);
+int scipnp_pack_conv3x3_split_device_scaled(const float* w, const float* bias, const float* scale, void* packed, int Cin_real,
+                                            int Cout_real, int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
+                          const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
 size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
@@ -463,14 +478,15 @@ int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, i
 
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout, int h, int w,
                        int flags, scipnp_stream_t s) {
-    SCIPNP_REQUIRE(!(flags & 16), "ReLU-mask epilogue needs scipnp_conv3x3_c8s_ex");
-    return scipnp_conv3x3_c8s_ex(in_c8s, packed_split, out, nullptr, n, Cin, Cout, h, w, flags, s);
+    SCIPNP_REQUIRE(!(flags & (16 | 2)), "ReLU-mask / residual epilogues need scipnp_conv3x3_c8s_ex");
+    return scipnp_conv3x3_c8s_ex(in_c8s, packed_split, out, nullptr, nullptr, n, Cin, Cout, h, w, flags, s);
 }
 
-int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
-                          int Cout, int h, int w, int flags, scipnp_stream_t s) {
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
+                          const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in_c8s && packed_split && out, "null pointer");
     SCIPNP_REQUIRE(!(flags & 16) || (mask_c8s && !(flags & (4 | 8 | 32))), "flag bit4 needs mask_c8s and a c8s stride-1 output");
+    SCIPNP_REQUIRE(!(flags & 2) || (residual_c8s && !(flags & (4 | 8))), "flag bit1 needs residual_c8s and a stride-1 output");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
     SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(packed_split); SCIPNP_ALIGNED(out);
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 31), "image too large for 32-bit tile offsets");
@@ -478,7 +494,7 @@ int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* ou
     SCIPNP_REQUIRE(!(stride2 && shuf), "stride-2 and pixel-shuffle epilogue cannot be combined");
     SCIPNP_REQUIRE(!shuf || Cout % 32 == 0, "pixel-shuffle epilogue needs Cout %% 32 == 0 (got %d)", Cout);
     SplitArgs a;
-    a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out; a.mask = (const char*)mask_c8s;
+    a.in = (const char*)in_c8s; a.wpk = (const char*)packed_split; a.out = (char*)out; a.mask = (const char*)mask_c8s; a.res = (const char*)residual_c8s;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.CoutP_total = round_up_s(Cout, 32); a.nsplit = 1;
     a.H = h; a.W = w;
     a.Ho = stride2 ? (h - 1) / 2 + 1 : h;
@@ -524,6 +540,11 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
 
 int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* packed, int Cin_real, int Cout_real, int Cin,
                                      int Cout, int transpose_flip, scipnp_stream_t s) {
+    return scipnp_pack_conv3x3_split_device_scaled(w, bias, nullptr, packed, Cin_real, Cout_real, Cin, Cout, transpose_flip, s);
+}
+
+int scipnp_pack_conv3x3_split_device_scaled(const float* w, const float* bias, const float* scale, void* packed, int Cin_real,
+                                            int Cout_real, int Cin, int Cout, int transpose_flip, scipnp_stream_t s) {
     SCIPNP_REQUIRE(w && packed, "null pointer");
     SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
                    "bad channel counts");
@@ -531,7 +552,7 @@ int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* pa
     const int KoutP = round_up_s(transpose_flip ? Cin : Cout, 32);
     const size_t total = (size_t)(Kin / 8) * 9 * KoutP * 8 + KoutP;
     hipLaunchKernelGGL(pack_split_device_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, bias,
-                       (char*)packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
+                       scale, (char*)packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
     return launch_status("pack_split_device_kernel");
 }
 

@@ -94,6 +94,37 @@ unshuffle_bwd_kernel(const float* __restrict__ dshuf, float* __restrict__ dconv,
     d[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// the same two data movements on c8s tensors ([n][CG][2 planes][HW][8 fp16]): pure permutations, applied to the hi and
+// the lo' plane alike.  `img` = (n*CG + cg)*2 + plane.
+__global__ void __launch_bounds__(256)
+upsample_zero_c8s_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int h, int w, int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index over out (16 B each)
+    if (i >= total) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const size_t img = i / ((size_t)W * H);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!(X & 1) && !(Y & 1) && (Y >> 1) < h && (X >> 1) < w) v = in[(img * h + (Y >> 1)) * (size_t)w + (X >> 1)];
+    out[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+unshuffle_bwd_c8s_kernel(const _Float16* __restrict__ dshuf, _Float16* __restrict__ dconv, int CGs, int h, int w, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (n, conv channel group, plane, y, x)
+    if (i >= total) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const int plane = (int)((i / ((size_t)w * h)) & 1);
+    const int cog = (int)((i / ((size_t)w * h * 2)) % (4 * CGs));
+    const size_t n = i / ((size_t)w * h * 2 * 4 * CGs);
+    half8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = cog * 8 + e;
+        const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+        v[e] = dshuf[((((n * CGs + (c >> 3)) * 2 + plane) * (2 * h) + 2 * y + dy) * (size_t)(2 * w) + 2 * x + dx) * 8 + (c & 7)];
+    }
+    *(half8_t*)(dconv + i * 8) = v;
+}
+
 // measurement loss on planar RGB frames and its gradient (reference test_fastdvdnet.py:424-431):
 //   L = mean_{r,c} ( sum_t Phi_mosaic[r,c,t] * out[t][color(r,c)][r][c] - y_mosaic[r,c] )^2
 // thread = one Bayer quad; Phi, y plane-major ([B][4][M][N], [4][M][N]); dout planar, zero off the CFA sites.
@@ -226,6 +257,25 @@ int scipnp_pixel_shuffle_bwd_c8(const float* dshuf, float* dconv, int n, int Cs,
     hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, dshuf,
                        dconv, Cs / 8, h, w, total);
     return launch_status("unshuffle_bwd_kernel");
+}
+
+int scipnp_upsample_zero_c8s(const void* in, void* out, int n, int C, int h, int w, int H, int W, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && out && n > 0 && C % 8 == 0 && h > 0 && w > 0 && H >= 2 * h - 1 && W >= 2 * w - 1 && H <= 2 * h &&
+                   W <= 2 * w, "bad arguments");
+    SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(out);
+    const size_t total = (size_t)n * (C / 8) * 2 * H * W;
+    hipLaunchKernelGGL(upsample_zero_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       (const uint4*)in, (uint4*)out, h, w, H, W, total);
+    return launch_status("upsample_zero_c8s_kernel");
+}
+
+int scipnp_pixel_shuffle_bwd_c8s(const void* dshuf, void* dconv, int n, int Cs, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(dshuf && dconv && n > 0 && Cs % 8 == 0 && h > 0 && w > 0, "bad arguments");
+    SCIPNP_ALIGNED(dconv);
+    const size_t total = (size_t)n * (4 * Cs / 8) * 2 * h * w;
+    hipLaunchKernelGGL(unshuffle_bwd_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                       (const _Float16*)dshuf, (_Float16*)dconv, Cs / 8, h, w, total);
+    return launch_status("unshuffle_bwd_c8s_kernel");
 }
 
 int scipnp_fastdvd_loss_grad(const float* out, const float* Phi, const float* y, float* dout, double* loss_part, int M,

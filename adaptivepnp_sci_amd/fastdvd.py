@@ -170,17 +170,24 @@ def denblock_forward(pk, frames, sigma, out, b):
     return ops.fastdvd_finish(frames, b['x8'], out)
 
 
-def alloc_denblock_buffers_split(B, H, W, device):
+def alloc_denblock_buffers_split(B, H, W, device, alias=True):
     """buffers of the split-fp16 DenBlock: c8s activations (float16, same bytes as fp32 c8) plus the two fp32
-    PixelShuffle outputs and the fp32 8-channel tail."""
+    PixelShuffle outputs and the fp32 8-channel tail.  alias=False keeps every activation (finetune stash)."""
     h16 = lambda c, h, w: torch.empty(B, c // 8, 2, h, w, 8, dtype=torch.float16, device=device)  # noqa: E731
     f32 = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
     H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
-    a = [h16(64, H2, W2) for _ in range(3)]
-    d = [h16(128, H4, W4) for _ in range(3)]
-    return dict(t_in=h16(16, H, W), t96=h16(96, H, W), x0=h16(32, H, W), s32=h16(32, H, W), o32=h16(32, H, W),
-                x8=f32(8, H, W), sh64=f32(64, H2, W2), sh32=f32(32, H, W),
-                a0=a[0], a1=a[1], x1=a[0], d0=d[0], d1=d[1], x2=d[0], u0=d[1], u1=d[2], s64=a[1], c0=a[2], c1=a[1])
+    b = dict(t_in=h16(16, H, W), t96=h16(96, H, W), x0=h16(32, H, W), s32=h16(32, H, W), o32=h16(32, H, W),
+             x8=f32(8, H, W), sh64=f32(64, H2, W2), sh32=f32(32, H, W))
+    if alias:
+        a = [h16(64, H2, W2) for _ in range(3)]
+        d = [h16(128, H4, W4) for _ in range(3)]
+        b.update(a0=a[0], a1=a[1], x1=a[0], d0=d[0], d1=d[1], x2=d[0], u0=d[1], u1=d[2], s64=a[1], c0=a[2], c1=a[1])
+    else:
+        for k in ('a0', 'a1', 'x1', 's64', 'c0', 'c1'):
+            b[k] = h16(64, H2, W2)
+        for k in ('d0', 'd1', 'x2', 'u0', 'u1'):
+            b[k] = h16(128, H4, W4)
+    return b
 
 
 def denblock_forward_split(pk, frames, sigma, out, b):

@@ -213,9 +213,10 @@ class _DenBlockTrainer:
     """Master parameters, folded/packed weights, gradients and Adam state of one DenBlock (temp1 / temp2)."""
 
     # per layer: (input buffer key, output-gradient resolution divisor, stride2, shuffle)
-    def __init__(self, sd, prefix, device, lib):
+    def __init__(self, sd, prefix, device, lib, split=False):
         from .fastdvd import _LAYERS, _BN_EPS
         self.lib, self.dev, self.prefix = lib, device, prefix
+        self.split = split
         self.eps = _BN_EPS
         self.spec = _LAYERS
         self.sd_keys = []
@@ -237,6 +238,11 @@ class _DenBlockTrainer:
                     for _, _, ci, co, *_ in _LAYERS]
         self.bwd = [torch.empty(lib.scipnp_conv3x3_packed_floats(co, ci), dtype=F32, device=device)
                     for _, _, ci, co, *_ in _LAYERS]
+        if split:
+            self.fwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(ci, co), dtype=torch.uint8, device=device)
+                          for _, _, ci, co, *_ in _LAYERS]
+            self.bwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(co, ci), dtype=torch.uint8, device=device)
+                          for _, _, ci, co, *_ in _LAYERS]
         self.dense0 = torch.zeros(90, 12, 3, 3, dtype=F32, device=device)      # block-diagonal form of the grouped conv
         self.G = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
         self.dW = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
@@ -269,21 +275,34 @@ class _DenBlockTrainer:
                 _lib.check(lib.scipnp_bn_fold(_ptr(self.gamma[i]), _ptr(self.beta[i]), _ptr(self.mean[i]), _ptr(self.var[i]),
                                               self.eps, _ptr(self.scale[i]), _ptr(self.shift[i]), co_r, _s()), 'bn_fold')
                 sc, sh = self.scale[i], self.shift[i]
+            if self.split:
+                ops.pack_conv3x3_split_device(w, sh, self.fwd_s[i], cin, cout, scale=sc)
+                ops.pack_conv3x3_split_device(w, None, self.bwd_s[i], cin, cout, transpose=True, scale=sc)
+                continue
             _lib.check(lib.scipnp_pack_conv3x3_device_scaled(_ptr(w), _ptr(sh), _ptr(sc), _ptr(self.fwd[i]), ci_r, co_r, cin,
                                                              cout, 0, _s()), 'pack fwd')
             _lib.check(lib.scipnp_pack_conv3x3_device_scaled(_ptr(w), None, _ptr(sc), _ptr(self.bwd[i]), ci_r, co_r, cin,
                                                              cout, 1, _s()), 'pack bwd')
 
-    def grads_of_layer(self, i, x_in, dy, n, h, w, ws, bws, nslab):
-        """parameter gradients of layer i from its input activation and the gradient at its (BN) output"""
+    def grads_of_layer(self, i, x_in, dy, n, h, w, ws, bws, nslab, inv_scale=1.0):
+        """parameter gradients of layer i from its input activation and the gradient at its (BN) output; in split mode
+        x_in / dy are c8s tensors and dy carries the gradient times 1/inv_scale"""
         lib = self.lib
         key, bn, cin, cout, *_r = self.spec[i]
         wd = self.dense_w(i)
         co_r, ci_r = wd.shape[0], wd.shape[1]
-        _lib.check(lib.scipnp_conv3x3_wgrad(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin, cout,
-                                            h, w, _s()), 'wgrad')
-        if bn is not None:
+        if self.split:
+            _lib.check(lib.scipnp_conv3x3_wgrad_split(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin,
+                                                      cout, h, w, inv_scale, _s()), 'wgrad split')
+        else:
+            _lib.check(lib.scipnp_conv3x3_wgrad(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin, cout,
+                                                h, w, _s()), 'wgrad')
+        if bn is not None and self.split:
+            _lib.check(lib.scipnp_conv_bias_grad_split(_ptr(dy), _ptr(self.sdy[i]), _ptr(bws), n, co_r, cout, h, w, inv_scale,
+                                                       _s()), 'bgrad split')
+        elif bn is not None:
             _lib.check(lib.scipnp_conv_bias_grad(_ptr(dy), _ptr(self.sdy[i]), _ptr(bws), n, co_r, cout, h, w, _s()), 'bgrad')
+        if bn is not None:
             _lib.check(lib.scipnp_bn_fold_grads(_ptr(wd), _ptr(self.G[i]), _ptr(self.sdy[i]), _ptr(self.gamma[i]),
                                                 _ptr(self.mean[i]), _ptr(self.var[i]), self.eps, _ptr(self.dW[i]),
                                                 _ptr(self.dgamma[i]), _ptr(self.dbeta[i]), co_r, ci_r * 9, _s()), 'bn grads')
@@ -312,15 +331,29 @@ class _FastDVDTrainer:
         self.model_sd = model.state_dict()
         self.prefixed = any(k.startswith('module.') for k in self.model_sd)
         sd = _strip(self.model_sd)
-        self.blocks = {p: _DenBlockTrainer(sd, p, dev, self.lib) for p in ('temp1', 'temp2')}
+        self.split = getattr(eng, 'precision', 'f32') == 'f16x3'
+        self.blocks = {p: _DenBlockTrainer(sd, p, dev, self.lib, self.split) for p in ('temp1', 'temp2')}
         B, H, W = eng.B, eng.H, eng.W
-        self.stash = {p: alloc_denblock_buffers(B, H, W, dev, alias=False) for p in ('temp1', 'temp2')}
-        f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=F32, device=dev)  # noqa: E731
+        if self.split:
+            # forward stash, backward-data convolutions and weight gradients on the split-fp16 kernels; gradients travel
+            # pre-scaled by the power of two nearest H*W/2 (the loss carries 2/(H*W)) and are un-scaled exactly where
+            # they leave the convolution chain (weight / bias gradients, input-frame gradient)
+            from .fastdvd import alloc_denblock_buffers_split
+            self.NSLAB = 85
+            self.gscale = float(2.0 ** round(np.log2(H * W / 2.0)))
+            self.stash = {p: alloc_denblock_buffers_split(B, H, W, dev, alias=False) for p in ('temp1', 'temp2')}
+            f = lambda c, h, w: torch.empty(B, c // 8, 2, h, w, 8, dtype=torch.float16, device=dev)  # noqa: E731
+        else:
+            self.stash = {p: alloc_denblock_buffers(B, H, W, dev, alias=False) for p in ('temp1', 'temp2')}
+            f = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=F32, device=dev)  # noqa: E731
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         # gradient scratch (reused by both stages)
         self.g = dict(x8=f(8, H, W), f32a=f(32, H, W), f32b=f(32, H, W), f32c=f(32, H, W), f96=f(96, H, W), f16=f(16, H, W),
                       up64=f(64, H, W), h64a=f(64, H2, W2), h64b=f(64, H2, W2), h64c=f(64, H2, W2), h128=f(128, H2, W2),
                       q128a=f(128, H4, W4), q128b=f(128, H4, W4), q256=f(256, H4, W4))
+        if self.split:
+            self.g['x8_32'] = torch.empty(B, 1, H, W, 8, dtype=F32, device=dev)
+            self.g['f16_32'] = torch.empty(B, 2, H, W, 8, dtype=F32, device=dev)
         self.s1 = torch.empty(B, 3, H, W, dtype=F32, device=dev)
         self.out = torch.empty_like(self.s1)
         self.dout = torch.empty_like(self.s1)
@@ -339,7 +372,11 @@ class _FastDVDTrainer:
             b.pack()
 
     def forward(self, frames, sigma):
-        from .fastdvd import denblock_forward
+        from .fastdvd import denblock_forward, denblock_forward_split
+        if self.split:
+            denblock_forward_split(self.blocks['temp1'].fwd_s, frames, sigma, self.s1, self.stash['temp1'])
+            denblock_forward_split(self.blocks['temp2'].fwd_s, self.s1, sigma, self.out, self.stash['temp2'])
+            return
         denblock_forward(self.blocks['temp1'].fwd, frames, sigma, self.s1, self.stash['temp1'])
         denblock_forward(self.blocks['temp2'].fwd, self.s1, sigma, self.out, self.stash['temp2'])
 
@@ -355,6 +392,8 @@ class _FastDVDTrainer:
         """backward-data of layer i: out = [mask]( conv(dz; W_i^T flipped, BN scale folded) [+ residual] );
         (h, w) = size of dz (already zero-upsampled for stride-2 layers)."""
         _k, _bn, cin, cout, *_r = blk.spec[i]
+        if self.split:
+            return ops.conv3x3_c8s(dz, blk.bwd_s[i], cin, out=out, mask=mask, residual=residual)
         flags = (2 if residual is not None else 0) | (16 if mask is not None else 0)
         _lib.check(self.lib.scipnp_conv3x3_c8_ex(_ptr(dz), _ptr(blk.bwd[i]), _ptr(out), _ptr(residual), _ptr(mask), n, cout,
                                                  cin, h, w, flags, _s()), 'backward-data conv')
@@ -367,20 +406,35 @@ class _FastDVDTrainer:
         blk, a = self.blocks[name], self.stash[name]
         B, H, W = eng.B, eng.H, eng.W
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
-        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(i, x_in, dy, B, h, w, self.ws, self.bws, self.NSLAB)  # noqa: E731
-        _lib.check(lib.scipnp_fastdvd_finish_bwd(_ptr(dout), _ptr(g['x8']), B, H, W, _s()), 'finish_bwd')
+        sp = self.split
+        inv = 1.0 / self.gscale if sp else 1.0
+        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(i, x_in, dy, B, h, w, self.ws, self.bws, self.NSLAB, inv)  # noqa: E731
+
+        def unshuffle(src, dst, cs, h, w):
+            fn = lib.scipnp_pixel_shuffle_bwd_c8s if sp else lib.scipnp_pixel_shuffle_bwd_c8
+            _lib.check(fn(_ptr(src), _ptr(dst), B, cs, h, w, _s()), 'unshuffle')
+
+        def upzero(src, dst, c, h, w, hh, ww):
+            fn = lib.scipnp_upsample_zero_c8s if sp else lib.scipnp_upsample_zero_c8
+            _lib.check(fn(_ptr(src), _ptr(dst), B, c, h, w, hh, ww, _s()), 'upsample')
+
+        if sp:
+            _lib.check(lib.scipnp_fastdvd_finish_bwd(_ptr(dout), _ptr(g['x8_32']), B, H, W, _s()), 'finish_bwd')
+            ops.c8_scale_to_c8s(g['x8_32'], g['x8'], self.gscale)
+        else:
+            _lib.check(lib.scipnp_fastdvd_finish_bwd(_ptr(dout), _ptr(g['x8']), B, H, W, _s()), 'finish_bwd')
         gl(15, a['o32'], g['x8'], H, W)
         dy14 = self._bwd(blk, 15, g['x8'], g['f32a'], B, H, W, mask=a['o32'])
         gl(14, a['s32'], dy14, H, W)
         d_s32 = self._bwd(blk, 14, dy14, g['f32b'], B, H, W)                          # skip: also the gradient of x0
-        _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(_ptr(d_s32), _ptr(g['h128']), B, 32, H2, W2, _s()), 'unshuffle')
+        unshuffle(d_s32, g['h128'], 32, H2, W2)
         gl(13, a['c1'], g['h128'], H2, W2)
         dy12 = self._bwd(blk, 13, g['h128'], g['h64a'], B, H2, W2, mask=a['c1'])
         gl(12, a['c0'], dy12, H2, W2)
         dy11 = self._bwd(blk, 12, dy12, g['h64b'], B, H2, W2, mask=a['c0'])
         gl(11, a['s64'], dy11, H2, W2)
         d_s64 = self._bwd(blk, 11, dy11, g['h64c'], B, H2, W2)                        # skip: also the gradient of x1
-        _lib.check(lib.scipnp_pixel_shuffle_bwd_c8(_ptr(d_s64), _ptr(g['q256']), B, 64, H4, W4, _s()), 'unshuffle')
+        unshuffle(d_s64, g['q256'], 64, H4, W4)
         gl(10, a['u1'], g['q256'], H4, W4)
         dy9 = self._bwd(blk, 10, g['q256'], g['q128a'], B, H4, W4, mask=a['u1'])
         gl(9, a['u0'], dy9, H4, W4)
@@ -392,14 +446,14 @@ class _FastDVDTrainer:
         gl(6, a['d0'], dy6, H4, W4)
         dy5 = self._bwd(blk, 6, dy6, g['q128a'], B, H4, W4, mask=a['d0'])
         # stride-2 layer 5 (x1 @H/2 -> d0 @H/4): gradient = stride-1 backward of the zero-upsampled dy5
-        _lib.check(lib.scipnp_upsample_zero_c8(_ptr(dy5), _ptr(g['h128']), B, 128, H4, W4, H2, W2, _s()), 'upsample')
+        upzero(dy5, g['h128'], 128, H4, W4, H2, W2)
         gl(5, a['x1'], g['h128'], H2, W2)
         dy4 = self._bwd(blk, 5, g['h128'], g['h64a'], B, H2, W2, residual=d_s64, mask=a['x1'])
         gl(4, a['a1'], dy4, H2, W2)
         dy3 = self._bwd(blk, 4, dy4, g['h64b'], B, H2, W2, mask=a['a1'])
         gl(3, a['a0'], dy3, H2, W2)
         dy2 = self._bwd(blk, 3, dy3, g['h64a'], B, H2, W2, mask=a['a0'])
-        _lib.check(lib.scipnp_upsample_zero_c8(_ptr(dy2), _ptr(g['up64']), B, 64, H2, W2, H, W, _s()), 'upsample')
+        upzero(dy2, g['up64'], 64, H2, W2, H, W)
         gl(2, a['x0'], g['up64'], H, W)
         dy1 = self._bwd(blk, 2, g['up64'], g['f32c'], B, H, W, residual=d_s32, mask=a['x0'])
         gl(1, a['t96'], dy1, H, W)
@@ -407,6 +461,8 @@ class _FastDVDTrainer:
         gl(0, a['t_in'], dy0, H, W)
         if dframes is not None:
             d_tin = self._bwd(blk, 0, dy0, g['f16'], B, H, W)
+            if sp:
+                d_tin = ops.c8s_to_c8(d_tin, g['f16_32'], inv)
             _lib.check(lib.scipnp_fastdvd_unpack_bwd(_ptr(d_tin), _ptr(dout), _ptr(dframes), B, H, W, _s()), 'unpack_bwd')
 
     def adam(self, lr):
@@ -456,5 +512,6 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
             if trace is not None:
                 trace.append(val)
     tr.write_back()
-    eng.refresh(model)            # repack (fp32 or split-fp16) from the updated parameters
+    # the engine continues on the device-packed updated weights (no host repack)
+    eng.packed = {p: (b.fwd_s if tr.split else b.fwd) for p, b in tr.blocks.items()}
     return model

@@ -309,7 +309,7 @@ def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_s
 
 
 def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False, stride2=False, shuffle=False,
-                mask=None):
+                mask=None, residual=None):
     """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s, or fp32 c8 if f32_out / shuffle
     (shuffle: PixelShuffle(2)-ed fp32 c8 [n][Cout/32][2h][2w][8]).  mask: c8s tensor of the output's shape, output
     zeroed where it is not positive (backward-data convolution of the finetune)."""
@@ -324,19 +324,19 @@ def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False
             out = torch.empty(n, Cout // 8, 2, ho, wo, 8, device=x.device, dtype=torch.float16)
     fp32 = f32_out or shuffle
     flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
-             (0x100 if head else 0) | (16 if mask is not None else 0))
+             (0x100 if head else 0) | (16 if mask is not None else 0) | (2 if residual is not None else 0))
     _call('scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
-          _p(out, 'out', F32 if fp32 else torch.float16), _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags,
-          _stream())
+          _p(out, 'out', F32 if fp32 else torch.float16), _p(residual, 'residual', torch.float16),
+          _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
     return out
 
 
-def pack_conv3x3_split_device(w, bias, packed, Cin, Cout, transpose=False):
-    """device fp32 OIHW weights (+bias) -> `packed` (uint8 device buffer of scipnp_conv3x3_split_packed_bytes);
-    transpose=True packs the backward-data convolution (buffer sized for (Cout, Cin))."""
+def pack_conv3x3_split_device(w, bias, packed, Cin, Cout, transpose=False, scale=None):
+    """device fp32 OIHW weights (+bias, + per-output-channel BN scale) -> `packed` (uint8 device buffer of
+    scipnp_conv3x3_split_packed_bytes); transpose=True packs the backward-data convolution (buffer sized for (Cout, Cin))."""
     co, ci = w.shape[0], w.shape[1]
-    _call('scipnp_pack_conv3x3_split_device', _p(w, 'w'), _p(bias, 'bias'), _p(packed, 'packed', torch.uint8), ci, co, Cin,
-          Cout, int(bool(transpose)), _stream())
+    _call('scipnp_pack_conv3x3_split_device_scaled', _p(w, 'w'), _p(bias, 'bias'), _p(scale, 'scale'),
+          _p(packed, 'packed', torch.uint8), ci, co, Cin, Cout, int(bool(transpose)), _stream())
     return packed
 
 

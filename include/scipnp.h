@@ -213,15 +213,20 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
 /* split-fp16 conv with a ReLU-mask epilogue (flag bit4 = 16): out = conv(in) where mask_c8s (a c8s tensor of the
  * output's shape, the stashed forward activation) is positive, else 0 -- the backward-data convolution of the online
  * finetune on the fp16 MFMA (packages/ffdnet/test_ffdnet_ipol.py:296 `loss.backward()`).  Other flags as
- * scipnp_conv3x3_c8s; mask_c8s may be NULL when bit4 is clear. */
-int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* mask_c8s, int n, int Cin,
-                          int Cout, int h, int w, int flags, scipnp_stream_t s);
+ * scipnp_conv3x3_c8s; mask_c8s may be NULL when bit4 is clear.  Flag bit1 = 2 adds residual_c8s (a c8s tensor of
+ * the output's shape: the gradient arriving over a skip connection) before the mask. */
+int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
+                          const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
 /* device-side packing of fp32 master weights (device pointers) into the split layout: transpose_flip = 0 forward
  * (with bias), 1 the backward-data convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (Cin/Cout are the FORWARD
  * conv's padded channel counts; no bias).  Raises the split-overflow flag if |w| >= 31.9. */
 int scipnp_pack_conv3x3_split_device(const float* w, const float* bias, void* packed, int Cin_real, int Cout_real,
                                      int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
+/* same with a folded eval-mode BatchNorm: forward W*scale[co] (bias = BN shift), backward-data W*scale[co] as well */
+int scipnp_pack_conv3x3_split_device_scaled(const float* w, const float* bias, const float* scale, void* packed,
+                                            int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
+                                            scipnp_stream_t s);
 
 /* weight / bias gradients from c8s operands on the fp16 MFMA (error-compensated, transposing LDS reads); same
  * workspace and slab scheme as scipnp_conv3x3_wgrad / scipnp_conv_bias_grad.  dz_c8s carries the gradient
@@ -304,6 +309,9 @@ int scipnp_upsample_zero_c8(const float* in, float* out, int n, int C, int h, in
                             scipnp_stream_t s);
 /* PixelShuffle(2) backward: dshuf [n][Cs/8][2h][2w][8] -> dconv [n][4Cs/8][h][w][8] */
 int scipnp_pixel_shuffle_bwd_c8(const float* dshuf, float* dconv, int n, int Cs, int h, int w, scipnp_stream_t s);
+/* the same two permutations on c8s tensors (applied to the hi and lo' planes alike) */
+int scipnp_upsample_zero_c8s(const void* in, void* out, int n, int C, int h, int w, int H, int W, scipnp_stream_t s);
+int scipnp_pixel_shuffle_bwd_c8s(const void* dshuf, void* dconv, int n, int Cs, int h, int w, scipnp_stream_t s);
 /* measurement loss on planar frames [B][3][H][W] and its gradient (zero off the CFA sites); loss partials as in
  * scipnp_ffdnet_loss_grad                                       -- test_fastdvdnet.py:424-431 */
 int scipnp_fastdvd_loss_grad(const float* out, const float* Phi, const float* y, float* dout, double* loss_part,
