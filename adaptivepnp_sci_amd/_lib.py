@@ -129,8 +129,17 @@ def check(rc, what):
         raise ScipnpError(f'{what}: {msg} (code {rc})')
 
 
+_gpu_ok = False
+
+
 def require_gpu():
+    global _gpu_ok
+    if _gpu_ok:
+        return
     import torch
+    if torch.cuda.is_available():
+        _gpu_ok = True
+        return
     if not torch.cuda.is_available():
         raise ScipnpError('no MI355X/ROCm device visible: the scipnp hot path runs only on the GPU '
                           '(no CPU fallback by design)')

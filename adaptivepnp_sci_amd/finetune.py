@@ -28,6 +28,15 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _carve(flat, like):
+    """consecutive views of `flat` shaped like the tensors in `like` (one Adam launch covers them all)"""
+    out, off = [], 0
+    for t in like:
+        out.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    return out
+
+
 class _FFDNetTrainer:
     """Device master copies of the parameters, packed forward/backward weights, Adam state and the
     activation stash of one FFDNetEngine geometry."""
@@ -42,8 +51,16 @@ class _FFDNetTrainer:
             import os
             self.NSLAB = int(os.environ.get('SCIPNP_WGRAD_SLABS', 85))   # x 3 input-channel blocks = 255 persistent workgroups
         self.layers = ffdnet_layers(model)                # [(weight, bias)] tensors of the module (any device)
-        self.w = [w.detach().to(dev, F32).contiguous().clone() for w, _ in self.layers]
-        self.b = [b.detach().to(dev, F32).contiguous().clone() for _, b in self.layers]
+        srcs = [w.detach() for w, _ in self.layers] + [b.detach() for _, b in self.layers]
+        total = sum(t.numel() for t in srcs)
+        # master parameters, gradients and Adam moments live in four flat buffers: one Adam launch per step
+        self.flat_p, self.flat_g = torch.empty(total, dtype=F32, device=dev), torch.empty(total, dtype=F32, device=dev)
+        self.flat_m, self.flat_v = torch.zeros(total, dtype=F32, device=dev), torch.zeros(total, dtype=F32, device=dev)
+        views = _carve(self.flat_p, srcs)
+        for v_, t in zip(views, srcs):
+            v_.copy_(t)
+        nl = len(self.layers)
+        self.w, self.b = views[:nl], views[nl:]
         self.nb, self.nc = eng.nb, eng.nc
         B, M, N, nc = eng.B, eng.M, eng.N, eng.nc
         self.cin = [16] + [nc] * (self.nb - 1)
@@ -57,10 +74,8 @@ class _FFDNetTrainer:
         self.acts = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(self.nb - 1)]
         self.dz = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(2)]
         self.gout = torch.empty(B, 2, M, N, 8, dtype=F32, device=dev)
-        self.dw = [torch.empty_like(w) for w in self.w]
-        self.db = [torch.empty_like(b) for b in self.b]
-        self.m = [torch.zeros_like(t) for t in self.w + self.b]
-        self.v = [torch.zeros_like(t) for t in self.w + self.b]
+        gviews = _carve(self.flat_g, srcs)
+        self.dw, self.db = gviews[:nl], gviews[nl:]
         ws = max(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, self.NSLAB) for ci, co in zip(self.cin, self.cout))
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty((nc // 8) * 64 * 8, dtype=F32, device=dev)
@@ -171,11 +186,9 @@ class _FFDNetTrainer:
 
     def adam(self, lr):
         self.step += 1
-        params = self.w + self.b
-        grads = self.dw + self.db
-        for p, g, m, v in zip(params, grads, self.m, self.v):
-            _lib.check(self.lib.scipnp_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), 0.9, 0.999,
-                                                 1e-8, self.step, _s()), 'scipnp_adam_step')
+        _lib.check(self.lib.scipnp_adam_step(_ptr(self.flat_p), _ptr(self.flat_g), _ptr(self.flat_m), _ptr(self.flat_v),
+                                             self.flat_p.numel(), float(lr), 0.9, 0.999, 1e-8, self.step, _s()),
+                   'scipnp_adam_step')
 
     def write_back(self):
         """the reference mutates `model` in place and returns it (test_ffdnet_ipol.py:356-357)"""
@@ -220,17 +233,38 @@ class _DenBlockTrainer:
         self.eps = _BN_EPS
         self.spec = _LAYERS
         self.sd_keys = []
-        self.W, self.gamma, self.beta, self.mean, self.var = [], [], [], [], []
-        for key, bn, cin, cout, *_ in _LAYERS:
-            wk = f'{prefix}.{key}.weight'
-            self.W.append(sd[wk].detach().to(device, F32).contiguous().clone())
+        # parameter order = Adam order: all conv weights, then (gamma, beta) of every BatchNorm; parameters, gradients and
+        # Adam moments live in four flat buffers (views below), so one Adam launch per step covers the whole block
+        names, srcs = [], []
+        for key, bn, *_r in _LAYERS:
+            names.append(f'{prefix}.{key}.weight')
+        for key, bn, *_r in _LAYERS:
             if bn is not None:
-                self.gamma.append(sd[f'{prefix}.{bn}.weight'].detach().to(device, F32).clone())
-                self.beta.append(sd[f'{prefix}.{bn}.bias'].detach().to(device, F32).clone())
+                names += [f'{prefix}.{bn}.weight', f'{prefix}.{bn}.bias']
+        srcs = [sd[k].detach() for k in names]
+        total = sum(t.numel() for t in srcs)
+        self.flat_p, self.flat_g = (torch.empty(total, dtype=F32, device=device) for _ in range(2))
+        self.flat_m, self.flat_v = (torch.zeros(total, dtype=F32, device=device) for _ in range(2))
+        pv, gv = _carve(self.flat_p, srcs), _carve(self.flat_g, srcs)
+        for v_, t in zip(pv, srcs):
+            v_.copy_(t)
+        nl = len(_LAYERS)
+        self.W = pv[:nl]
+        self.gamma, self.beta, self.mean, self.var = [], [], [], []
+        self.dgamma, self.dbeta = [], []
+        j = nl
+        for key, bn, cin, cout, *_ in _LAYERS:
+            if bn is not None:
+                self.gamma.append(pv[j]); self.beta.append(pv[j + 1])
+                self.dgamma.append(gv[j]); self.dbeta.append(gv[j + 1])
+                j += 2
                 self.mean.append(sd[f'{prefix}.{bn}.running_mean'].detach().to(device, F32).clone())
                 self.var.append(sd[f'{prefix}.{bn}.running_var'].detach().to(device, F32).clone())
             else:
                 self.gamma.append(None); self.beta.append(None); self.mean.append(None); self.var.append(None)
+                self.dgamma.append(None); self.dbeta.append(None)
+        self.params = list(zip(names, pv))
+        self._gW = gv[:nl]
         n = len(_LAYERS)
         self.scale = [None if g is None else torch.empty_like(g) for g in self.gamma]
         self.shift = [None if g is None else torch.empty_like(g) for g in self.gamma]
@@ -245,18 +279,10 @@ class _DenBlockTrainer:
                           for _, _, ci, co, *_ in _LAYERS]
         self.dense0 = torch.zeros(90, 12, 3, 3, dtype=F32, device=device)      # block-diagonal form of the grouped conv
         self.G = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
-        self.dW = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
-        self.dW0_grouped = torch.empty_like(self.W[0])
+        # dW[i] (i >= 1) and the grouped form of dW[0] are the flat gradient views; dW[0] itself is the dense scratch
+        self.dW = [torch.empty_like(self.dense0)] + self._gW[1:]
+        self.dW0_grouped = self._gW[0]
         self.sdy = [None if g is None else torch.empty_like(g) for g in self.gamma]
-        self.dgamma = [None if g is None else torch.empty_like(g) for g in self.gamma]
-        self.dbeta = [None if g is None else torch.empty_like(g) for g in self.gamma]
-        self.params = [(f'{prefix}.{key}.weight', self.W[i]) for i, (key, *_r) in enumerate(_LAYERS)]
-        for i, (key, bn, *_r) in enumerate(_LAYERS):
-            if bn is not None:
-                self.params.append((f'{prefix}.{bn}.weight', self.gamma[i]))
-                self.params.append((f'{prefix}.{bn}.bias', self.beta[i]))
-        self.m = [torch.zeros_like(p) for _, p in self.params]
-        self.v = [torch.zeros_like(p) for _, p in self.params]
 
     def dense_w(self, i):
         if i != 0:
@@ -311,13 +337,6 @@ class _DenBlockTrainer:
         if i == 0:
             for g in range(3):
                 self.dW0_grouped[g * 30:(g + 1) * 30] = self.dW[0][g * 30:(g + 1) * 30, g * 4:(g + 1) * 4]
-
-    def grad_list(self):
-        out = [self.dW0_grouped] + self.dW[1:]
-        for i, (key, bn, *_r) in enumerate(self.spec):
-            if bn is not None:
-                out += [self.dgamma[i], self.dbeta[i]]
-        return out
 
 
 class _FastDVDTrainer:
@@ -468,15 +487,37 @@ class _FastDVDTrainer:
     def adam(self, lr):
         self.step += 1
         for blk in self.blocks.values():
-            for (_, p), gr, m, v in zip(blk.params, blk.grad_list(), blk.m, blk.v):
-                _lib.check(self.lib.scipnp_adam_step(_ptr(p), _ptr(gr), _ptr(m), _ptr(v), p.numel(), float(lr), 0.9, 0.999,
-                                                     1e-8, self.step, _s()), 'scipnp_adam_step')
+            _lib.check(self.lib.scipnp_adam_step(_ptr(blk.flat_p), _ptr(blk.flat_g), _ptr(blk.flat_m), _ptr(blk.flat_v),
+                                                 blk.flat_p.numel(), float(lr), 0.9, 0.999, 1e-8, self.step, _s()),
+                       'scipnp_adam_step')
 
     def write_back(self):
         with torch.no_grad():
             for blk in self.blocks.values():
                 for key, p in blk.params:
                     self.model_sd[('module.' + key) if self.prefixed else key].copy_(p)
+
+
+class NoisePrefetch:
+    """The reference draws the finetune noise with np.random.normal(0, 5/255, (B,3,H,W)) from the GLOBAL NumPy RNG, one
+    draw per finetune event (utils/utils_image.py:183-192) -- 6.3 M float64 normals, ~65 ms of host time at 512x512x8.
+    When the solver knows from its schedule that `count` events WILL fire, this worker thread makes exactly those
+    draws, in order, while the GPU is busy with the preceding iterations (NumPy releases the GIL while it fills the
+    array); the stream of values is the one a synchronous caller would have obtained."""
+
+    def __init__(self, shape, count):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=2)
+        self.t = threading.Thread(target=self._run, args=(tuple(shape), int(count)), daemon=True)
+        self.t.start()
+
+    def _run(self, shape, count):
+        for _ in range(count):
+            self.q.put(np.random.normal(0, 5 / 255, shape))
+
+    def get(self):
+        return self.q.get()
 
 
 def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None,
@@ -489,17 +530,18 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
     _lib.require_gpu()
     steps = [update_per_iter] if isinstance(update_per_iter, int) else list(update_per_iter)
     lrs = [lr_] if isinstance(update_per_iter, int) else list(lr_)
-    v_np = frames.detach().cpu().numpy()
     if noise is None:
-        noise = np.random.normal(0, 5 / 255, v_np.shape)
-    v_plus = (frames + torch.from_numpy(v_np + noise).float().to(frames.device)).contiguous()
+        noise = np.random.normal(0, 5 / 255, tuple(frames.shape))
+    # frames + float32(float64(frames) + noise): the float64 sum and its rounding are done on the device (same IEEE result)
+    noise_d = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float64)).to(frames.device)
+    v_plus = (frames + (frames.double() + noise_d).float()).contiguous()
+    del noise_d
     tr = _FastDVDTrainer(model, eng)
     tr.pack()
     for n_steps, lr_i in zip(steps, lrs):
         tr.step = 0
         for blk in tr.blocks.values():                        # a new Adam per lr group (:385)
-            for m, v in zip(blk.m, blk.v):
-                m.zero_(); v.zero_()
+            blk.flat_m.zero_(); blk.flat_v.zero_()
         for _ in range(n_steps):
             tr.forward(v_plus, sigma)
             loss = tr.loss_and_grad(y_pm, Phi_pm)

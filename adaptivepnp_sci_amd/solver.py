@@ -114,6 +114,7 @@ class AdmmRun:
         self.out_rgb = None
         self.profile_events = None       # bench.py: list receiving (start,end) events around the body convs
         self.phi_events = None           # bench.py: list receiving (start,end) events around the projection launch
+        self.noise_source = None         # finetune.NoisePrefetch set by _run_schedule (FastDVDnet finetune noise)
         # ---- prior workspaces
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
@@ -210,7 +211,8 @@ class AdmmRun:
             if gate and self.two_stage and (self.update_i < self.update_times or self.update_times < 0):
                 from .finetune import fastdvdnet_online_finetune
                 fastdvdnet_online_finetune(self.model, self.eng, net_in, self.y, self.Phi, nsig, self.lr_,
-                                           self.update_per_iter, logf=self.logf)
+                                           self.update_per_iter, logf=self.logf,
+                                           noise=None if self.noise_source is None else self.noise_source.get())
                 self.update_i += 1
             src_rgb, src_c8 = self.eng.forward(net_in, nsig), None
         iqa_here = self.iqa and self.two_stage
@@ -255,8 +257,23 @@ class AdmmRun:
         return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
 
 
+def _finetune_events(run, total):
+    """number of FastDVDnet finetune events the schedule will fire (the gate of _cnn_step, evaluated ahead of time)"""
+    if not (run.update_ and run.two_stage and run.denoiser == 'fastdvd_color'):
+        return 0
+    n = 0
+    for k in range(run.k, run.k + total):
+        if k > run.inital_iter and k % run.interval_iter == 0 and (run.update_i + n < run.update_times or run.update_times < 0):
+            n += 1
+    return n
+
+
 def _run_schedule(run, sigma, iter_max):
     total = sum(iter_max)
+    n_events = _finetune_events(run, total)
+    if n_events:
+        from .finetune import NoisePrefetch
+        run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
     for idx, nsig in enumerate(sigma):
         for _ in range(iter_max[idx]):
             run.step(nsig, last=(run.k == total - 1))

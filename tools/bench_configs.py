@@ -63,3 +63,27 @@ y, Phi, orig = synth.make_problem(256, 256, 16, 0)
 net = FFDNet(); net.load_state_dict(sd)
 run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net)
 print(f'FFDNet f16x3 tile 256x256x16: {timeit(run, 25/255, 20):.3f} ms/iteration')
+
+# whole adaptive reconstructions with the reference drivers' schedules (Beauty scene): wall time of the solver call
+from adaptivepnp_sci_amd import twoStageAdmm_denoise_bayer
+y, Phi, orig = synth.make_problem(512, 512, 8, 0)
+os.environ['SCIPNP_CONV_PRECISION'] = 'f16x3'
+for name, kw in (('FFDNet [15,6,4] its, finetune at k=15 (2 Adam steps)',
+                  dict(denoiser='ffdnet_color', iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255], lr_=2e-6,
+                       interval_iter=15, update_=True, update_per_iter=2)),
+                 ('FFDNet [15,6,4] its, no finetune',
+                  dict(denoiser='ffdnet_color', iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255])),
+                 ('FastDVDnet [18] its, finetune at k=9 (2 Adam steps, update_times=1)',
+                  dict(denoiser='fastdvd_color', iter_max=[18], sigma=[8 / 255], lr_=2e-6, interval_iter=9, update_=True,
+                       update_per_iter=2, update_times=1)),
+                 ('FastDVDnet [18] its, no finetune', dict(denoiser='fastdvd_color', iter_max=[18], sigma=[8 / 255]))):
+    ts = []
+    for rep in range(3):
+        if kw['denoiser'] == 'ffdnet_color':
+            model = FFDNet(); model.load_state_dict(sd)
+        else:
+            model = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        twoStageAdmm_denoise_bayer(y, Phi, x0_bayer=warm, X_orig=orig, model_denoise=model, logf=io.StringIO(), **kw)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f'whole reconstruction 512x512x8, {name}: {min(ts):.1f} ms (runs: {" ".join(f"{t:.0f}" for t in ts)})')

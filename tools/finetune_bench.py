@@ -9,9 +9,15 @@ from adaptivepnp_sci_amd.nets import FFDNet
 g = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'ffdnet_color_weights.npz'))
 sd = {k: torch.from_numpy(g[k]) for k in g.files}
 y, Phi, orig = synth.make_problem(512, 512, 8, 0)
-net = FFDNet(); net.load_state_dict(sd)
-run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,
-              inital_iter=0, interval_iter=1)
+if os.environ.get('FT_DENOISER', 'ffdnet') == 'fastdvd':
+    from oracle.nets import synth_fastdvdnet_weights          # synthetic weights only (test infrastructure as data source)
+    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    run = AdmmRun(y, Phi, 'fastdvd_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,
+                  inital_iter=0, interval_iter=1)
+else:
+    net = FFDNet(); net.load_state_dict(sd)
+    run = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,
+                  inital_iter=0, interval_iter=1)
 run.step(25 / 255)
 ts = []
 for _ in range(int(os.environ.get('FT_REPS', 2))):
