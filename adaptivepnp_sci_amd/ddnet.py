@@ -108,22 +108,32 @@ def _dense_from_grouped(w, groups):
 
 
 def _pack(w, cin, cout, device, split):
+    buf = ops.packed_buffer(cin, cout, device, split)
     if split:
-        return ops.pack_conv3x3_split(w, None, Cin=cin, Cout=cout, device=device)
-    return ops.pack_conv3x3(w, None, None, None, Cin=cin, Cout=cout, device=device)
+        return ops.pack_conv3x3_split_device(w, None, buf, cin, cout)
+    return ops.pack_conv3x3_device(w, None, buf, cin, cout)
 
 
 def pack_block(sd, prefix, ch_each_frame, device, split):
+    """one upload of the block's weights, packing on the device"""
+    device = torch.device(device)
+    keys = [f'{prefix}.{key}.weight' for key, *_r in _LAYERS]
+    fusion = f'{prefix}.fusion.convblock.0.weight' in sd
+    if fusion:
+        keys += [f'{prefix}.fusion.convblock.0.weight', f'{prefix}.fusion.convblock.2.weight']
+    dev = ops.device_params([sd[k] for k in keys], device)
     packed = []
-    for key, cin, cout, _r, _s, _sh in _LAYERS:
-        w = sd[f'{prefix}.{key}.weight'].detach().float().cpu()
+    for (key, cin, cout, _r, _s, _sh), w in zip(_LAYERS, dev):
         if cin is None:
-            w = _dense_from_grouped(w, 3)
-            cin = _p8(3 * ch_each_frame)
-        packed.append(_pack(w, cin, cout, device, split))
-    if f'{prefix}.fusion.convblock.0.weight' in sd:
-        packed.append(_pack(sd[f'{prefix}.fusion.convblock.0.weight'].detach().float().cpu(), 8, 8, device, split))
-        packed.append(_pack(sd[f'{prefix}.fusion.convblock.2.weight'].detach().float().cpu(), 8, 8, device, split))
+            dense = torch.zeros(w.shape[0], w.shape[1] * 3, 3, 3, dtype=w.dtype, device=device)
+            per = w.shape[0] // 3
+            for g in range(3):                                   # grouped -> block-diagonal (data movement only)
+                dense[g * per:(g + 1) * per, g * w.shape[1]:(g + 1) * w.shape[1]] = w[g * per:(g + 1) * per]
+            w, cin = dense, _p8(3 * ch_each_frame)
+        packed.append(_pack(w.contiguous(), cin, cout, device, split))
+    if fusion:
+        packed.append(_pack(dev[-2].contiguous(), 8, 8, device, split))
+        packed.append(_pack(dev[-1].contiguous(), 8, 8, device, split))
     return packed
 
 

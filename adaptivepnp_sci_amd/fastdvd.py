@@ -105,23 +105,35 @@ def _strip(sd):
 
 def pack_denblock(sd, prefix, device, split=False):
     """Packed weights of one DenBlock from a (stripped) state dict; eval-mode BatchNorm folded:
-    y = conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps)).  split=True packs for the
-    error-compensated split-fp16 kernels (conv_split.hip)."""
+    y = conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps)).  The parameters travel to the device in one
+    upload; the fold (scipnp_bn_fold) and the packing (scipnp_pack_conv3x3_device_scaled / _split_device_scaled) run
+    there.  split=True packs for the error-compensated split-fp16 kernels (conv_split.hip)."""
+    device = torch.device(device)
+    names = []
+    for key, bn, *_r in _LAYERS:
+        names.append(f'{prefix}.{key}.weight')
+        if bn is not None:
+            names += [f'{prefix}.{bn}.weight', f'{prefix}.{bn}.bias', f'{prefix}.{bn}.running_mean', f'{prefix}.{bn}.running_var']
+    dev = dict(zip(names, ops.device_params([sd[k] for k in names], device)))
     packed = []
     for key, bn, cin, cout, _relu, _s2, _shuf in _LAYERS:
-        w = sd[f'{prefix}.{key}.weight'].detach().float().cpu()
+        w = dev[f'{prefix}.{key}.weight']
         if key == 'inc.convblock.0':
-            w = _dense_from_grouped(w, 3)
+            dense = torch.zeros(w.shape[0], w.shape[1] * 3, 3, 3, dtype=w.dtype, device=device)
+            per = w.shape[0] // 3
+            for g in range(3):                                   # grouped -> block-diagonal (data movement only)
+                dense[g * per:(g + 1) * per, g * w.shape[1]:(g + 1) * w.shape[1]] = w[g * per:(g + 1) * per]
+            w = dense
         scale = shift = None
         if bn is not None:
-            g, b_ = sd[f'{prefix}.{bn}.weight'].float().cpu(), sd[f'{prefix}.{bn}.bias'].float().cpu()
-            mu, var = sd[f'{prefix}.{bn}.running_mean'].float().cpu(), sd[f'{prefix}.{bn}.running_var'].float().cpu()
-            scale = g / torch.sqrt(var + _BN_EPS)
-            shift = b_ - mu * scale
+            scale, shift = torch.empty_like(dev[f'{prefix}.{bn}.weight']), torch.empty_like(dev[f'{prefix}.{bn}.weight'])
+            ops.bn_fold(dev[f'{prefix}.{bn}.weight'], dev[f'{prefix}.{bn}.bias'], dev[f'{prefix}.{bn}.running_mean'],
+                        dev[f'{prefix}.{bn}.running_var'], _BN_EPS, scale, shift)
+        buf = ops.packed_buffer(cin, cout, device, split)
         if split:
-            packed.append(ops.pack_conv3x3_split(w, None, Cin=cin, Cout=cout, device=device, bn_scale=scale, bn_shift=shift))
+            packed.append(ops.pack_conv3x3_split_device(w, shift, buf, cin, cout, scale=scale))
         else:
-            packed.append(ops.pack_conv3x3(w, None, scale, shift, Cin=cin, Cout=cout, device=device))
+            packed.append(ops.pack_conv3x3_device(w, shift, buf, cin, cout, scale=scale))
     return packed
 
 

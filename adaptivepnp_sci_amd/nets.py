@@ -85,19 +85,20 @@ class FFDNetEngine:
         self.nc = layers[0][0].shape[0]
         if layers[0][0].shape[1] != 13 or layers[-1][0].shape[0] != 12 or self.nc % 8:
             raise ValueError('FFDNetEngine supports the colour network (13 -> nc -> 12 channels, nc % 8 == 0)')
-        self.packed = []
-        for i, (w, b) in enumerate(layers):
+        # weights travel to the device in one upload and are packed there (scipnp_pack_conv3x3_device /
+        # _split_device): both layouts are kept, the fp32 one serves the C entry scipnp_ffdnet_forward
+        dev_t = ops.device_params([w for w, _ in layers] + [b for _, b in layers], torch.device(self.device))
+        ws, bs = dev_t[:self.nb], dev_t[self.nb:]
+        split = self.precision == 'f16x3'
+        self.packed, self.packed_split = [], ([] if split else None)
+        for i in range(self.nb):
             cin = 16 if i == 0 else self.nc
             cout = 16 if i == self.nb - 1 else self.nc
-            self.packed.append(ops.pack_conv3x3(w, b, Cin=cin, Cout=cout, device=self.device))
+            self.packed.append(ops.pack_conv3x3_device(ws[i], bs[i], ops.packed_buffer(cin, cout, self.device, False), cin, cout))
+            if split:
+                self.packed_split.append(ops.pack_conv3x3_split_device(ws[i], bs[i], ops.packed_buffer(cin, cout, self.device, True),
+                                                                       cin, cout))
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
-        self.packed_split = None
-        if self.precision == 'f16x3':
-            self.packed_split = []
-            for i, (w, b) in enumerate(layers):
-                cin = 16 if i == 0 else self.nc
-                cout = 16 if i == self.nb - 1 else self.nc
-                self.packed_split.append(ops.pack_conv3x3_split(w, b, Cin=cin, Cout=cout, device=self.device))
 
     def adopt(self, packed_f32, packed_split=None):
         """Take over device-packed weights (the online finetune packs its updated master weights on the GPU,
