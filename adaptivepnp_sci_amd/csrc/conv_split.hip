@@ -71,7 +71,8 @@ struct SplitArgs {
     int CGin, CGout, CoutP_total, nsplit;
     int H, W;            // input size
     int Ho, Wo;          // conv output size (before any pixel shuffle)
-    int flags;           // bit0 ReLU, bit4 (16) ReLU-mask, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle store (fp32 only)
+    int flags;           // bit0 ReLU, bit1 (2) residual, bit4 (16) ReLU-mask, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle
+                         // store (fp32 c8, or c8s with bit6 (64), where the residual has the shuffled shape)
 };
 
 // set when a value leaves fp16's finite range on its way into the c8s format (results are then invalid and the
@@ -239,7 +240,54 @@ conv3x3_c8s_kernel(const SplitArgs a) {
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         const int y = y0 + 2 * wv + pb;
-        if (y < Ho && x < Wo) {
+        if (SHUF && (a.flags & 64)) {
+            // PixelShuffle(2) store straight into c8s, with the skip tensor added (flag bit1): a lane holds, per conv
+            // channel group g, the four sub-pixels e of OUTPUT channel 2g+lh; v_permlane32_swap exchanges the bottom-row
+            // values of lane (li, 0) with the top-row values of lane (li, 1), after which lane (li, lh) owns all eight
+            // channels of output group (split*COB+cb) at the two pixels (2y+lh, 2x), (2y+lh, 2x+1).
+            if (y < Ho && x < Wo) {
+                const int CGs = a.CGout >> 2;
+                const size_t HWs = 4 * HWo;
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb) {
+                    const int og = split * COB + cb;
+                    if (og < CGs) {
+                        float o8[2][8];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bs = *(const f32x4*)(bias + (og * 4 + g) * 8 + 4 * lh);
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[pb][cb][4 * g + e] * CS_LO_INV + bs[e];
+                                if (relu) v[e] = fmaxf(v[e], 0.f);
+                            }
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[dx]), __float_as_uint(v[2 + dx]),
+                                                                                false, false);
+                                o8[dx][2 * g] = __uint_as_float(r[0]);
+                                o8[dx][2 * g + 1] = __uint_as_float(r[1]);
+                            }
+                        }
+                        const size_t pix = (size_t)(2 * y + lh) * (2 * Wo) + 2 * x;
+                        const size_t grp = ((size_t)n * CGs + og) * (2 * HWs * 16);
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            if (a.flags & 2) {
+                                const char* rg = a.res + grp + (pix + dx) * 16;
+                                const f16x8 rh = *(const f16x8*)rg, rl = *(const f16x8*)(rg + HWs * 16);
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) o8[dx][c] = o8[dx][c] + ((float)rh[c] + (float)rl[c] * CS_LO_INV);
+                            }
+                            char* og_ptr = a.out + grp + (pix + dx) * 16;
+                            split_store(o8[dx][0], o8[dx][1], o8[dx][2], o8[dx][3], og_ptr, og_ptr + HWs * 16);
+                            split_store(o8[dx][4], o8[dx][5], o8[dx][6], o8[dx][7], og_ptr + 8, og_ptr + HWs * 16 + 8);
+                        }
+                    }
+                }
+            }
+        } else if (y < Ho && x < Wo) {
 #pragma unroll
             for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
@@ -486,7 +534,9 @@ int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* ou
                           const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in_c8s && packed_split && out, "null pointer");
     SCIPNP_REQUIRE(!(flags & 16) || (mask_c8s && !(flags & (4 | 8 | 32))), "flag bit4 needs mask_c8s and a c8s stride-1 output");
-    SCIPNP_REQUIRE(!(flags & 2) || (residual_c8s && !(flags & (4 | 8))), "flag bit1 needs residual_c8s and a stride-1 output");
+    SCIPNP_REQUIRE(!(flags & 2) || (residual_c8s && !(flags & 4) && (!(flags & 8) || (flags & 64))),
+                   "flag bit1 needs residual_c8s and a stride-1 output (with pixel shuffle: the c8s store, bit6)");
+    SCIPNP_REQUIRE(!(flags & 64) || ((flags & 8) && !(flags & 32)), "flag bit6 (c8s pixel-shuffle store) needs bit3 and excludes bit5");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
     SCIPNP_ALIGNED(in_c8s); SCIPNP_ALIGNED(packed_split); SCIPNP_ALIGNED(out);
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 31), "image too large for 32-bit tile offsets");

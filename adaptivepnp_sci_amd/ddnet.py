@@ -156,8 +156,6 @@ class _Bufs:
         self.a0, self.a1, self.x1, self.s1, self.c0, self.c1 = a[0], a[1], a[0], a[1], a[2], a[1]
         self.d0, self.d1, self.x2, self.u0, self.u1 = d[0], d[1], d[0], d[1], d[2]
         self.x8 = f32(8, h, w)
-        if split:
-            self.sh1, self.sh0 = f32(C1, h2, w2), f32(C0, h, w)
 
 
 def unet_forward(pk, b, split):
@@ -175,12 +173,10 @@ def unet_forward(pk, b, split):
         c(b.d1, pk[7], C2, relu=True, out=b.x2)
         c(b.x2, pk[8], C2, relu=True, out=b.u0)
         c(b.u0, pk[9], C2, relu=True, out=b.u1)
-        c(b.u1, pk[10], 4 * C1, shuffle=True, out=b.sh1)
-        ops.c8_add_to_c8s(b.sh1, b.x1, b.s1)
+        c(b.u1, pk[10], 4 * C1, shuffle=True, residual=b.x1, out=b.s1)
         c(b.s1, pk[11], C1, relu=True, out=b.c0)
         c(b.c0, pk[12], C1, relu=True, out=b.c1)
-        c(b.c1, pk[13], 4 * C0, shuffle=True, out=b.sh0)
-        ops.c8_add_to_c8s(b.sh0, b.x0, b.s0)
+        c(b.c1, pk[13], 4 * C0, shuffle=True, residual=b.x0, out=b.s0)
         c(b.s0, pk[14], C0, relu=True, out=b.o0)
         c(b.o0, pk[15], 8, out=b.x8, f32_out=True)
     else:

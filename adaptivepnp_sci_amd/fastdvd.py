@@ -184,12 +184,12 @@ def denblock_forward(pk, frames, sigma, out, b):
 
 def alloc_denblock_buffers_split(B, H, W, device, alias=True):
     """buffers of the split-fp16 DenBlock: c8s activations (float16, same bytes as fp32 c8) plus the two fp32
-    PixelShuffle outputs and the fp32 8-channel tail.  alias=False keeps every activation (finetune stash)."""
+    8-channel tail.  alias=False keeps every activation (finetune stash)."""
     h16 = lambda c, h, w: torch.empty(B, c // 8, 2, h, w, 8, dtype=torch.float16, device=device)  # noqa: E731
     f32 = lambda c, h, w: torch.empty(B, c // 8, h, w, 8, dtype=torch.float32, device=device)  # noqa: E731
     H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
     b = dict(t_in=h16(16, H, W), t96=h16(96, H, W), x0=h16(32, H, W), s32=h16(32, H, W), o32=h16(32, H, W),
-             x8=f32(8, H, W), sh64=f32(64, H2, W2), sh32=f32(32, H, W))
+             x8=f32(8, H, W))
     if alias:
         a = [h16(64, H2, W2) for _ in range(3)]
         d = [h16(128, H4, W4) for _ in range(3)]
@@ -203,8 +203,8 @@ def alloc_denblock_buffers_split(B, H, W, device, alias=True):
 
 
 def denblock_forward_split(pk, frames, sigma, out, b):
-    """denblock_forward on the split-fp16 kernels: c8s activations, the two UpBlock convs write their PixelShuffle-d
-    result in fp32 and one element-wise pass adds the skip tensor and converts back to c8s."""
+    """denblock_forward on the split-fp16 kernels: c8s activations; the two UpBlock convs store their PixelShuffle-d
+    result plus the skip tensor straight into c8s (epilogue flag bit6)."""
     c = ops.conv3x3_c8s
     ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'])
     c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
@@ -217,12 +217,10 @@ def denblock_forward_split(pk, frames, sigma, out, b):
     c(b['d1'], pk[7], 128, relu=True, out=b['x2'])
     c(b['x2'], pk[8], 128, relu=True, out=b['u0'])
     c(b['u0'], pk[9], 128, relu=True, out=b['u1'])
-    c(b['u1'], pk[10], 256, shuffle=True, out=b['sh64'])
-    ops.c8_add_to_c8s(b['sh64'], b['x1'], b['s64'])                 # x1 + upc2(x2)
+    c(b['u1'], pk[10], 256, shuffle=True, residual=b['x1'], out=b['s64'])      # x1 + upc2(x2), PixelShuffle fused
     c(b['s64'], pk[11], 64, relu=True, out=b['c0'])
     c(b['c0'], pk[12], 64, relu=True, out=b['c1'])
-    c(b['c1'], pk[13], 128, shuffle=True, out=b['sh32'])
-    ops.c8_add_to_c8s(b['sh32'], b['x0'], b['s32'])                 # x0 + upc1(.)
+    c(b['c1'], pk[13], 128, shuffle=True, residual=b['x0'], out=b['s32'])      # x0 + upc1(.)
     c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
     c(b['o32'], pk[15], 8, out=b['x8'], f32_out=True)
     return ops.fastdvd_finish(frames, b['x8'], out)

@@ -315,15 +315,19 @@ def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False
     zeroed where it is not positive (backward-data convolution of the finetune)."""
     n, cg, _two, h, w, _ = x.shape
     ho, wo = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if stride2 else (h, w)
+    shuffle_c8s = bool(shuffle) and ((out is not None and out.dtype == torch.float16) or shuffle == 'c8s')
     if out is None:
-        if shuffle:
+        if shuffle_c8s:
+            out = torch.empty(n, Cout // 32, 2, 2 * h, 2 * w, 8, device=x.device, dtype=torch.float16)
+        elif shuffle:
             out = torch.empty(n, Cout // 32, 2 * h, 2 * w, 8, device=x.device, dtype=F32)
         elif f32_out:
             out = torch.empty(n, Cout // 8, ho, wo, 8, device=x.device, dtype=F32)
         else:
             out = torch.empty(n, Cout // 8, 2, ho, wo, 8, device=x.device, dtype=torch.float16)
-    fp32 = f32_out or shuffle
+    fp32 = f32_out or (shuffle and not shuffle_c8s)
     flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
+             (64 if shuffle_c8s else 0) |
              (0x100 if head else 0) | (16 if mask is not None else 0) | (2 if residual is not None else 0))
     _call('scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
           _p(out, 'out', F32 if fp32 else torch.float16), _p(residual, 'residual', torch.float16),

@@ -145,11 +145,14 @@ def main():
 
     for _ in range(args.warmup):
         run.step(SIGMA)
+    from adaptivepnp_sci_amd import shard
+    if dist is not None:
+        # untimed: the first gather sets up RCCL's point-to-point connections over xGMI
+        shard.gather_units({rank: run.result_mosaic()}, world, (H, W, B), dev, dst=0)
     events = []
     run.profile_events = events
     phi_events = []
     run.phi_events = phi_events
-    from adaptivepnp_sci_amd import shard
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

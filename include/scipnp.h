@@ -214,7 +214,9 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
  * output's shape, the stashed forward activation) is positive, else 0 -- the backward-data convolution of the online
  * finetune on the fp16 MFMA (packages/ffdnet/test_ffdnet_ipol.py:296 `loss.backward()`).  Other flags as
  * scipnp_conv3x3_c8s; mask_c8s may be NULL when bit4 is clear.  Flag bit1 = 2 adds residual_c8s (a c8s tensor of
- * the output's shape: the gradient arriving over a skip connection) before the mask. */
+ * the output's shape: the gradient arriving over a skip connection) before the mask.  Flag bit6 = 64 together with
+ * bit3: the PixelShuffle(2)-ed result is stored as c8s [n][Cout/32][2][2h*2w][8] (residual_c8s, if bit1, has that
+ * shape: the UpBlock's skip tensor, fastdvdnet models.py:190-193) instead of fp32 c8. */
 int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
                           const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 

@@ -527,6 +527,13 @@ def test_conv3x3_split_stride2_shuffle_bn(ops):
     sh32 = ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda())), pk, 128, shuffle=True)
     got = ops.from_c8(ops.c8s_to_float(ops.c8_add_to_c8s(sh32, ops.c8_to_c8s(ops.to_c8(res.cuda()))))).cpu()
     assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 2e-6
+    # the same in one launch: PixelShuffle + skip add stored straight into c8s (epilogue flag bit6)
+    res_s = ops.c8_to_c8s(ops.to_c8(res.cuda()))
+    fused = ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda())), pk, 128, shuffle='c8s', residual=res_s)
+    got = ops.from_c8(ops.c8s_to_float(fused)).cpu()
+    assert got.shape == ref.shape and rel_l2(got.numpy(), ref.numpy()) < 2e-6
+    plain = ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x.cuda())), pk, 128, shuffle='c8s')
+    assert rel_l2(ops.from_c8(ops.c8s_to_float(plain)).cpu().numpy(), (ref - res.double()).numpy()) < 2e-6
 
 
 # ------------------------------------------------------------------ DDnet (deep demosaicking) glue and forward

@@ -51,7 +51,9 @@ def layer(cin, cout, hh, ww, **kw):
 for name, args, kw in [('96->32 512^2', (96, 32, 512, 512), {}), ('32->64 s2 512^2', (32, 64, 512, 512), dict(stride2=True)),
                        ('64->64 256^2', (64, 64, 256, 256), {}), ('64->128 s2 256^2', (64, 128, 256, 256), dict(stride2=True)),
                        ('128->128 128^2', (128, 128, 128, 128), {}), ('128->256 shuf 128^2', (128, 256, 128, 128), dict(shuffle=True)),
-                       ('64->128 shuf 256^2', (64, 128, 256, 256), dict(shuffle=True)), ('32->32 512^2', (32, 32, 512, 512), {})]:
+                       ('64->128 shuf 256^2', (64, 128, 256, 256), dict(shuffle=True)),
+                       ('128->256 shuf->c8s', (128, 256, 128, 128), dict(shuffle='c8s')),
+                       ('64->128 shuf->c8s', (64, 128, 256, 256), dict(shuffle='c8s')), ('32->32 512^2', (32, 32, 512, 512), {})]:
     f, fl = layer(*args, **kw)
     for _ in range(3):
         f()
