@@ -181,3 +181,14 @@ def test_ffdnet_finetune_golden(ffdnet_state_dict):
     sd = o['model'].state_dict()
     for k, w0 in ffdnet_state_dict.items():
         assert rel_l2((sd[k] - w0).numpy(), g[k.replace('.', '_') + '_delta']) == 0
+
+
+def test_package_synthetic_weights_equal_the_oracle_ones():
+    """the GPU-side tools take their synthetic FastDVDnet / DDnet weights from the package (no oracle import outside
+    tests / smoke / cpu_baseline); both generators must produce the very weights the goldens were made with"""
+    from adaptivepnp_sci_amd import synth
+    for mine, ref in ((synth.synth_fastdvdnet(0), ON.synth_fastdvdnet_weights(0)), (synth.synth_ddnet(0), ON.synth_ddnet_weights(0))):
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

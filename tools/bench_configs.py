@@ -42,7 +42,7 @@ for prec in ('f32', 'f16x3'):
     run.step(25 / 255); torch.cuda.synchronize()
     t0 = time.perf_counter(); run.step(25 / 255); torch.cuda.synchronize()
     print(f'FFDNet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
-from oracle.nets import synth_fastdvdnet_weights
+from adaptivepnp_sci_amd.synth import synth_fastdvdnet as synth_fastdvdnet_weights
 fnet = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
 for prec in ('f32', 'f16x3'):
     os.environ['SCIPNP_CONV_PRECISION'] = prec
@@ -53,7 +53,7 @@ for prec in ('f32', 'f16x3'):
     run.step(8 / 255); torch.cuda.synchronize()
     t0 = time.perf_counter(); run.step(8 / 255); torch.cuda.synchronize()
     print(f'FastDVDnet {prec} iteration WITH online finetune (2 Adam steps): {(time.perf_counter() - t0) * 1e3:.1f} ms')
-from oracle.nets import synth_ddnet_weights
+from adaptivepnp_sci_amd.synth import synth_ddnet as synth_ddnet_weights
 dd = synth_ddnet_weights(0)
 os.environ['SCIPNP_CONV_PRECISION'] = 'f16x3'
 net = FFDNet(); net.load_state_dict(sd)

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import synth
 from adaptivepnp_sci_amd.solver import AdmmRun
-from oracle.nets import synth_fastdvdnet_weights          # synthetic weights only (the checkpoint is not in the snapshot)
+from adaptivepnp_sci_amd.synth import synth_fastdvdnet as synth_fastdvdnet_weights
 y, Phi, orig = synth.make_problem(512, 512, 8, 0)
 run = AdmmRun(y, Phi, 'fastdvd_color', True, X_orig=orig, model=torch.nn.DataParallel(synth_fastdvdnet_weights(0)))
 for _ in range(3):

@@ -10,7 +10,7 @@ g = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'ff
 sd = {k: torch.from_numpy(g[k]) for k in g.files}
 y, Phi, orig = synth.make_problem(512, 512, 8, 0)
 if os.environ.get('FT_DENOISER', 'ffdnet') == 'fastdvd':
-    from oracle.nets import synth_fastdvdnet_weights          # synthetic weights only (test infrastructure as data source)
+    from adaptivepnp_sci_amd.synth import synth_fastdvdnet as synth_fastdvdnet_weights
     net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
     run = AdmmRun(y, Phi, 'fastdvd_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,
                   inital_iter=0, interval_iter=1)

@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import synth
 from adaptivepnp_sci_amd.solver import AdmmRun
-from oracle.nets import synth_fastdvdnet_weights
+from adaptivepnp_sci_amd.synth import synth_fastdvdnet as synth_fastdvdnet_weights
 y, Phi, orig = synth.make_problem(512, 512, 8, 0)
 net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
 run = AdmmRun(y, Phi, 'fastdvd_color', True, X_orig=orig, model=net, update_=True, lr_=2e-6, update_per_iter=2,

@@ -16,7 +16,7 @@ def once():
         net = FFDNet(); net.load_state_dict(sd)
         return twoStageAdmm_denoise_bayer(y, Phi, denoiser='ffdnet_color', iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255],
                                           X_orig=orig, model_denoise=net, logf=io.StringIO())
-    from oracle.nets import synth_fastdvdnet_weights
+    from adaptivepnp_sci_amd.synth import synth_fastdvdnet as synth_fastdvdnet_weights
     net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
     return twoStageAdmm_denoise_bayer(y, Phi, denoiser='fastdvd_color', iter_max=[18], sigma=[8 / 255], X_orig=orig,
                                       model_denoise=net, logf=io.StringIO())
