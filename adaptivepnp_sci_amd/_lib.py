@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libscipnp.so')
+LIB_PATH = os.environ.get('SCIPNP_LIB', os.path.join(_HERE, 'libscipnp.so'))     # SCIPNP_LIB: kernel-variant experiments
 
 _f = C.POINTER(C.c_float)
 _d = C.POINTER(C.c_double)

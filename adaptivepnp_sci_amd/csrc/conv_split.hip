@@ -39,27 +39,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CS_TH = 8, CS_TW = 32;
-constexpr int CS_THREADS = 256;
+constexpr int CS_TW = 32;
 constexpr float CS_LO_SCALE = 2048.f, CS_LO_INV = 1.f / 2048.f;
 
-template <int COB, int STRIDE>
+// PB = output rows per wave, NW = waves per workgroup: the workgroup tile is (NW*PB) rows x 32 columns.  <2, 4> = 8 x 32
+// pixels, two workgroups per CU, is what is dispatched.  Measured alternative <4, 8> (32 x 32 pixels, one 8-wave workgroup
+// per CU, 192 accumulator registers per lane, twice the matrix work per LDS operand read and staged weight byte):
+// 284 us against 231-242 us for the FFDNet body layer -- 256 VGPRs with spills, and a lone workgroup per CU leaves
+// its barrier waits uncovered.
+template <int COB, int STRIDE, int PB = 2, int NW = 4>
 struct SplitCfg {
+    static constexpr int TH = NW * PB;
+    static constexpr int THREADS = NW * 64;
     static constexpr int TWP = (CS_TW - 1) * STRIDE + 3;      // input tile columns (34 / 65)
-    static constexpr int THP = (CS_TH - 1) * STRIDE + 3;      // input tile rows    (10 / 17)
+    static constexpr int THP = (TH - 1) * STRIDE + 3;         // input tile rows    (10 / 17; 34 for the 32-row tile)
     static constexpr int IN_PLANE = THP * TWP * 16;           // bytes of one plane of the input tile
     static constexpr int IN_VEC = 2 * THP * TWP;              // 16-byte units (both planes)
-    static constexpr int IN_ITERS = (IN_VEC + CS_THREADS - 1) / CS_THREADS;
+    static constexpr int IN_ITERS = (IN_VEC + THREADS - 1) / THREADS;
     static constexpr int COUTP = 32 * COB;
     static constexpr int W_VEC = 9 * 2 * COUTP;
-    static constexpr int W_ITERS = (W_VEC + CS_THREADS - 1) / CS_THREADS;
+    static constexpr int W_ITERS = (W_VEC + THREADS - 1) / THREADS;
     // every lane of every 64-lane LDS-DMA instruction writes 16 bytes: both regions are padded to whole 256-unit
     // rounds (out-of-range lanes fetch zeros through the buffer bounds check)
-    static constexpr int IN_PAD = IN_ITERS * CS_THREADS * 16;
-    static constexpr int W_PAD = W_ITERS * CS_THREADS * 16;
+    static constexpr int IN_PAD = IN_ITERS * THREADS * 16;
+    static constexpr int W_PAD = W_ITERS * THREADS * 16;
     static constexpr int STAGE = IN_PAD + W_PAD;
     static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
-    static constexpr int WAVES_PER_SIMD = (LDS_BYTES * 2 <= 160 * 1024 && COB <= 3) ? 2 : 1;
+    static constexpr int WAVES_PER_SIMD = NW == 8 ? 2 : ((LDS_BYTES * 2 <= 160 * 1024 && COB <= 3) ? 2 : 1);
 };
 
 struct SplitArgs {
@@ -94,15 +100,16 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
 }
 
 // TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
-template <int COB, int TAG, int STRIDE, int SHUF>
-__global__ void __launch_bounds__(CS_THREADS, (SplitCfg<COB, STRIDE>::WAVES_PER_SIMD))
+template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4>
+__global__ void __launch_bounds__((SplitCfg<COB, STRIDE, PB, NW>::THREADS), (SplitCfg<COB, STRIDE, PB, NW>::WAVES_PER_SIMD))
 conv3x3_c8s_kernel(const SplitArgs a) {
-    using Cfg = SplitCfg<COB, STRIDE>;
+    using Cfg = SplitCfg<COB, STRIDE, PB, NW>;
+    constexpr int CS_THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * CS_TH;
+    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * Cfg::TH;
     const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
@@ -156,9 +163,9 @@ conv3x3_c8s_kernel(const SplitArgs a) {
         w_g += w_step;
     };
 
-    f32x16 acc[2][COB];
+    f32x16 acc[PB][COB];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
@@ -170,7 +177,7 @@ conv3x3_c8s_kernel(const SplitArgs a) {
 
     // LDS byte offsets.  input: plane p at p*IN_PLANE, pixel (r,c) at (r*TWP + c)*16
     //                    weights: IN_PAD + ((tap*2 + plane)*COUTP + co)*16
-    const int px_base = ((2 * wv * STRIDE) * Cfg::TWP + li * STRIDE) * 16;   // + ((pb*S+ky)*TWP + kx)*16
+    const int px_base = ((PB * wv * STRIDE) * Cfg::TWP + li * STRIDE) * 16;   // + ((pb*S+ky)*TWP + kx)*16
     const int co_base = Cfg::IN_PAD + li * 16;                               // + ((tap*2+plane)*COUTP + cb*32)*16
     // hi x hi tap pairs: lane half h handles tap 2p+h; per-lane offsets and scale (0 for the missing tap 9) hoisted
     int pair_px[5], pair_co[5];
@@ -191,30 +198,30 @@ conv3x3_c8s_kernel(const SplitArgs a) {
         if (cig + 1 < a.CGin) dma_stage(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
         // 14 MFMA steps per group: 5 hi x hi tap pairs (lane half h handles tap 2p+h, tap 9 -> zero weights)
         // then 9 cross-term taps (k 0..7 = w_lo' x_hi from lane half 0, k 8..15 = w_hi x_lo' from lane half 1).
-        f16x8 bfA[2], afA[COB], bfB[2], afB[COB];
-        auto load_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
+        f16x8 bfA[PB], afA[COB], bfB[PB], afB[COB];
+        auto load_step = [&](int s, f16x8 (&bf)[PB], f16x8 (&af)[COB]) {
             if (s < 5) {
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * STRIDE * Cfg::TWP * 16);
+                for (int pb = 0; pb < PB; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * STRIDE * Cfg::TWP * 16);
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb) af[cb] = *(const f16x8*)(buf + pair_co[s] + cb * 32 * 16);
             } else {
                 const int tap = s - 5, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
+                for (int pb = 0; pb < PB; ++pb)
                     bf[pb] = *(const f16x8*)(buf + lh * Cfg::IN_PLANE + px_base + ((pb * STRIDE + ky) * Cfg::TWP + kx) * 16);
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
                     af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
             }
         };
-        auto mma_step = [&](int s, f16x8 (&bf)[2], f16x8 (&af)[COB]) {
+        auto mma_step = [&](int s, f16x8 (&bf)[PB], f16x8 (&af)[COB]) {
             if (s < 5) {
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb) af[cb] = af[cb] * (f16x8)pair_scale[s];     // exact 2^11 (or 0)
             }
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
                     acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[pb], acc[pb][cb], 0, 0, 0);
@@ -238,8 +245,8 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     const size_t HWo = (size_t)Ho * Wo;
     const int x = x0 + li;
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int y = y0 + 2 * wv + pb;
+    for (int pb = 0; pb < PB; ++pb) {
+        const int y = y0 + PB * wv + pb;
         if (SHUF && (a.flags & 64)) {
             // PixelShuffle(2) store straight into c8s, with the skip tensor added (flag bit1): a lane holds, per conv
             // channel group g, the four sub-pixels e of OUTPUT channel 2g+lh; v_permlane32_swap exchanges the bottom-row
@@ -338,18 +345,18 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     }
 }
 
-template <int COB, int TAG, int STRIDE, int SHUF>
+template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4>
 static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
-    using Cfg = SplitCfg<COB, STRIDE>;
+    using Cfg = SplitCfg<COB, STRIDE, PB, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + CS_TH - 1) / CS_TH, n * a.nsplit);
-    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF>), grid, dim3(CS_THREADS), Cfg::LDS_BYTES, st, a);
+    const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + Cfg::TH - 1) / Cfg::TH, n * a.nsplit);
+    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_kernel");
 }
 
