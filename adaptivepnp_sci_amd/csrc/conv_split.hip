@@ -47,7 +47,7 @@ constexpr float CS_LO_SCALE = 2048.f, CS_LO_INV = 1.f / 2048.f;
 // per CU, 192 accumulator registers per lane, twice the matrix work per LDS operand read and staged weight byte):
 // 284 us against 231-242 us for the FFDNet body layer -- 256 VGPRs with spills, and a lone workgroup per CU leaves
 // its barrier waits uncovered.
-template <int COB, int STRIDE, int PB = 2, int NW = 4>
+template <int COB, int STRIDE, int PB = 2, int NW = 4, int WS = 0>
 struct SplitCfg {
     static constexpr int TH = NW * PB;
     static constexpr int THREADS = NW * 64;
@@ -63,9 +63,13 @@ struct SplitCfg {
     // rounds (out-of-range lanes fetch zeros through the buffer bounds check)
     static constexpr int IN_PAD = IN_ITERS * THREADS * 16;
     static constexpr int W_PAD = W_ITERS * THREADS * 16;
-    static constexpr int STAGE = IN_PAD + W_PAD;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
-    static constexpr int WAVES_PER_SIMD = NW == 8 ? 2 : ((LDS_BYTES * 2 <= 160 * 1024 && COB <= 3) ? 2 : 1);
+    // WS = 0: [input | weights] x 2 buffers, both prefetched one group ahead.  WS = 1: the input tile is double-buffered,
+    // the weight slab is not (it is re-fetched between two barriers after each group): 51 KiB instead of 77 KiB for
+    // COB = 3, i.e. three workgroups (12 waves) per CU cover each other's waits instead of two.
+    static constexpr int STAGE = WS ? IN_PAD : IN_PAD + W_PAD;
+    static constexpr int W_AT = WS ? 2 * IN_PAD : IN_PAD;                 // weights: after both input buffers / inside the stage
+    static constexpr size_t LDS_BYTES = WS ? 2 * (size_t)IN_PAD + W_PAD : 2 * (size_t)STAGE;
+    static constexpr int WAVES_PER_SIMD = WS ? 3 : (NW == 8 ? 2 : ((LDS_BYTES * 2 <= 160 * 1024 && COB <= 3) ? 2 : 1));
 };
 
 struct SplitArgs {
@@ -100,10 +104,10 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
 }
 
 // TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
-template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4>
-__global__ void __launch_bounds__((SplitCfg<COB, STRIDE, PB, NW>::THREADS), (SplitCfg<COB, STRIDE, PB, NW>::WAVES_PER_SIMD))
+template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4, int WS = 0>
+__global__ void __launch_bounds__((SplitCfg<COB, STRIDE, PB, NW, WS>::THREADS), (SplitCfg<COB, STRIDE, PB, NW, WS>::WAVES_PER_SIMD))
 conv3x3_c8s_kernel(const SplitArgs a) {
-    using Cfg = SplitCfg<COB, STRIDE, PB, NW>;
+    using Cfg = SplitCfg<COB, STRIDE, PB, NW, WS>;
     constexpr int CS_THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     const int tid = threadIdx.x;
@@ -145,22 +149,29 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     const size_t w_step = (size_t)9 * 2 * a.CoutP_total * 16;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     (void)wvu;
-    auto dma_stage = [&](char* buf) {
+    auto dma_in = [&](char* buf) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep them out of the host pass that only emits the launch stub
         auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, (int)grp_bytes, 0x00020000);
-        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, (int)w_step, 0x00020000);
 #pragma unroll
         for (int k = 0; k < Cfg::IN_ITERS; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 r_in, (__attribute__((address_space(3))) void*)(buf + 16 * (wvu * 64 + k * CS_THREADS)), 16, in_off[k], 0, 0, 0);
+#endif
+        in_g += grp_bytes;
+    };
+    auto dma_w = [&](char* wbuf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, (int)w_step, 0x00020000);
 #pragma unroll
         for (int k = 0; k < Cfg::W_ITERS; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_w, (__attribute__((address_space(3))) void*)(buf + Cfg::IN_PAD + 16 * (wvu * 64 + k * CS_THREADS)), 16,
-                w_off[k], 0, 0, 0);
+                r_w, (__attribute__((address_space(3))) void*)(wbuf + 16 * (wvu * 64 + k * CS_THREADS)), 16, w_off[k], 0, 0, 0);
 #endif
-        in_g += grp_bytes;
         w_g += w_step;
+    };
+    auto dma_stage = [&](char* buf) {
+        dma_in(buf);
+        dma_w(WS ? smem_s + Cfg::W_AT : buf + Cfg::W_AT);
     };
 
     f32x16 acc[PB][COB];
@@ -178,7 +189,8 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     // LDS byte offsets.  input: plane p at p*IN_PLANE, pixel (r,c) at (r*TWP + c)*16
     //                    weights: IN_PAD + ((tap*2 + plane)*COUTP + co)*16
     const int px_base = ((PB * wv * STRIDE) * Cfg::TWP + li * STRIDE) * 16;   // + ((pb*S+ky)*TWP + kx)*16
-    const int co_base = Cfg::IN_PAD + li * 16;                               // + ((tap*2+plane)*COUTP + cb*32)*16
+    // weight fragment offsets are relative to the weight region of the current buffer (WS: the one shared region)
+    const int co_base = li * 16;                                             // + ((tap*2+plane)*COUTP + cb*32)*16
     // hi x hi tap pairs: lane half h handles tap 2p+h; per-lane offsets and scale (0 for the missing tap 9) hoisted
     int pair_px[5], pair_co[5];
     _Float16 pair_scale[5];
@@ -195,7 +207,11 @@ conv3x3_c8s_kernel(const SplitArgs a) {
 
     for (int cig = 0; cig < a.CGin; ++cig) {
         const char* buf = smem_s + (cig & 1) * Cfg::STAGE;
-        if (cig + 1 < a.CGin) dma_stage(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+        const char* wb = WS ? smem_s + Cfg::W_AT : buf + Cfg::W_AT;
+        if (cig + 1 < a.CGin) {
+            if (WS) dma_in(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+            else dma_stage(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+        }
         // 14 MFMA steps per group: 5 hi x hi tap pairs (lane half h handles tap 2p+h, tap 9 -> zero weights)
         // then 9 cross-term taps (k 0..7 = w_lo' x_hi from lane half 0, k 8..15 = w_hi x_lo' from lane half 1).
         f16x8 bfA[PB], afA[COB], bfB[PB], afB[COB];
@@ -204,7 +220,7 @@ conv3x3_c8s_kernel(const SplitArgs a) {
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) bf[pb] = *(const f16x8*)(buf + pair_px[s] + pb * STRIDE * Cfg::TWP * 16);
 #pragma unroll
-                for (int cb = 0; cb < COB; ++cb) af[cb] = *(const f16x8*)(buf + pair_co[s] + cb * 32 * 16);
+                for (int cb = 0; cb < COB; ++cb) af[cb] = *(const f16x8*)(wb + pair_co[s] + cb * 32 * 16);
             } else {
                 const int tap = s - 5, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
@@ -212,7 +228,7 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                     bf[pb] = *(const f16x8*)(buf + lh * Cfg::IN_PLANE + px_base + ((pb * STRIDE + ky) * Cfg::TWP + kx) * 16);
 #pragma unroll
                 for (int cb = 0; cb < COB; ++cb)
-                    af[cb] = *(const f16x8*)(buf + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
+                    af[cb] = *(const f16x8*)(wb + co_base + ((tap * 2 + (1 - lh)) * Cfg::COUTP + cb * 32) * 16);
             }
         };
         auto mma_step = [&](int s, f16x8 (&bf)[PB], f16x8 (&af)[COB]) {
@@ -236,6 +252,11 @@ conv3x3_c8s_kernel(const SplitArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next group's LDS-DMA has landed
         __syncthreads();
+        if (WS && cig + 1 < a.CGin) {                            // every wave is done with the weight slab: refill it
+            dma_w(smem_s + Cfg::W_AT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     // ---- epilogue
@@ -345,18 +366,204 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     }
 }
 
-template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4>
-static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
-    using Cfg = SplitCfg<COB, STRIDE, PB, NW>;
+// ---------------------------------------------------------------------------------------------------------------
+// The same convolution on v_mfma_f32_16x16x32_f16 (stride 1, c8s / fp32 c8 store): K = 32 holds FOUR 8-channel
+// sub-blocks, one per 16-lane group ks of the wave, each with its own (tap, operand plane) pair:
+//   steps 0,1 : hi x hi of taps 4s+ks                                   (A = w_hi * 2^11, B = x_hi)
+//   steps 2-5 : cross terms, sub-block j = 4(s-2)+ks -> tap j/2:  even j  w_lo' x x_hi,  odd j  w_hi x x_lo'
+//   step  6   : ks 0,1 cross terms of tap 8;  ks 2 hi x hi of tap 8;  ks 3 empty (A scaled by 0)
+// = 7 steps x 32 = 224 K-slots per 8 input channels, exactly the 14 x 16 of the 32x32x16 kernel; the wave tile
+// (32*COB channels x 2 rows x 32 columns) is 2*COB x 4 blocks of 16x16, 4 accumulator registers each.  Same LDS image,
+// same packed weights, same bytes read per flop.  On random data the chip holds a higher clock on this MFMA shape
+// (MI355X_MICROARCH.md, DVFS give-back (7)).
+template <int COB, int TAG>
+__global__ void __launch_bounds__(256, (SplitCfg<COB, 1>::WAVES_PER_SIMD))
+conv3x3_c8s_k32_kernel(const SplitArgs a) {
+    using Cfg = SplitCfg<COB, 1>;
+    constexpr int CS_THREADS = 256, NCB = 2 * COB;
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lc = lane & 15, ks = lane >> 4;
+    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * Cfg::TH;
+    const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const size_t grp_bytes = 2 * HW * 16;
+
+    const unsigned OOB = 0x80000000u;
+    unsigned in_off[Cfg::IN_ITERS];
+#pragma unroll
+    for (int k = 0; k < Cfg::IN_ITERS; ++k) {
+        const int e = tid + k * CS_THREADS;
+        in_off[k] = OOB;
+        if (e < Cfg::IN_VEC) {
+            const int plane = e / (Cfg::THP * Cfg::TWP), pix = e - plane * (Cfg::THP * Cfg::TWP);
+            const int r = pix / Cfg::TWP, c = pix - r * Cfg::TWP;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[k] = (unsigned)((plane * HW + (size_t)gy * W + gx) * 16);
+        }
+    }
+    unsigned w_off[Cfg::W_ITERS];
+#pragma unroll
+    for (int k = 0; k < Cfg::W_ITERS; ++k) {
+        const int e = tid + k * CS_THREADS;
+        w_off[k] = OOB;
+        if (e < Cfg::W_VEC) {
+            const int tp = e / Cfg::COUTP, co = e - tp * Cfg::COUTP;
+            w_off[k] = (unsigned)((tp * a.CoutP_total + split * Cfg::COUTP + co) * 16);
+        }
+    }
+    const char* in_g = a.in + (size_t)n * a.CGin * grp_bytes;
+    const char* w_g = a.wpk;
+    const size_t w_step = (size_t)9 * 2 * a.CoutP_total * 16;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    (void)wvu;
+    auto dma_stage = [&](char* buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, (int)grp_bytes, 0x00020000);
+        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, (int)w_step, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < Cfg::IN_ITERS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_in, (__attribute__((address_space(3))) void*)(buf + 16 * (wvu * 64 + k * CS_THREADS)), 16, in_off[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < Cfg::W_ITERS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_w, (__attribute__((address_space(3))) void*)(buf + Cfg::IN_PAD + 16 * (wvu * 64 + k * CS_THREADS)), 16,
+                w_off[k], 0, 0, 0);
+#endif
+        in_g += grp_bytes;
+        w_g += w_step;
+    };
+
+    f32x4 acc[4][NCB];                                   // [pixel block = 2*pb + half][16-channel block]
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[pq][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma_stage(smem_s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-step, per-lane-group operand selection (tap, A plane, B plane, A scale)
+    int offA[7], offB[7];
+    _Float16 sc6 = (_Float16)1.f;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        int tap, pa, pbl;
+        if (s < 2) { tap = 4 * s + ks; pa = 0; pbl = 0; }
+        else if (s < 6) { const int j = 4 * (s - 2) + ks; tap = j >> 1; pa = (j & 1) ? 0 : 1; pbl = (j & 1) ? 1 : 0; }
+        else { tap = 8; pa = (ks == 0) ? 1 : 0; pbl = (ks == 1) ? 1 : 0; }
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        offA[s] = Cfg::IN_PAD + ((tap * 2 + pa) * Cfg::COUTP + lc) * 16;                               // + cb*16*16
+        offB[s] = pbl * Cfg::IN_PLANE + ((2 * wv + ky) * Cfg::TWP + lc + kx) * 16;                      // + (pb*TWP + 16*half)*16
+    }
+    if (ks == 2) sc6 = (_Float16)CS_LO_SCALE;
+    if (ks == 3) sc6 = (_Float16)0.f;
+
+    for (int cig = 0; cig < a.CGin; ++cig) {
+        const char* buf = smem_s + (cig & 1) * Cfg::STAGE;
+        if (cig + 1 < a.CGin) dma_stage(smem_s + ((cig + 1) & 1) * Cfg::STAGE);
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            f16x8 bf[4], af[NCB];
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) bf[pq] = *(const f16x8*)(buf + offB[s] + ((pq >> 1) * Cfg::TWP + 16 * (pq & 1)) * 16);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) af[cb] = *(const f16x8*)(buf + offA[s] + cb * 16 * 16);
+            if (s < 2) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) af[cb] = af[cb] * (f16x8)(_Float16)CS_LO_SCALE;
+            } else if (s == 6) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) af[cb] = af[cb] * (f16x8)sc6;
+            }
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[pq][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cb], bf[pq], acc[pq][cb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = pixel column lc of its block, channels 16*cb + 4*ks .. +3
+    const float* bias = (const float*)(a.wpk + (size_t)a.CGin * w_step);
+    const bool relu = a.flags & 1, f32out = a.flags & 32;
+    const int Ho = a.Ho, Wo = a.Wo;
+    const size_t HWo = (size_t)Ho * Wo;
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+        const int y = y0 + 2 * wv + (pq >> 1), x = x0 + 16 * (pq & 1) + lc;
+        if (y < Ho && x < Wo) {
+            const size_t pix = (size_t)y * Wo + x;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int cog = (split * COB) * 4 + 2 * cb + (ks >> 1), sub = 4 * (ks & 1);
+                if (cog < a.CGout) {
+                    const f32x4 bs = *(const f32x4*)(bias + cog * 8 + sub);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[pq][cb][e] * CS_LO_INV + bs[e];
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.flags & 2) {
+                        const char* rg = a.res + ((size_t)n * a.CGout + cog) * (2 * HWo * 16) + pix * 16 + 2 * sub;
+                        const f16x4 rh = *(const f16x4*)rg, rl = *(const f16x4*)(rg + HWo * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] + ((float)rh[e] + (float)rl[e] * CS_LO_INV);
+                    }
+                    if (a.flags & 16) {
+                        const char* mg = a.mask + ((size_t)n * a.CGout + cog) * (2 * HWo * 16) + pix * 16 + 2 * sub;
+                        const f16x4 mh = *(const f16x4*)mg, ml = *(const f16x4*)(mg + HWo * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((float)mh[e] > 0.f || (float)ml[e] > 0.f)) v[e] = 0.f;
+                    }
+                    if (f32out) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HWo + pix) * 8 + sub) * 4) = o;
+                    } else {
+                        char* grp = a.out + ((size_t)n * a.CGout + cog) * (2 * HWo * 16);
+                        split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 2 * sub, grp + HWo * 16 + pix * 16 + 2 * sub);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int COB, int TAG>
+static int launch_split_k32(const SplitArgs& a, int n, hipStream_t st) {
+    using Cfg = SplitCfg<COB, 1>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_k32_kernel<COB, TAG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s_k32): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + Cfg::TH - 1) / Cfg::TH, n * a.nsplit);
+    hipLaunchKernelGGL((conv3x3_c8s_k32_kernel<COB, TAG>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
+    return launch_status("conv3x3_c8s_k32_kernel");
+}
+
+template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4, int WS = 0>
+static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
+    using Cfg = SplitCfg<COB, STRIDE, PB, NW, WS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW, WS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
         attr_set = true;
     }
     const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + Cfg::TH - 1) / Cfg::TH, n * a.nsplit);
-    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW, WS>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_kernel");
 }
 
@@ -366,6 +573,8 @@ static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
     if (CoutP % 96 == 0) {
         a.nsplit = CoutP / 96;
         if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return launch_split<3, 1, 1, 0>(a, n, st);
+        if (STRIDE == 1 && !SHUF && (a.flags & 0x200)) return launch_split<3, 0, 1, 0, 2, 4, 1>(a, n, st);
+        if (STRIDE == 1 && !SHUF && (a.flags & 0x400)) return launch_split_k32<3, 0>(a, n, st);
         return launch_split<3, 0, STRIDE, SHUF>(a, n, st);
     }
     if (CoutP % 128 == 0) { a.nsplit = CoutP / 128; return launch_split<4, 0, STRIDE, SHUF>(a, n, st); }

@@ -309,7 +309,7 @@ def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_s
 
 
 def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False, stride2=False, shuffle=False,
-                mask=None, residual=None):
+                mask=None, residual=None, variant=0):
     """split-fp16 conv: x c8s [n][Cin/8][2][h][w][8] float16 -> c8s, or fp32 c8 if f32_out / shuffle
     (shuffle: PixelShuffle(2)-ed fp32 c8 [n][Cout/32][2h][2w][8]).  mask: c8s tensor of the output's shape, output
     zeroed where it is not positive (backward-data convolution of the finetune)."""
@@ -328,7 +328,7 @@ def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False
     fp32 = f32_out or (shuffle and not shuffle_c8s)
     flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
              (64 if shuffle_c8s else 0) |
-             (0x100 if head else 0) | (16 if mask is not None else 0) | (2 if residual is not None else 0))
+             (0x100 if head else 0) | (16 if mask is not None else 0) | (2 if residual is not None else 0) | variant)
     _call('scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
           _p(out, 'out', F32 if fp32 else torch.float16), _p(residual, 'residual', torch.float16),
           _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags, _stream())

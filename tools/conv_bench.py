@@ -19,13 +19,22 @@ pks = ops.pack_conv3x3_split(wt, b, Cin=c, Cout=c, device='cuda')
 o8 = torch.empty_like(x8)
 os_ = torch.empty_like(xs)
 variants = {'fp32': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
-            'f16x3': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_)}
+            'f16x3': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_),
+            'f16x3 W single-buffered, 3 WG/CU': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x200),
+            'f16x3 16x16x32 MFMA': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x400)}
 variants['f16x3']()
 torch.cuda.synchronize()
+ref_out = None
 for name, f in variants.items():
     for _ in range(3):
         f()
     torch.cuda.synchronize()
+    if name.startswith('f16x3'):
+        if ref_out is None:
+            ref_out = os_.clone()
+        else:
+            d = (ops.c8s_to_float(os_) - ops.c8s_to_float(ref_out)).norm() / ops.c8s_to_float(ref_out).norm()
+            print(f'{name}: output identical to default: {bool(torch.equal(os_, ref_out))}, rel-L2 {float(d):.2e}')
 torch.cuda.synchronize()
 res = {k: [] for k in variants}
 for r in range(5):
@@ -40,6 +49,9 @@ for r in range(5):
 for k, v in res.items():
     us = sorted(v)[len(v) // 2]
     print(f'{k:26s} median {us:8.1f} us  min {min(v):8.1f} us   {flop / us / 1e6:7.1f} TFLOP/s (algorithmic)')
+
+if os.environ.get('CONV_BENCH_SHORT'):
+    sys.exit(0)
 
 # FastDVDnet DenBlock layer shapes (512x512 frames): 64 ch at 256x256, 128 ch at 128x128, stride-2 and PixelShuffle layers
 def layer(cin, cout, hh, ww, **kw):
