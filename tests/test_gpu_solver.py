@@ -306,3 +306,39 @@ def test_deep_demosaicking_iterates(solver, ffdnet_state_dict, precision, monkey
     for k in range(3):
         assert rel_l2(tr.it[k], g['theta_fastdvd'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], g['theta_fastdvd'][k]))
     assert rel_l2(res[0], g['rgb_fastdvd']) <= REL_TOL
+
+
+@pytest.mark.parametrize('shape', [(40, 52, 5), (24, 72, 11), (68, 36, 16)])
+def test_ragged_cubes_match_the_oracle(solver, ffdnet_state_dict, shape):
+    """frame sizes that are not multiples of the kernels' 8x32 / 16-pixel tiles and frame counts other than 8 (the
+    torch summation-order emulation of A_ / Phi_sum depends on B): TV one-stage, TV two-stage and FFDNet two-stage
+    against the CPU oracle, per iterate"""
+    from adaptivepnp_sci_amd import synth
+    from oracle import nets as ON
+    from oracle import solver as OS
+    H, W, B = shape
+    y, Phi, orig = synth.make_problem(H, W, B, seed=H + B)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [4], False, [0], X_orig=orig, logf=io.StringIO())
+    o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [4], [0], X_orig=orig)
+    for k in range(4):
+        assert rel_l2(tr.it[k], o['x_iterates'][k]) <= REL_TOL, ('tv one-stage', k)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'tv', [4], False, [0], X_orig=orig, logf=io.StringIO())
+    o = OS.two_stage_admm(y, Phi, 'tv', [4], [0], X_orig=orig)
+    for k in range(4):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, ('tv two-stage', k)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2], False, [25 / 255], X_orig=orig,
+                                            model_denoise=make_ffdnet(ffdnet_state_dict), logf=io.StringIO())
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2], [25 / 255], X_orig=orig, model_denoise=onet)
+    for k in range(2):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, ('ffdnet', k, rel_l2(tr.it[k], o['theta_iterates'][k]))
+    assert res[0].shape == (H, W, 3, B) and rel_l2(res[0], o['rgb']) <= REL_TOL
+    assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
