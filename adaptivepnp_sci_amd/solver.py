@@ -115,6 +115,7 @@ class AdmmRun:
         self.profile_events = None       # bench.py: list receiving (start,end) events around the body convs
         self.phi_events = None           # bench.py: list receiving (start,end) events around the projection launch
         self.noise_source = None         # finetune.NoisePrefetch set by _run_schedule (FastDVDnet finetune noise)
+        self._sse_fixed = None
         # ---- prior workspaces
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
@@ -234,6 +235,8 @@ class AdmmRun:
 
     # ------------------------------------------------------------------ reporting
     def _new_sse(self, nblocks):
+        if self._sse_fixed is not None:           # hipGraph replay: one fixed buffer, rows are collected on the device
+            return self._sse_fixed
         t = torch.empty(nblocks, dtype=torch.float64, device=self.device)
         self.sse_rows.append(t)
         return t
@@ -268,8 +271,45 @@ def _finetune_events(run, total):
     return n
 
 
+def _run_tv_graphed(run, total):
+    """ADMM-TV iterations are ten small launches (projection, 6 for Chambolle, dual update, PSNR row) of 5-25 us each:
+    launch-bound on the host for quarter-resolution planes up to ~128 x 128.  Every pointer and scalar of an iteration
+    is fixed, so iteration 0 runs eagerly (lazy one-time setup), iteration 1 is captured into a hipGraph and replayed
+    for the rest; the per-iteration squared-error partials go to a fixed buffer and are appended to a device table by
+    an index_copy_ driven by a device-side counter inside the graph."""
+    run.step(0)
+    n = total - 1
+    table = kdev = None
+    if run.iqa:
+        nb = ops.sse_nblocks(run.x.numel())
+        table = torch.zeros(n, nb, dtype=torch.float64, device=run.device)
+        kdev = torch.zeros(1, dtype=torch.int64, device=run.device)
+        run._sse_fixed = torch.empty(nb, dtype=torch.float64, device=run.device)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    k0 = run.k
+    try:
+        with torch.cuda.graph(g):
+            run.step(0)
+            if table is not None:
+                table.index_copy_(0, kdev, run._sse_fixed.unsqueeze(0))
+                kdev.add_(1)
+    finally:
+        run._sse_fixed = None
+        run.k = k0                                 # the capture recorded an iteration, it did not run one
+    for _ in range(n):
+        g.replay()
+        run.k += 1
+    if table is not None:
+        run.sse_rows.extend(table[i] for i in range(n))
+
+
 def _run_schedule(run, sigma, iter_max):
     total = sum(iter_max)
+    import os
+    if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
+            and os.environ.get('SCIPNP_HIPGRAPH', '1') != '0'):
+        return _run_tv_graphed(run, total)
     n_events = _finetune_events(run, total)
     if n_events:
         from .finetune import NoisePrefetch

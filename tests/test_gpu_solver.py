@@ -342,3 +342,20 @@ def test_ragged_cubes_match_the_oracle(solver, ffdnet_state_dict, shape):
         assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, ('ffdnet', k, rel_l2(tr.it[k], o['theta_iterates'][k]))
     assert res[0].shape == (H, W, 3, B) and rel_l2(res[0], o['rgb']) <= REL_TOL
     assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+
+
+def test_tv_solver_hipgraph_replay_equals_eager(solver, monkeypatch):
+    """the ADMM-TV loop replays a captured hipGraph (iteration 0 eager, iteration 1 captured): results and the
+    per-iteration PSNR trace must be bit-identical to the eager launch sequence"""
+    from adaptivepnp_sci_amd import synth
+    y, Phi, orig = synth.make_problem(96, 64, 8, seed=9)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('SCIPNP_HIPGRAPH', mode)
+        a = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [12], False, [0], X_orig=orig, logf=io.StringIO())
+        b = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'tv', [5, 4], False, [0, 0], X_orig=orig, logf=io.StringIO())
+        out[mode] = (a, b)
+    for i in range(2):
+        g, e = out['1'][i], out['0'][i]
+        assert np.array_equal(g[0], e[0]) and g[1] == e[1] and g[2] == e[2] and g[3] == e[3]
+    assert len(out['1'][0][3]) == 12 and len(out['1'][1][3]) == 9

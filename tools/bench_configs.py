@@ -87,3 +87,15 @@ for name, kw in (('FFDNet [15,6,4] its, finetune at k=15 (2 Adam steps)',
         twoStageAdmm_denoise_bayer(y, Phi, x0_bayer=warm, X_orig=orig, model_denoise=model, logf=io.StringIO(), **kw)
         ts.append((time.perf_counter() - t0) * 1e3)
     print(f'whole reconstruction 512x512x8, {name}: {min(ts):.1f} ms (runs: {" ".join(f"{t:.0f}" for t in ts)})')
+
+# configs[0]: ADMM-TV 256x256x8, 50 iterations, whole call; hipGraph replay of the iteration vs eager launches
+from adaptivepnp_sci_amd import admm_denoise_bayer_demosaic_pre
+y0, Phi0, orig0 = synth.make_problem(256, 256, 8, 0)
+for mode in ('1', '0'):
+    os.environ['SCIPNP_HIPGRAPH'] = mode
+    ts = []
+    for rep in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        admm_denoise_bayer_demosaic_pre(y0, Phi0, 1, 0.01, 'tv', [50], False, [0], X_orig=orig0, logf=io.StringIO())
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f'whole ADMM-TV call 256x256x8, 50 iterations, hipGraph={mode}: {min(ts):.2f} ms (runs: {" ".join(f"{t:.1f}" for t in ts)})')
