@@ -276,7 +276,10 @@ def _run_tv_graphed(run, total):
     launch-bound on the host for quarter-resolution planes up to ~128 x 128.  Every pointer and scalar of an iteration
     is fixed, so iteration 0 runs eagerly (lazy one-time setup), iteration 1 is captured into a hipGraph and replayed
     for the rest; the per-iteration squared-error partials go to a fixed buffer and are appended to a device table by
-    an index_copy_ driven by a device-side counter inside the graph."""
+    an index_copy_ driven by a device-side counter inside the graph.  Opt-in (SCIPNP_HIPGRAPH=1): measured on MI355X at
+    256 x 256 x 8, 50 iterations, the whole call takes 5.0 ms with capture + instantiate + 49 replays against 4.1 ms for
+    50 eager iterations -- one solve is too short to amortise the capture; it pays for schedules of several hundred
+    iterations."""
     run.step(0)
     n = total - 1
     table = kdev = None
@@ -308,7 +311,7 @@ def _run_schedule(run, sigma, iter_max):
     total = sum(iter_max)
     import os
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
-            and os.environ.get('SCIPNP_HIPGRAPH', '1') != '0'):
+            and os.environ.get('SCIPNP_HIPGRAPH', '0') == '1'):
         return _run_tv_graphed(run, total)
     n_events = _finetune_events(run, total)
     if n_events:
