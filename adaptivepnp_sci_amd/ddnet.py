@@ -98,15 +98,6 @@ def _strip(sd):
     return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
 
 
-def _dense_from_grouped(w, groups):
-    co, cig = w.shape[:2]
-    dense = torch.zeros(co, cig * groups, 3, 3, dtype=w.dtype)
-    per = co // groups
-    for g in range(groups):
-        dense[g * per:(g + 1) * per, g * cig:(g + 1) * cig] = w[g * per:(g + 1) * per]
-    return dense
-
-
 def _pack(w, cin, cout, device, split):
     buf = ops.packed_buffer(cin, cout, device, split)
     if split:

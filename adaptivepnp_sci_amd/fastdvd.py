@@ -89,16 +89,6 @@ _LAYERS = [
 ]
 
 
-def _dense_from_grouped(w, groups):
-    """(Cout, Cin/groups, 3, 3) grouped weights -> block-diagonal dense (Cout, Cin, 3, 3)."""
-    co, cig = w.shape[:2]
-    dense = torch.zeros(co, cig * groups, 3, 3, dtype=w.dtype)
-    per = co // groups
-    for g in range(groups):
-        dense[g * per:(g + 1) * per, g * cig:(g + 1) * cig] = w[g * per:(g + 1) * per]
-    return dense
-
-
 def _strip(sd):
     return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
 

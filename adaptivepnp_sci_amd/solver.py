@@ -18,6 +18,8 @@ Documented deviations from the reference:
   * `logf=None` is accepted (no-op writer); arrays may be NumPy or CUDA tensors;
   * log lines are printed after the loop instead of during it (identical text).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -309,7 +311,6 @@ def _run_tv_graphed(run, total):
 
 def _run_schedule(run, sigma, iter_max):
     total = sum(iter_max)
-    import os
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
             and os.environ.get('SCIPNP_HIPGRAPH', '0') == '1'):
         return _run_tv_graphed(run, total)
