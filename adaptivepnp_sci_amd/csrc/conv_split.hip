@@ -113,8 +113,20 @@ conv3x3_c8s_kernel(const SplitArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * Cfg::TH;
-    const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the linear id is
+    // remapped such that one XCD works through a CONTIGUOUS run of tiles (for the FFDNet body: one frame per XCD) and
+    // the halo rows shared by vertically adjacent tiles hit in that XCD's L2 instead of being fetched by another one
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+        if (!(a.flags & 0x800) && (total & 7) == 0) {
+            unsigned w = bx + nx * (by + ny * bz);
+            w = (w & 7) * (total >> 3) + (w >> 3);
+            bx = w % nx; by = (w / nx) % ny; bz = w / (nx * ny);
+        }
+    }
+    const int x0 = bx * CS_TW, y0 = by * Cfg::TH;
+    const int n = bz / a.nsplit, split = bz % a.nsplit;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const size_t grp_bytes = 2 * HW * 16;                      // one input channel group (both planes)
@@ -385,8 +397,20 @@ conv3x3_c8s_k32_kernel(const SplitArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int lc = lane & 15, ks = lane >> 4;
-    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * Cfg::TH;
-    const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the linear id is
+    // remapped such that one XCD works through a CONTIGUOUS run of tiles (for the FFDNet body: one frame per XCD) and
+    // the halo rows shared by vertically adjacent tiles hit in that XCD's L2 instead of being fetched by another one
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+        if (!(a.flags & 0x800) && (total & 7) == 0) {
+            unsigned w = bx + nx * (by + ny * bz);
+            w = (w & 7) * (total >> 3) + (w >> 3);
+            bx = w % nx; by = (w / nx) % ny; bz = w / (nx * ny);
+        }
+    }
+    const int x0 = bx * CS_TW, y0 = by * Cfg::TH;
+    const int n = bz / a.nsplit, split = bz % a.nsplit;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const size_t grp_bytes = 2 * HW * 16;
@@ -573,13 +597,20 @@ static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
     if (CoutP % 96 == 0) {
         a.nsplit = CoutP / 96;
         if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return launch_split<3, 1, 1, 0>(a, n, st);
-        if (STRIDE == 1 && !SHUF && (a.flags & 0x200)) return launch_split<3, 0, 1, 0, 2, 4, 1>(a, n, st);
+        // stride-1 96-channel layers: weights single-buffered, three workgroups per CU (consistently 2-5 % ahead of the
+        // fully double-buffered two-workgroup form, flag 0x200, across the boxes measured; flag 0x400: 16x16x32 MFMA form)
         if (STRIDE == 1 && !SHUF && (a.flags & 0x400)) return launch_split_k32<3, 0>(a, n, st);
+        if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<3, 0, 1, 0, 2, 4, 1>(a, n, st);
         return launch_split<3, 0, STRIDE, SHUF>(a, n, st);
     }
     if (CoutP % 128 == 0) { a.nsplit = CoutP / 128; return launch_split<4, 0, STRIDE, SHUF>(a, n, st); }
-    if (CoutP % 64 == 0) { a.nsplit = CoutP / 64; return launch_split<2, 0, STRIDE, SHUF>(a, n, st); }
+    if (CoutP % 64 == 0) {
+        a.nsplit = CoutP / 64;
+        if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<2, 0, 1, 0, 2, 4, 1>(a, n, st);
+        return launch_split<2, 0, STRIDE, SHUF>(a, n, st);
+    }
     a.nsplit = CoutP / 32;
+    if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<1, 0, 1, 0, 2, 4, 1>(a, n, st);
     return launch_split<1, 0, STRIDE, SHUF>(a, n, st);
 }
 

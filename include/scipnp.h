@@ -217,9 +217,9 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
  * the output's shape: the gradient arriving over a skip connection) before the mask.  Flag bit6 = 64 together with
  * bit3: the PixelShuffle(2)-ed result is stored as c8s [n][Cout/32][2][2h*2w][8] (residual_c8s, if bit1, has that
  * shape: the UpBlock's skip tensor, fastdvdnet models.py:190-193) instead of fp32 c8. 
- * Flags 0x200 / 0x400 select the two measured-alternative kernels of the 96-channel stride-1 layer (weights
- * single-buffered with 3 workgroups per CU / v_mfma_f32_16x16x32_f16) for tools/conv_bench.py; same results to fp32
- * re-association. */
+ * Flags 0x200 / 0x400 / 0x800 select measured-alternative forms of the 96-channel stride-1 kernel for
+ * tools/conv_bench.py (weights double-buffered with 2 workgroups per CU / v_mfma_f32_16x16x32_f16 / linear instead of
+ * XCD-aware tile order); same results to fp32 re-association. */
 int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
                           const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 

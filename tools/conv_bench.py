@@ -20,7 +20,8 @@ o8 = torch.empty_like(x8)
 os_ = torch.empty_like(xs)
 variants = {'fp32': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
             'f16x3': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_),
-            'f16x3 W single-buffered, 3 WG/CU': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x200),
+            'f16x3 linear tile order (no XCD remap)': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x800),
+            'f16x3 W double-buffered, 2 WG/CU': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x200),
             'f16x3 16x16x32 MFMA': lambda: ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_, variant=0x400)}
 variants['f16x3']()
 torch.cuda.synchronize()
@@ -79,3 +80,13 @@ for name, args, kw in [('96->32 512^2', (96, 32, 512, 512), {}), ('32->64 s2 512
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
     us = sorted(ts)[2]
     print(f'f16x3 {name:22s} median {us:8.1f} us   {fl / us / 1e6:7.1f} TFLOP/s (algorithmic)')
+    if not kw:                       # the same layer on the double-buffered two-workgroup form
+        f, fl = layer(*args, variant=0x200)
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        print(f'      {"(W double-buffered)":22s}        {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us')
