@@ -17,7 +17,8 @@ The JSON line also carries
                  HIP events around the body-layer launches inside the timed region;
   phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch (events inside the timed region);
   cpu_baseline : the CPU oracle (bit-exact restatement of the reference) timed on this host on a
-                 bounded sample of the same workload (rank 0, N=1 only).
+                 bounded sample of the same workload (rank 0, N=1 only); when the budget allows it runs the
+                 very iterations the GPU ran and the line carries their parity (`cpu_baseline.parity`).
 """
 import argparse
 import io
@@ -67,7 +68,7 @@ def _usable_cpus():
     return n
 
 
-def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0):
+def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosaic=None, gpu_psnr=None):
     """The CPU oracle on the SAME cube and schedule, bounded to ~budget_s of CPU work.  Thread count:
     the fastest of a short calibration over {8,16,32,64} <= usable CPUs (PyTorch-CPU per-frame
     convolutions do not scale to hundreds of threads)."""
@@ -93,12 +94,24 @@ def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0):
         OS.two_stage_admm(y, Phi, 'ffdnet_color', [1], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
         t1 = time.perf_counter() - t0
         iters = int(min(30, max(1, budget_s // max(t1, 1e-3))))
+        # when the budget allows, run exactly as many iterations as the GPU did: the sample then doubles as a
+        # full-size, free-running parity check of the timed run (north_star gates: 1e-5 rel-L2, 1e-4 dB)
+        check = gpu_iters is not None and gpu_iters * t1 <= 2.5 * budget_s
+        if check:
+            iters = gpu_iters
         t0 = time.perf_counter()
-        OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
         dt = time.perf_counter() - t0
-    return dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port',
-                sample=f'{iters} two-stage ADMM+FFDNet iteration(s) of the same 512x512x8 cube (sigma 25/255, TV warm '
-                       f'start), PyTorch-CPU oracle, {cores} of {usable} usable CPU threads, {dt:.1f} s')
+    out = dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port',
+               sample=f'{iters} two-stage ADMM+FFDNet iteration(s) of the same 512x512x8 cube (sigma 25/255, TV warm '
+                      f'start), PyTorch-CPU oracle, {cores} of {usable} usable CPU threads, {dt:.1f} s')
+    if check:
+        ref = o['x_bayer']
+        out['parity'] = {'iterations': iters,
+                         'rel_l2_final_iterate': float(np.linalg.norm(gpu_mosaic - ref) / np.linalg.norm(ref)),
+                         'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_psnr) - np.array(o['psnr_all'])))),
+                         'gates': {'rel_l2': 1e-5, 'psnr_db': 1e-4}}
+    return out
 
 
 def main():
@@ -217,7 +230,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = net.state_dict()
-            line['cpu_baseline'] = cpu_baseline(y, Phi, warm.cpu().numpy(), orig, sd, args.cpu_budget)
+            line['cpu_baseline'] = cpu_baseline(y, Phi, warm.cpu().numpy(), orig, sd, args.cpu_budget,
+                                                gpu_iters=args.warmup + args.steps, gpu_mosaic=mosaic.cpu().numpy(),
+                                                gpu_psnr=psnr)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
