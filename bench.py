@@ -105,6 +105,15 @@ def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosa
     out = dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port',
                sample=f'{iters} two-stage ADMM+FFDNet iteration(s) of the same 512x512x8 cube (sigma 25/255, TV warm '
                       f'start), PyTorch-CPU oracle, {cores} of {usable} usable CPU threads, {dt:.1f} s')
+    # one iteration on ONE thread (SURVEY 8d asks for both figures), if it fits the sample budget
+    per_iter = dt / iters
+    if per_iter * cores * 0.6 <= 15.0:
+        torch.set_num_threads(1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            OS.two_stage_admm(y, Phi, 'ffdnet_color', [1], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+        out['value_1_thread'] = 1.0 / (time.perf_counter() - t0)
+        torch.set_num_threads(cores)
     if check:
         ref = o['x_bayer']
         out['parity'] = {'iterations': iters,
