@@ -148,3 +148,33 @@ def test_config4_tiled_cube_matches_per_tile_oracle(solver, ffdnet_state_dict):
                               X_orig=np.ascontiguousarray(orig_t), model_denoise=onet, lr=2e-6, inital_iter=0,
                               interval_iter=2, update=True, update_per_iter=1)
         assert rel_l2(out[r:r + 64, c:c + 64], o['x_bayer']) <= REL_TOL, (r, c)
+
+
+def test_largest_cube_1024x1024x16_untiled(solver, ffdnet_state_dict):
+    """configs[4]'s cube reconstructed in one piece (no tiling): 16.8 M-element state tensors, 64 MiB per tensor --
+    index arithmetic, grid limits and the summation-order emulation for B = 16 at full size, per iterate vs the oracle"""
+    from adaptivepnp_sci_amd import synth
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(1024, 1024, 16, seed=11)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [2], False, [0], X_orig=orig, logf=io.StringIO())[0]
+    ot = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [2], [0], X_orig=orig)
+    for k in range(2):
+        assert rel_l2(tr.it[k], ot['x_iterates'][k]) <= REL_TOL, ('tv', k)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    from adaptivepnp_sci_amd.nets import FFDNet
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2], False, [25 / 255], x0_bayer=warm,
+                                            X_orig=orig, model_denoise=net, logf=io.StringIO())
+    with torch.no_grad():
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2], [25 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+    for k in range(2):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, ('ffdnet', k, rel_l2(tr.it[k], o['theta_iterates'][k]))
+    assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
