@@ -326,9 +326,11 @@ def _run_schedule(run, sigma, iter_max):
                                'SCIPNP_CONV_PRECISION=f32 (inputs are expected in [0,1] units like the reference)')
 
 
-def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, two_stage):
+def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, two_stage, no_orig=None):
     """Reference log text (dvp...:282-309 / :513-535), emitted after the loop."""
     name = denoiser.upper()
+    if no_orig is None:
+        no_orig = not have_orig
     k = 0
     for nsig, iters in schedule:
         for _ in range(iters):
@@ -349,7 +351,7 @@ def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, tw
                     print(line)
                     logf.write(line + '\n')
             k += 1
-            if two_stage and (not have_orig) and ((k + 1) % 2 == 0):
+            if two_stage and no_orig and ((k + 1) % 2 == 0):       # only when X_orig is None (reference :307-309)
                 logf.write('  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255 \n'.format(name, k + 1, nsig * 255))
 
 
@@ -381,7 +383,7 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                   close_form_demosaic=close_form_demosaic, model_demosaic=model_demosaic)
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
-    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True)
+    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True, run.orig is None)
     x_bayer_np = run.result_mosaic().cpu().numpy()
     psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
