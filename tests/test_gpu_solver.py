@@ -382,3 +382,15 @@ def test_without_ground_truth_and_without_iqa(solver, ffdnet_state_dict):
     assert quiet[2] == full[2] and quiet[3] == full[3] and len(quiet[2]) == 8
     tv = solver.admm_denoise_bayer_demosaic_pre(y, Phi, denoiser='tv', iter_max=[3], sigma=[0], X_orig=None, logf=None)
     assert tv[1] == [] and tv[2] == [] and tv[3] == [] and tv[0].shape == (48, 64, 8)
+
+
+def test_log_text_equals_the_reference(solver):
+    """every branch of the reference's log formatting (sigma < 1 / >= 1, noise_estimate, blind, quiet; both solvers),
+    captured from the reference run into tests/golden/log_text_16x16x4.npz"""
+    g = load_gold('log_text_16x16x4')
+    for name, fn in (('two', solver.twoStageAdmm_denoise_bayer), ('one', solver.admm_denoise_bayer_demosaic_pre)):
+        for tag, ne, orig, iqa in (('est_off', False, g['orig'], True), ('est_on', True, g['orig'], True),
+                                   ('blind', False, None, True), ('quiet', False, g['orig'], False)):
+            logf = io.StringIO()
+            fn(g['y'], g['Phi'], 1, 0.01, 'tv', [3, 3], ne, [0.1, 2], x0_bayer=None, X_orig=orig, show_iqa=iqa, logf=logf)
+            assert logf.getvalue() == str(g[f'{name}_{tag}']), (name, tag, logf.getvalue())

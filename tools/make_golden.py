@@ -475,7 +475,25 @@ def g_ddnet():
          psnr_ffdnet=res[4], theta_fastdvd=ref_it2, rgb_fastdvd=res2[0])
 
 
-GROUPS = dict(ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+def g_logs():
+    """Log text of both solvers (dvp...:282-309, :513-535) for every branch of the formatting code: sigma < 1 and
+    sigma >= 1, noise_estimate on/off, with and without ground truth; tiny TV problems, real reference run."""
+    y, Phi, orig = synth.make_problem(16, 16, 4, seed=31)
+    out = {}
+    for solver_name, fn in (('two', R.twoStageAdmm_denoise_bayer), ('one', R.admm_denoise_bayer_demosaic_pre)):
+        for tag, kw in (('est_off', dict(noise_estimate=False, X_orig=orig)), ('est_on', dict(noise_estimate=True, X_orig=orig)),
+                        ('blind', dict(noise_estimate=False, X_orig=None)), ('quiet', dict(noise_estimate=False, X_orig=orig, show_iqa=False))):
+            logf = io.StringIO()
+            seed_all()
+            extra = dict(model_denoise=None) if solver_name == 'two' else dict(model=None)
+            fn(y, Phi, 1, 0.01, 'tv', [3, 3], kw['noise_estimate'], [0.1, 2], x0_bayer=None, X_orig=kw['X_orig'],
+               show_iqa=kw.get('show_iqa', True), logf=logf, **extra)
+            out[f'{solver_name}_{tag}'] = np.array(logf.getvalue())
+            print(f'   {solver_name}_{tag}: {logf.getvalue()!r}')
+    save('log_text_16x16x4', y=y, Phi=Phi, orig=orig, **out)
+
+
+GROUPS = dict(logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
