@@ -635,3 +635,37 @@ def test_split_wgrad_bgrad_backward_data_vs_autograd(ops):
         got = ops.from_c8(ops.c8s_to_c8(dx, scale=1 / S))[:, :ci_r].cpu()
         ref = xd.grad * (x > 0)
         assert rel_l2(got.numpy(), ref.numpy()) < 2e-6, (ci_r, co_r)
+
+
+def test_denoiser_plugins_with_online_update_vs_oracle(ffdnet_state_dict):
+    """the reference's plug-in entry points called directly with updata_=True (finetune on the measurement loss, then
+    denoise): ffdnet_rgb_denoise_full_tensor (test_ffdnet_ipol.py:240-359) and fastdvdnet_denoiser_full_tensor_v2
+    (test_fastdvdnet.py:325-500) on reference-layout yall (M,N,4) / Phiall (M,N,B,4)"""
+    from adaptivepnp_sci_amd import fastdvdnet_denoiser_full_tensor_v2, ffdnet_rgb_denoise_full_tensor, synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import denoisers as OD
+    from oracle import nets as ON
+    from oracle import sci_ops as OO
+    y, Phi, orig = synth.make_problem(48, 64, 8, seed=17)
+    yall, Phiall, _ps, _x0 = OO.setup_planes(torch.from_numpy(y), torch.from_numpy(Phi))
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(np.clip(np.repeat(orig[:, :, None, :], 3, 2) + 0.05 * rng.standard_normal((48, 64, 3, 8)), 0, 1)
+                         .astype(np.float32))
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    out, net2 = ffdnet_rgb_denoise_full_tensor(dev(x), dev(yall), dev(Phiall), 25 / 255, net, True, 2e-6, True, 2)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    ref, onet2 = OD.ffdnet_pass(x.clone(), yall, Phiall, 25 / 255, onet, 2e-6, True, 2)
+    assert net2 is net and rel_l2(out.cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    w_got, w_ref = net.state_dict()['model.2.weight'], onet2.state_dict()['model.2.weight']
+    assert not torch.equal(w_got, ffdnet_state_dict['model.2.weight'])
+    assert rel_l2((w_got - ffdnet_state_dict['model.2.weight']).numpy(), (w_ref - ffdnet_state_dict['model.2.weight']).numpy()) < 2e-2
+    # FastDVDnet: same noise for both sides (the reference draws it from the global NumPy RNG)
+    fnet = torch.nn.DataParallel(synth.synth_fastdvdnet(0))
+    onet = torch.nn.DataParallel(ON.synth_fastdvdnet_weights(0))
+    np.random.seed(5)
+    out, _ = fastdvdnet_denoiser_full_tensor_v2(dev(x), 8 / 255, dev(yall), dev(Phiall), fnet, True, 2e-6, True, 1)
+    np.random.seed(5)
+    ref, _ = OD.fastdvdnet_pass(x.clone(), 8 / 255, yall, Phiall, onet, 2e-6, True, 1)
+    assert rel_l2(out.cpu().numpy(), ref.detach().numpy()) <= 1e-5
