@@ -69,8 +69,9 @@ class AdmmRun:
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
                  update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None):
-        if denoiser not in DENOISERS:
+        if str(denoiser).lower() not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+        denoiser = denoiser.lower()                # the reference compares denoiser.lower() (:146, :164, :214)
         _lib.load()
         _lib.require_gpu()
         self.device = torch.device('cuda', torch.cuda.current_device())
@@ -372,8 +373,9 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                inital_iter=1, interval_iter=5, logf=None, useGPU=True, update_=False,
                                update_per_iter=1, close_form_demosaic=False,
                                large=False, update_times=-1, args=None):
-    if denoiser not in DENOISERS:
+    if str(denoiser).lower() not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+    denoiser = denoiser.lower()
     _check_demosaic(denoiser, demosaic_method, model_demosaic)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
@@ -398,8 +400,9 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                     lr_=0.000001,
                                     inital_iter=1, interval_iter=5, logf=None, useGPU=True, device=0,
                                     update_=False, update_per_iter=1):
-    if denoiser not in DENOISERS:
+    if str(denoiser).lower() not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+    denoiser = denoiser.lower()
     _check_demosaic(denoiser, demosaic_method)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)

@@ -382,6 +382,9 @@ def test_without_ground_truth_and_without_iqa(solver, ffdnet_state_dict):
     assert quiet[2] == full[2] and quiet[3] == full[3] and len(quiet[2]) == 8
     tv = solver.admm_denoise_bayer_demosaic_pre(y, Phi, denoiser='tv', iter_max=[3], sigma=[0], X_orig=None, logf=None)
     assert tv[1] == [] and tv[2] == [] and tv[3] == [] and tv[0].shape == (48, 64, 8)
+    # scalar schedule arguments and a denoiser name in another case (the reference lower-cases it)
+    tv2 = solver.admm_denoise_bayer_demosaic_pre(y, Phi, denoiser='TV', iter_max=3, sigma=0, X_orig=None, logf=None)
+    assert np.array_equal(tv2[0], tv[0])
 
 
 def test_log_text_equals_the_reference(solver):

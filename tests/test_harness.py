@@ -128,3 +128,27 @@ def test_drivers_match_the_oracle_with_model_carry_over(tmp_path, ffdnet_state_d
     assert np.array_equal(out3['v'], out2['v']) and np.array_equal(out3['rgb'], out2['rgb'])
     with pytest.raises(ValueError):
         harness.run_two_stage(sc, warm, 'ffdnet_color', net2, None, sch, update=True, reuse_model=True, shard=True)
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_scene_end_to_end(tmp_path, capsys):
+    """`python -m adaptivepnp_sci_amd.harness scene --weights ...`: TV warm start (saved, then re-used on the second
+    call), two-stage FFDNet with the Beauty schedule and online finetune, result .mat and log file"""
+    import scipy.io as sio
+    meas, mask, orig = _scene_arrays(64, 64, 8, 1)
+    scene = str(tmp_path / 'Beauty_bayer.npz')
+    np.savez(scene, meas_bayer=meas[:, :, 0], mask_bayer=mask, orig_bayer=orig)
+    weights = os.path.join(os.path.dirname(__file__), 'golden', 'ffdnet_color_weights.npz')
+    res = str(tmp_path / 'results')
+    assert harness.main([scene, '--denoiser', 'ffdnet_color', '--weights', weights, '--results', res]) == 0
+    warm = harness.warm_start_path(res, harness.load_scene(scene))
+    assert os.path.exists(warm)
+    out = [f for f in os.listdir(os.path.join(res, 'savedmat')) if f.startswith('twoStageAdmm_ffdnet_color_Beauty_bayer8_sigma6')]
+    assert len(out) == 1
+    saved = sio.loadmat(os.path.join(res, 'savedmat', out[0]))
+    assert saved['v_twoStageAdmm_ffd_gray_bayer'].shape == (64, 64, 8) and saved['psnr_ffd_gray'].shape == (8, 1)
+    log = open(os.path.join(res, 'log.txt')).read()
+    assert log.startswith('cacti midscale bayer: \n') and 'tv_denoiser start...' in log and 'FFDnet-rgb-demosaic start.' in log
+    mtime = os.path.getmtime(warm)
+    assert harness.main([scene, '--denoiser', 'ffdnet_color', '--weights', weights, '--results', res, '--no-update']) == 0
+    assert os.path.getmtime(warm) == mtime                       # the saved warm start was loaded, not recomputed
