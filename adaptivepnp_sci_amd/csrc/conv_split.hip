@@ -594,23 +594,28 @@ static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
 template <int STRIDE, int SHUF>
 static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
     const int CoutP = a.CoutP_total;
+    // stride-1 layers (plain or PixelShuffle store) run in the single-buffered-weights form, three workgroups per CU
+    // (2-16 % ahead of the fully double-buffered two-workgroup form across the layer shapes and boxes measured; flag
+    // 0x200 selects the latter for tools/conv_bench.py); 128-channel multiples as two 64-channel halves (the 4-block
+    // form needs 288 VGPRs = one workgroup per CU).  Stride-2 layers keep the double-buffered form (their 17 x 65
+    // input tile leaves room for one workgroup either way).
+    constexpr int WS = STRIDE == 1 ? 1 : 0;
+    const bool ws = WS && !(a.flags & 0x200);
     if (CoutP % 96 == 0) {
         a.nsplit = CoutP / 96;
         if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return launch_split<3, 1, 1, 0>(a, n, st);
-        // stride-1 96-channel layers: weights single-buffered, three workgroups per CU (consistently 2-5 % ahead of the
-        // fully double-buffered two-workgroup form, flag 0x200, across the boxes measured; flag 0x400: 16x16x32 MFMA form)
-        if (STRIDE == 1 && !SHUF && (a.flags & 0x400)) return launch_split_k32<3, 0>(a, n, st);
-        if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<3, 0, 1, 0, 2, 4, 1>(a, n, st);
+        if (STRIDE == 1 && !SHUF && (a.flags & 0x400)) return launch_split_k32<3, 0>(a, n, st);     // 16x16x32 MFMA form
+        if (ws) return launch_split<3, 0, STRIDE, SHUF, 2, 4, WS>(a, n, st);
         return launch_split<3, 0, STRIDE, SHUF>(a, n, st);
     }
-    if (CoutP % 128 == 0) { a.nsplit = CoutP / 128; return launch_split<4, 0, STRIDE, SHUF>(a, n, st); }
     if (CoutP % 64 == 0) {
+        if (ws) { a.nsplit = CoutP / 64; return launch_split<2, 0, STRIDE, SHUF, 2, 4, WS>(a, n, st); }
+        if (CoutP % 128 == 0) { a.nsplit = CoutP / 128; return launch_split<4, 0, STRIDE, SHUF>(a, n, st); }
         a.nsplit = CoutP / 64;
-        if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<2, 0, 1, 0, 2, 4, 1>(a, n, st);
         return launch_split<2, 0, STRIDE, SHUF>(a, n, st);
     }
     a.nsplit = CoutP / 32;
-    if (STRIDE == 1 && !SHUF && !(a.flags & 0x200)) return launch_split<1, 0, 1, 0, 2, 4, 1>(a, n, st);
+    if (ws) return launch_split<1, 0, STRIDE, SHUF, 2, 4, WS>(a, n, st);
     return launch_split<1, 0, STRIDE, SHUF>(a, n, st);
 }
 
