@@ -603,7 +603,7 @@ static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
     const bool ws = WS && !(a.flags & 0x200);
     if (CoutP % 96 == 0) {
         a.nsplit = CoutP / 96;
-        if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return launch_split<3, 1, 1, 0>(a, n, st);
+        if (STRIDE == 1 && !SHUF && (a.flags & 0x100)) return ws ? launch_split<3, 1, 1, 0, 2, 4, 1>(a, n, st) : launch_split<3, 1, 1, 0>(a, n, st);
         if (STRIDE == 1 && !SHUF && (a.flags & 0x400)) return launch_split_k32<3, 0>(a, n, st);     // 16x16x32 MFMA form
         if (ws) return launch_split<3, 0, STRIDE, SHUF, 2, 4, WS>(a, n, st);
         return launch_split<3, 0, STRIDE, SHUF>(a, n, st);
