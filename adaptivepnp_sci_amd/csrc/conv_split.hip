@@ -876,4 +876,20 @@ int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n
     return launch_status("c8_scale_to_c8s_kernel");
 }
 
+int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                              void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8s && out_c8 && packed_split && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
+    void* buf[2] = {scratch0, scratch1};
+    int rc = scipnp_conv3x3_c8s(in_c8s, packed_split[0], buf[0], B, 16, nc, M, N, 1 | 0x100, s);
+    if (rc) return rc;
+    int cur = 0;
+    for (int l = 1; l < nb - 1; ++l) {
+        rc = scipnp_conv3x3_c8s(buf[cur], packed_split[l], buf[cur ^ 1], B, nc, nc, M, N, 1, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return scipnp_conv3x3_c8s(buf[cur], packed_split[nb - 1], out_c8, B, nc, 16, M, N, 32, s);
+}
+
 }  // extern "C"

@@ -165,3 +165,19 @@ class FFDNetEngine:
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, 'scipnp_ffdnet_forward')
         return out_c8
+
+    def forward_c_entry_split(self, in_c8s=None, out_c8=None):
+        """The split-fp16 pass through its single C entry point scipnp_ffdnet_forward_c8s."""
+        if self.precision != 'f16x3':
+            raise _lib.ScipnpError('engine was built with precision f32')
+        in_c8s = self.in_c8s if in_c8s is None else in_c8s
+        out_c8 = self.out_c8 if out_c8 is None else out_c8
+        lib = _lib.load()
+        _lib.require_gpu()
+        ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed_split])
+        rc = lib.scipnp_ffdnet_forward_c8s(C.c_void_p(in_c8s.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, self.nb,
+                                           self.nc, C.c_void_p(self.scratch[0].data_ptr()),
+                                           C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, 'scipnp_ffdnet_forward_c8s')
+        return out_c8

@@ -256,6 +256,11 @@ int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n
  * -- models/network_ffdnet.py:54-69 called per frame by packages/ffdnet/test_ffdnet_ipol.py:340-354 */
 int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const* packed, int nb, int nc,
                           float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+/* the same on the split-fp16 kernels (the default precision): in_c8s [B][2][2][M*N][8] fp16 from
+ * scipnp_pm_pre_denoise_ex, fp32 c8 output, packed_split from scipnp_pack_conv3x3_split(_device), two c8s scratch
+ * buffers of B*nc*M*N*4 bytes each */
+int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                              void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------- online finetune (measurement loss)
  * -- packages/ffdnet/test_ffdnet_ipol.py:248-300: Adam steps on  MSE( sum_t Phi * bayer_sample(net(x)), y ).

@@ -669,3 +669,27 @@ def test_denoiser_plugins_with_online_update_vs_oracle(ffdnet_state_dict):
     np.random.seed(5)
     ref, _ = OD.fastdvdnet_pass(x.clone(), 8 / 255, yall, Phiall, onet, 2e-6, True, 1)
     assert rel_l2(out.cpu().numpy(), ref.detach().numpy()) <= 1e-5
+
+
+def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict):
+    """scipnp_ffdnet_forward (fp32) and scipnp_ffdnet_forward_c8s (split-fp16): the whole 12-layer pass as ONE C-ABI
+    call each, bit-identical to the layer-by-layer launches the solver issues"""
+    from adaptivepnp_sci_amd.nets import FFDNet, FFDNetEngine
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, 16, 20, 36, generator=g)
+    x[:, 12] = 25 / 255
+    x[:, 13:] = 0
+    for prec in ('f32', 'f16x3'):
+        eng = FFDNetEngine(net, 3, 20, 36, torch.device('cuda'), precision=prec)
+        eng.in_c8.copy_(__import__('adaptivepnp_sci_amd').ops.to_c8(x.cuda()))
+        if prec == 'f16x3':
+            from adaptivepnp_sci_amd import ops as O
+            eng.in_c8s.copy_(O.c8_to_c8s(eng.in_c8))
+            a = eng.forward().clone()
+            b = eng.forward_c_entry_split().clone()
+        else:
+            a = eng.forward().clone()
+            b = eng.forward_c_entry().clone()
+        assert torch.equal(a, b), prec
