@@ -1,0 +1,56 @@
+// One whole ADMM iteration as ONE C-ABI call: the launch sequence the Python stepper (solver.AdmmRun.step) issues,
+// for hosts that run the solver loop natively.
+//   two-stage + FFDNet-colour (Malvar demosaic):  dvp_linear_inv_2_stage_ADMM_tensor_online.py:121-271, one pass
+//   ADMM-TV, either solver:                       :121-160 + :265-271  /  :385-407 + :500-509
+#include "common.hpp"
+
+using namespace scipnp;
+
+extern "C" {
+
+int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(a, "null argument block");
+    SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_in_c8s &&
+                   a->net_out_c8 && a->packed_split && a->scratch0 && a->scratch1, "null pointer in argument block");
+    SCIPNP_REQUIRE(a->rho > 0.f && a->tau > 0.f, "rho and tau must be positive");
+    const int M = a->M, N = a->N, B = a->B;
+    const float inv_rho = 1.0f / a->rho, inv_tau = 1.0f / a->tau;
+    // x = p + Phi^T((y - Phi p)/(alpha rho + Phi Phi^T)),  p = theta - b/rho                      (:128-140)
+    int rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, inv_rho, a->alpha * a->rho, s);
+    if (rc) return rc;
+    // mosaic of x + b/rho, Malvar demosaic, x_rgb - w/tau, FFDNet input (pixel-unshuffle + sigma map, c8s)   (:168-198)
+    rc = scipnp_pm_pre_denoise_ex(a->x, a->b, a->w, a->x_rgb, nullptr, nullptr, a->net_in_c8s, M, N, B, inv_rho, inv_tau,
+                                  a->sigma, s);
+    if (rc) return rc;
+    rc = scipnp_ffdnet_forward_c8s(a->net_in_c8s, a->net_out_c8, a->packed_split, a->nb, a->nc, a->scratch0, a->scratch1, B, M,
+                                   N, s);
+    if (rc) return rc;
+    // theta = clip(CFA samples of the denoised frames), b += x - theta, w += x_rgb - out, PSNR partials   (:206-209, :265-281)
+    return scipnp_pm_post_denoise(nullptr, a->net_out_c8, a->out_rgb, a->x, a->x_rgb, a->theta, a->b, a->w, a->orig,
+                                  a->sse_part, a->first_iter, M, N, B, nblocks, s);
+}
+
+int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(a, "null argument block");
+    SCIPNP_REQUIRE(a->theta && a->b && a->x && a->theta_raw && a->Phi && a->y && a->Phisum && a->tv_workspace,
+                   "null pointer in argument block");
+    const int M = a->M, N = a->N, B = a->B;
+    int rc;
+    float coef, sign;
+    if (a->two_stage) {
+        SCIPNP_REQUIRE(a->c0 > 0.f, "rho must be positive");
+        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, 1.0f / a->c0, a->c1 * a->c0, s);
+        coef = 1.0f / a->c0; sign = +1.0f;                 // theta = TV(x + b/rho), b += x - theta
+    } else {
+        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 1, a->c0, a->c1, s);
+        coef = -1.0f; sign = -1.0f;                         // theta = TV(x - b),     b -= x - theta
+    }
+    if (rc) return rc;
+    rc = scipnp_tv_chambolle(a->x, a->b, coef, a->theta_raw, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->tv_workspace,
+                             a->tv_workspace_bytes, nullptr, s);
+    if (rc) return rc;
+    return scipnp_pm_dual_update(a->theta_raw, a->x, a->theta, a->b, a->orig, a->sse_part, a->two_stage ? 0 : 1, sign, M, N, B,
+                                 nblocks, s);
+}
+
+}  // extern "C"

@@ -341,6 +341,49 @@ int scipnp_frame_metrics(const float* ref_state, const float* img_state, double*
                          double data_range, int* nblocks, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Whole ADMM iterations as single calls: the launch sequences of the solver loop for hosts that run it natively
+ * (the Python stepper issues the same launches one by one).  All pointers are device pointers in the plane-major
+ * layouts above; nothing is allocated or synchronised.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* two-stage ADMM + FFDNet-colour, Malvar demosaic (dvp...:121-271, one pass of the loop body):
+ *   x = project(theta, b);  x_rgb = malvar(mosaic(x + b/rho));  out = FFDNet(x_rgb - w/tau, sigma);
+ *   theta = clip(CFA(out));  b += x - theta;  w += x_rgb - out;  optional squared-error partials vs orig. */
+typedef struct {
+    int M, N, B;                        /* quarter-resolution plane size (H/2, W/2), frames */
+    float *theta, *b, *x;               /* state [B][4][M][N]; theta holds the start point at the first iteration */
+    const float *Phi, *y, *Phisum;      /* [B][4][M][N], [4][M][N], [4][M][N] (scipnp_pm_setup) */
+    float *w, *x_rgb;                   /* RGB dual and demosaicked frames [B][3][2M][2N] */
+    float* out_rgb;                     /* denoised frames [B][3][2M][2N], or NULL when not wanted this iteration */
+    void* net_in_c8s;                   /* FFDNet input  [B][2][2][M*N][8] fp16 */
+    float* net_out_c8;                  /* FFDNet output [B][2][M][N][8] fp32 */
+    const void* const* packed_split;    /* nb packed layers (scipnp_pack_conv3x3_split) */
+    int nb, nc;                         /* 12, 96 for ffdnet_color */
+    void *scratch0, *scratch1;          /* B*nc*M*N*4 bytes each */
+    const float* orig;                  /* ground truth state [B][4][M][N] or NULL */
+    double* sse_part;                   /* per-block partial sums for the PSNR, or NULL */
+    float rho, alpha, tau, sigma;       /* reference constants: rho = 1, alpha = 1, tau = 100 (:101-110) */
+    int first_iter;                     /* 1 on the very first iteration (x and theta are one tensor there) */
+} scipnp_twostage_ffdnet_args;
+int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
+
+/* ADMM-TV iteration of either solver (dvp...:121-160, :265-271 two-stage; :385-407, :500-509 one-stage):
+ * two_stage != 0: c0 = rho, c1 = alpha (theta = TV(x + b/rho), b += x - theta);
+ * two_stage == 0: c0 = lambda, c1 = gamma (theta = TV(x - b), b -= x - theta). */
+typedef struct {
+    int M, N, B, two_stage;
+    float *theta, *b, *x, *theta_raw;   /* state [B][4][M][N] */
+    const float *Phi, *y, *Phisum;
+    float c0, c1, tv_weight;            /* tv_weight = 0.1 in the reference */
+    int tv_iters;                       /* n_iter_max = 5 in the reference */
+    void* tv_workspace;                 /* scipnp_tv_workspace_bytes(M, N, 4*B, tv_iters) */
+    size_t tv_workspace_bytes;
+    const float* orig;
+    double* sse_part;
+} scipnp_admm_tv_args;
+int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * DDnet deep demosaicking -- glue around scipnp_conv3x3_c8 / _c8s.
  * reference: models/network_demosaicking.py:381-463 (DDnet.forward), :186-244, :310-379 (DenBlocks),
  *            packages/DDnet/DDnet_test.py:166-216 (circular 5-frame window), dvp...:192-194, :242-244 (call sites)
