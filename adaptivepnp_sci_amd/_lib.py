@@ -96,6 +96,16 @@ SIGNATURES = {
     'scipnp_ffdnet_forward_c8s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
 }
 
+class AdmmTvArgs(C.Structure):
+    """scipnp_admm_tv_args of include/scipnp.h"""
+    _fields_ = [('M', C.c_int), ('N', C.c_int), ('B', C.c_int), ('two_stage', C.c_int),
+                ('theta', C.c_void_p), ('b', C.c_void_p), ('x', C.c_void_p), ('theta_raw', C.c_void_p),
+                ('Phi', C.c_void_p), ('y', C.c_void_p), ('Phisum', C.c_void_p),
+                ('c0', C.c_float), ('c1', C.c_float), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
+                ('tv_workspace', C.c_void_p), ('tv_workspace_bytes', C.c_size_t),
+                ('orig', C.c_void_p), ('sse_part', C.c_void_p)]
+
+
 _lib = None
 
 

@@ -18,6 +18,7 @@ Documented deviations from the reference:
   * `logf=None` is accepted (no-op writer); arrays may be NumPy or CUDA tensors;
   * log lines are printed after the loop instead of during it (identical text).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -123,6 +124,13 @@ class AdmmRun:
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
             self.theta_raw = torch.empty_like(x0)
+            # the whole iteration is one C call (scipnp_admm_tv_iterate): ten launches of 5-25 us are host-bound when
+            # issued one ctypes call at a time
+            c0, c1 = (self.rou, self.alpha) if two_stage else (self._lambda, self.gamma)
+            self._tv_args = _lib.AdmmTvArgs(M, N, B, int(two_stage), self.theta.data_ptr(), self.b.data_ptr(), self.x.data_ptr(),
+                                            self.theta_raw.data_ptr(), self.Phi.data_ptr(), self.y.data_ptr(),
+                                            self.Phisum.data_ptr(), float(c0), float(c1), 0.1, 5, self.plan.ptr,
+                                            self.plan.nbytes, 0 if self.orig is None else self.orig.data_ptr(), 0)
         else:
             self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
             self.w = torch.zeros_like(self.x_rgb) if two_stage else None
@@ -146,6 +154,16 @@ class AdmmRun:
     def step(self, nsig, last=False):
         B, M, N = self.B, self.M, self.N
         k = self.k
+        if self.denoiser == 'tv' and self.phi_events is None:
+            part = self._new_sse(ops.sse_nblocks(self.x.numel())) if self.iqa else None
+            self._tv_args.sse_part = 0 if part is None else part.data_ptr()
+            _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(self._tv_args), None,
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       'scipnp_admm_tv_iterate')
+            if ITERATE_HOOK is not None:
+                ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
+            self.k += 1
+            return
         if self.phi_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
