@@ -194,6 +194,10 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):                           # measured in separate rocprofv3 --pmc passes, see the file's note
         traffic = json.load(open(tpath)).get(run.eng.precision, {}).get('hbm_bytes_per_launch')
+    measured = {}
+    mpath = os.path.join(ROOT, 'profiles', 'measured_peaks.json')
+    if os.path.exists(mpath):                          # tools/peaks_bench.py on an MI355X of the pool: register-resident MFMA loop
+        measured = json.load(open(mpath))              # on random operands, HBM read stream
     body_ms = [a.elapsed_time(b) for a, b in events]
     body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
     psnr = run.psnr_all()
@@ -228,11 +232,20 @@ def main():
                          # matrix pipes execute 3.11x that in fp16 products
                          'mfma_flop_executed_over_algorithmic': SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0,
                          'matrix_pipe_frac_of_peak': achieved * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) / peak,
-                         'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA},
+                         'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
+                         # the ceiling MEASURED with a register-resident MFMA loop on random operands (no memory traffic):
+                         # what the part sustains under its own clock management, vs the 2.5 PFLOP/s vendor figure
+                         'peak_measured': (measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs') if precision == 'f16x3'
+                                           else measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')),
+                         'matrix_pipe_frac_of_measured_peak': (
+                             achieved / 1e12 * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) /
+                             measured['mfma_f16_32x32x16_2wave_per_simd_TFLOPs' if precision == 'f16x3'
+                                      else 'mfma_f32_32x32x2_2wave_per_simd_TFLOPs']) if measured else None},
             # the Phi / Phi^T Phi projection step (north_star: HBM fraction), one launch per iteration, HIP events
             'phi_step': {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
                          'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
                          'achieved': phi_bytes / phi_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': phi_bytes / phi_s / 8e12,
+                         'peak_measured': measured.get('hbm_read_GBs'),
                          'note': 'event pair around one ~10 us launch includes ~2-3 us of event/launch overhead; rocprofv3 '
                                  'kernel time is in profiles/'},
             'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None],

@@ -411,6 +411,16 @@ int scipnp_bilinear_up2_c8(const float* in, float* out_c8, void* out_c8s, int E,
 /* x_out = gates[0][c]*branches[n] + gates[1][c]*branches[B+n], planar [2B][3][H*W] -> [B][3][H*W]  -- :461 */
 int scipnp_ddnet_mix(const float* branches, const float* gates, float* out, int B, int H, int W, scipnp_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Diagnostics: measured ceilings for the rooflines (tools/peaks_bench.py; not on the reconstruction path).
+ * scipnp_bench_mfma: register-resident MFMA loop on pseudo-random operands, mode 0 v_mfma_f32_32x32x16_f16,
+ * 1 v_mfma_f32_16x16x32_f16, 2 v_mfma_f32_32x32x2_f32; `blocks` workgroups of 4 waves, iters x 4 (mode 1: x 8)
+ * independent MFMAs per wave; out: blocks*256 floats.  scipnp_bench_stream: mode 0 reads n floats (sink: blocks*256
+ * floats), mode 1 copies n floats.
+ * ------------------------------------------------------------------------------------------------------------- */
+int scipnp_bench_mfma(float* out, int blocks, int iters, int mode, scipnp_stream_t s);
+int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
