@@ -517,7 +517,14 @@ class NoisePrefetch:
             self.q.put(np.random.normal(0, 5 / 255, shape))
 
     def get(self):
-        return self.q.get()
+        """next draw, or None once every planned draw has been handed out (the caller then draws synchronously)"""
+        import queue
+        while True:
+            try:
+                return self.q.get(timeout=0.05)
+            except queue.Empty:
+                if not self.t.is_alive() and self.q.empty():
+                    return None
 
 
 def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None,
