@@ -81,6 +81,31 @@ def test_argument_errors_are_reported(lib):
     assert rc == -2 and b'aligned' in lib.scipnp_last_error()
 
 
+def test_argument_errors_of_the_wider_entries(lib):
+    """validation happens before any launch, so the error behaviour of every family of entries is checkable without a GPU"""
+    p = C.c_void_p(256)
+    # split conv: incompatible epilogue flags
+    assert lib.scipnp_conv3x3_c8s_ex(p, p, p, None, None, 1, 96, 96, 8, 8, 16, None) == -1      # mask flag without mask
+    assert b'mask' in lib.scipnp_last_error()
+    assert lib.scipnp_conv3x3_c8s_ex(p, p, p, None, None, 1, 96, 96, 8, 8, 4 | 8, None) == -1   # stride 2 + pixel shuffle
+    assert lib.scipnp_conv3x3_c8s_ex(p, p, p, None, None, 1, 96, 80, 8, 8, 8, None) == -1       # shuffle needs Cout % 32 == 0
+    assert lib.scipnp_conv3x3_c8s_ex(p, p, p, p, None, 1, 96, 96, 8, 8, 2 | 8, None) == -1      # residual + fp32 shuffle store
+    # iteration-level entries: null block / null members
+    assert lib.scipnp_twostage_ffdnet_iterate(None, None, None) == -1 and b'null' in lib.scipnp_last_error()
+    from adaptivepnp_sci_amd import _lib
+    tv = _lib.AdmmTvArgs()
+    assert lib.scipnp_admm_tv_iterate(C.byref(tv), None, None) == -1 and b'null' in lib.scipnp_last_error()
+    # DDnet glue, metrics, weight gradients
+    assert lib.scipnp_ddnet_gather(p, p, None, p, None, 4, 2, 8, 8, None) == -1 and b'1, 3 or 4' in lib.scipnp_last_error()
+    nb = C.c_int(0)
+    assert lib.scipnp_frame_metrics(p, p, p, 2, 2, 8, 7, 1.0, C.byref(nb), None) == -1          # 4x4 image < 7x7 window
+    assert b'win_size' in lib.scipnp_last_error()
+    assert lib.scipnp_frame_metrics(None, None, None, 32, 32, 8, 7, 1.0, C.byref(nb), None) == 0 and nb.value == 16   # size query
+    assert lib.scipnp_conv3x3_wgrad_split(p, p, p, p, 0, 1, 96, 96, 96, 96, 8, 8, 1.0, None) == -1   # nslab = 0
+    assert lib.scipnp_conv3x3_wgrad_split(C.c_void_p(260), p, p, p, 4, 1, 96, 96, 96, 96, 8, 8, 1.0, None) == -2
+    assert lib.scipnp_bench_mfma(p, 1, 1, 7, None) == -1
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
 def test_no_cpu_fallback():
     from adaptivepnp_sci_amd import _lib, synth, twoStageAdmm_denoise_bayer
