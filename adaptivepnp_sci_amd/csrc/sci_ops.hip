@@ -231,6 +231,7 @@ rgb_cube_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, i
 // 16 B per (pixel,frame) + 8 B per pixel of measurement = the algorithmic minimum.
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<4> { using type = float4; };
 
 template <int VEC, int MAXB, int MODE>  // MODE 0 two-stage, 1 one-stage, 2 setup (Phi_sum, x0 = y*Phi)
@@ -320,6 +321,7 @@ static int launch_pm_project(const float* theta, const float* b, const float* Ph
                        theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1)
     if (vec && B <= 8) SCIPNP_GO(4, 8);
     else if (vec && B <= 16) SCIPNP_GO(4, 16);
+    else if (vec) SCIPNP_GO(2, 32);              // 17..32 frames: 2 pixels per thread keep p and Phi in 128 registers
     else if (B <= 8) SCIPNP_GO(1, 8);
     else SCIPNP_GO(1, 32);
 #undef SCIPNP_GO

@@ -693,3 +693,23 @@ def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict
             a = eng.forward().clone()
             b = eng.forward_c_entry().clone()
         assert torch.equal(a, b), prec
+
+
+def test_pm_project_with_more_than_16_frames(ops):
+    """B in 17..32 takes the two-pixels-per-thread path; bit-exact against the oracle's projection"""
+    from oracle import sci_ops as OO
+    rng = np.random.default_rng(8)
+    M, N, B = 12, 20, 23
+    theta, b = rng.random((M, N, B, 4), np.float32), (0.2 * rng.standard_normal((M, N, B, 4))).astype(np.float32)
+    Phi = (rng.random((M, N, B, 4)) < 0.5).astype(np.float32)
+    y = (rng.random((M, N, 4)) * B / 2).astype(np.float32)
+    Phisum = Phi.sum(2)
+    Phisum[Phisum == 0] = 1
+    T = torch.from_numpy
+    ref = OO.project_two_stage(T(theta), T(b), T(Phi), T(y), T(Phisum), 0.55, 1.0)
+    pm = lambda a: dev(np.ascontiguousarray(a.transpose(2, 3, 0, 1)))  # noqa: E731  (M,N,B,4) -> [B][4][M][N]
+    th_d = pm(theta)
+    out = ops.pm_project(th_d, pm(b), pm(Phi), dev(np.ascontiguousarray(y.transpose(2, 0, 1))),
+                         dev(np.ascontiguousarray(Phisum.transpose(2, 0, 1))), 0, np.float32(1 / 0.55), np.float32(0.55),
+                         out=torch.empty_like(th_d))
+    assert np.array_equal(out.cpu().numpy(), ref.numpy().transpose(2, 3, 0, 1))
