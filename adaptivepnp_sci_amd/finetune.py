@@ -28,6 +28,16 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _split_slabs(cin):
+    """persistent workgroups of the split weight-gradient kernel = slabs x (Cin/32 input-channel blocks): keep their
+    product at ~255 so that every CU of the MI355X gets one workgroup whatever the layer's input width"""
+    import os
+    env = os.environ.get('SCIPNP_WGRAD_SLABS')
+    if env:
+        return int(env)
+    return max(1, 255 // ((cin + 31) // 32))
+
+
 def _carve(flat, like):
     """consecutive views of `flat` shaped like the tensors in `like` (one Adam launch covers them all)"""
     out, off = [], 0
@@ -47,9 +57,6 @@ class _FFDNetTrainer:
         self.eng = eng
         dev = eng.device
         self.split = eng.precision == 'f16x3'
-        if self.split:
-            import os
-            self.NSLAB = int(os.environ.get('SCIPNP_WGRAD_SLABS', 85))   # x 3 input-channel blocks = 255 persistent workgroups
         self.layers = ffdnet_layers(model)                # [(weight, bias)] tensors of the module (any device)
         srcs = [w.detach() for w, _ in self.layers] + [b.detach() for _, b in self.layers]
         total = sum(t.numel() for t in srcs)
@@ -76,7 +83,8 @@ class _FFDNetTrainer:
         self.gout = torch.empty(B, 2, M, N, 8, dtype=F32, device=dev)
         gviews = _carve(self.flat_g, srcs)
         self.dw, self.db = gviews[:nl], gviews[nl:]
-        ws = max(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, self.NSLAB) for ci, co in zip(self.cin, self.cout))
+        self.slabs = [_split_slabs(ci) if self.split else self.NSLAB for ci in self.cin]
+        ws = max(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, ns) for ci, co, ns in zip(self.cin, self.cout, self.slabs))
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty((nc // 8) * 64 * 8, dtype=F32, device=dev)
         nb_ = C.c_int(0)
@@ -174,7 +182,7 @@ class _FFDNetTrainer:
         for l in range(self.nb - 1, -1, -1):
             a_in = eng.in_c8s if l == 0 else self.acts_s[l - 1]
             ci_r, co_r = self._real(l)
-            _lib.check(self.lib.scipnp_conv3x3_wgrad_split(_ptr(a_in), _ptr(dz_s), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB,
+            _lib.check(self.lib.scipnp_conv3x3_wgrad_split(_ptr(a_in), _ptr(dz_s), _ptr(self.dw[l]), _ptr(self.ws), self.slabs[l],
                                                            B, ci_r, co_r, self.cin[l], self.cout[l], M, N, inv, _s()),
                        'wgrad split')
             _lib.check(self.lib.scipnp_conv_bias_grad_split(_ptr(dz_s), _ptr(self.db[l]), _ptr(self.bws), B, co_r,
@@ -358,7 +366,6 @@ class _FastDVDTrainer:
             # pre-scaled by the power of two nearest H*W/2 (the loss carries 2/(H*W)) and are un-scaled exactly where
             # they leave the convolution chain (weight / bias gradients, input-frame gradient)
             from .fastdvd import alloc_denblock_buffers_split
-            self.NSLAB = 85
             self.gscale = float(2.0 ** round(np.log2(H * W / 2.0)))
             self.stash = {p: alloc_denblock_buffers_split(B, H, W, dev, alias=False) for p in ('temp1', 'temp2')}
             f = lambda c, h, w: torch.empty(B, c // 8, 2, h, w, 8, dtype=torch.float16, device=dev)  # noqa: E731
@@ -377,7 +384,7 @@ class _FastDVDTrainer:
         self.out = torch.empty_like(self.s1)
         self.dout = torch.empty_like(self.s1)
         self.ds1 = torch.empty_like(self.s1)
-        ws = max(self.lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, self.NSLAB)
+        ws = max(self.lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, _split_slabs(ci) if self.split else self.NSLAB)
                  for _, _, ci, co, *_ in self.blocks['temp1'].spec)
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty(32 * 64 * 8, dtype=F32, device=dev)
@@ -427,7 +434,8 @@ class _FastDVDTrainer:
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         sp = self.split
         inv = 1.0 / self.gscale if sp else 1.0
-        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(i, x_in, dy, B, h, w, self.ws, self.bws, self.NSLAB, inv)  # noqa: E731
+        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(  # noqa: E731
+            i, x_in, dy, B, h, w, self.ws, self.bws, _split_slabs(blk.spec[i][2]) if sp else self.NSLAB, inv)
 
         def unshuffle(src, dst, cs, h, w):
             fn = lib.scipnp_pixel_shuffle_bwd_c8s if sp else lib.scipnp_pixel_shuffle_bwd_c8
