@@ -530,6 +530,25 @@ class _FastDVDTrainer:
             _download_flat(blk.flat_p, [self.model_sd[('module.' + key) if self.prefixed else key] for key, _p in blk.params])
 
 
+def legacy_normal(loc, scale, shape):
+    """np.random.normal(loc, scale, shape) on the GLOBAL legacy NumPy generator -- same values, same final generator
+    state -- computed by libscipnp's host function (scipnp_host_legacy_normal) with the GIL released, so that the
+    launching thread keeps feeding the GPU while 6.3 M deviates are drawn.  Falls back to NumPy itself when the global
+    generator is not the default MT19937."""
+    st = np.random.get_state()
+    if st[0] != 'MT19937':
+        return np.random.normal(loc, scale, shape)
+    lib = _lib.load()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos, has_gauss, cached = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+    out = np.empty(shape, dtype=np.float64)
+    _lib.check(lib.scipnp_host_legacy_normal(C.c_void_p(key.ctypes.data), C.byref(pos), C.byref(has_gauss), C.byref(cached),
+                                             float(loc), float(scale), C.c_void_p(out.ctypes.data), out.size),
+               'scipnp_host_legacy_normal')
+    np.random.set_state(('MT19937', key, pos.value, has_gauss.value, cached.value))
+    return out
+
+
 class NoisePrefetch:
     """The reference draws the finetune noise with np.random.normal(0, 5/255, (B,3,H,W)) from the GLOBAL NumPy RNG, one
     draw per finetune event (utils/utils_image.py:183-192) -- 6.3 M float64 normals, ~65 ms of host time at 512x512x8.
@@ -546,7 +565,7 @@ class NoisePrefetch:
 
     def _run(self, shape, count):
         for _ in range(count):
-            self.q.put(np.random.normal(0, 5 / 255, shape))
+            self.q.put(legacy_normal(0, 5 / 255, shape))
 
     def get(self):
         """next draw, or None once every planned draw has been handed out (the caller then draws synchronously)"""
@@ -570,7 +589,7 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
     steps = [update_per_iter] if isinstance(update_per_iter, int) else list(update_per_iter)
     lrs = [lr_] if isinstance(update_per_iter, int) else list(lr_)
     if noise is None:
-        noise = np.random.normal(0, 5 / 255, tuple(frames.shape))
+        noise = legacy_normal(0, 5 / 255, tuple(frames.shape))
     # frames + float32(float64(frames) + noise): the float64 sum and its rounding are done on the device (same IEEE result)
     noise_d = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float64)).to(frames.device)
     v_plus = (frames + (frames.double() + noise_d).float()).contiguous()

@@ -281,13 +281,14 @@ class AdmmRun:
         return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
 
 
-def _finetune_events(run, total):
-    """number of FastDVDnet finetune events the schedule will fire (the gate of _cnn_step, evaluated ahead of time)"""
-    if not (run.update_ and run.two_stage and run.denoiser == 'fastdvd_color'):
+def _count_finetune_events(update_, two_stage, denoiser, total, inital_iter, interval_iter, update_times, k0=0, done=0):
+    """number of FastDVDnet finetune events a schedule of `total` iterations will fire (the gate of _cnn_step, evaluated
+    ahead of time)"""
+    if not (update_ and two_stage and denoiser == 'fastdvd_color'):
         return 0
     n = 0
-    for k in range(run.k, run.k + total):
-        if k > run.inital_iter and k % run.interval_iter == 0 and (run.update_i + n < run.update_times or run.update_times < 0):
+    for k in range(k0, k0 + total):
+        if k > inital_iter and k % interval_iter == 0 and (done + n < update_times or update_times < 0):
             n += 1
     return n
 
@@ -333,10 +334,12 @@ def _run_schedule(run, sigma, iter_max):
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
             and os.environ.get('SCIPNP_HIPGRAPH', '0') == '1'):
         return _run_tv_graphed(run, total)
-    n_events = _finetune_events(run, total)
-    if n_events:
-        from .finetune import NoisePrefetch
-        run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
+    if run.noise_source is None:
+        n_events = _count_finetune_events(run.update_, run.two_stage, run.denoiser, total, run.inital_iter, run.interval_iter,
+                                          run.update_times, run.k, run.update_i)
+        if n_events:
+            from .finetune import NoisePrefetch
+            run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
     for idx, nsig in enumerate(sigma):
         for _ in range(iter_max[idx]):
             run.step(nsig, last=(run.k == total - 1))
@@ -397,10 +400,17 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     _check_demosaic(denoiser, demosaic_method, model_demosaic)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
+    # the FastDVDnet finetune's NumPy noise draw (65 ms at 512x512x8) starts before anything else, on a worker thread
+    noise_source = None
+    n_events = _count_finetune_events(update_, True, denoiser, sum(iter_max), inital_iter, interval_iter, update_times)
+    if n_events:
+        from .finetune import NoisePrefetch
+        noise_source = NoisePrefetch((np.shape(Phi_bayer)[2], 3) + tuple(np.shape(Phi_bayer)[:2]), n_events)
     run = AdmmRun(y_bayer, Phi_bayer, denoiser, True, x0_bayer, X_orig, model_denoise, show_iqa, lr_=lr_,
                   inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
                   update_per_iter=update_per_iter, update_times=update_times, logf=logf,
                   close_form_demosaic=close_form_demosaic, model_demosaic=model_demosaic)
+    run.noise_source = noise_source
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
     _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True, run.orig is None)

@@ -411,6 +411,14 @@ int scipnp_bilinear_up2_c8(const float* in, float* out_c8, void* out_c8s, int E,
 /* x_out = gates[0][c]*branches[n] + gates[1][c]*branches[B+n], planar [2B][3][H*W] -> [B][3][H*W]  -- :461 */
 int scipnp_ddnet_mix(const float* branches, const float* gates, float* out, int B, int H, int W, scipnp_stream_t s);
 
+/* HOST function (no GPU involved): n deviates of NumPy's LEGACY normal stream -- np.random.normal(loc, scale, n) on the
+ * global RandomState, bit for bit -- from / to a generator state in np.random.get_state() form (key[624], pos,
+ * has_gauss, cached_gaussian).  The reference draws its FastDVDnet finetune noise from that stream
+ * (utils/utils_image.py:183-192, packages/fastdvdnet/test_fastdvdnet.py:359); NumPy holds the GIL while it does, this
+ * entry does not. */
+int scipnp_host_legacy_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, double loc, double scale,
+                              double* out, size_t n);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Diagnostics: measured ceilings for the rooflines (tools/peaks_bench.py; not on the reconstruction path).
  * scipnp_bench_mfma: register-resident MFMA loop on pseudo-random operands, mode 0 v_mfma_f32_32x32x16_f16,
