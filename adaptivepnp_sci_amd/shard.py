@@ -49,15 +49,44 @@ def gather_units(local, n_units, unit_shape, device, dtype=torch.float32, dst=0,
     return [recv[u % world][u // world] for u in range(n_units)]
 
 
-def reconstruct_sharded(units, solve, unit_shape, device, model=None, dst=0, group=None):
+def reconstruct_sharded(units, solve, unit_shape, device, model=None, dst=0, group=None, streams=1):
     """units: list of per-unit argument tuples (same on every rank); solve(unit_args, model_copy) -> tensor of
     unit_shape on `device`.  Every unit gets its own deep copy of `model` so that the online finetune of one
-    unit cannot leak into another (parity-exact sharding)."""
+    unit cannot leak into another (parity-exact sharding).
+
+    streams > 1: this rank's units are solved by that many host threads, each on its own HIP stream -- small units
+    (256 x 256 tiles) leave CUs idle at the tail of every launch and stall on the host-side steps of a finetune event;
+    a second stream fills those gaps.  Results do not depend on it (units are independent, kernels deterministic)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = partition(len(units), world, rank)
+
+    def one(u):
+        return solve(units[u], copy.deepcopy(model) if model is not None else None)
+
     local = {}
-    for u in partition(len(units), world, rank):
-        local[u] = solve(units[u], copy.deepcopy(model) if model is not None else None)
+    if streams <= 1 or len(mine) <= 1 or not torch.cuda.is_available():
+        for u in mine:
+            local[u] = one(u)
+    else:
+        import concurrent.futures as cf
+        cur = torch.cuda.current_stream()
+        pool_streams = [torch.cuda.Stream() for _ in range(min(streams, len(mine)))]
+        for st in pool_streams:
+            st.wait_stream(cur)
+
+        def worker(j):
+            out = {}
+            with torch.cuda.stream(pool_streams[j]):
+                for u in mine[j::len(pool_streams)]:
+                    out[u] = one(u)
+            return out
+
+        with cf.ThreadPoolExecutor(len(pool_streams)) as ex:
+            for part in ex.map(worker, range(len(pool_streams))):
+                local.update(part)
+        for st in pool_streams:
+            cur.wait_stream(st)
     return gather_units(local, len(units), unit_shape, device, dst=dst, group=group)
 
 
@@ -91,12 +120,12 @@ def stitch_tiles(tiles, H, W, tile):
     return out
 
 
-def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None):
+def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None, streams=1):
     """Tile a large cube, reconstruct the patches independently on the ranks of `group` (tile j on rank j % world, each
     with its own deep copy of `model`), gather them with ONE collective and stitch on rank `dst`.
     solve((y_t, Phi_t, x0_t, orig_t), model_copy) -> (tile, tile, B) tensor on `device`.
     Returns the (H, W, B) mosaic on rank dst, None elsewhere."""
     H, W, B = Phi.shape
     units = tile_cube(y, Phi, tile, x0, orig)
-    got = reconstruct_sharded(units, solve, (tile, tile, B), device, model=model, dst=dst, group=group)
+    got = reconstruct_sharded(units, solve, (tile, tile, B), device, model=model, dst=dst, group=group, streams=streams)
     return None if got is None else stitch_tiles(got, H, W, tile)

@@ -99,3 +99,28 @@ for mode in ('1', '0'):
         admm_denoise_bayer_demosaic_pre(y0, Phi0, 1, 0.01, 'tv', [50], False, [0], X_orig=orig0, logf=io.StringIO())
         ts.append((time.perf_counter() - t0) * 1e3)
     print(f'whole ADMM-TV call 256x256x8, 50 iterations, hipGraph={mode}: {min(ts):.2f} ms (runs: {" ".join(f"{t:.1f}" for t in ts)})')
+
+# configs[4] on one GPU: four 256x256x16 tiles of a 512x512x16 cube, FFDNet [15,6,4] with the online finetune (per-tile model
+# copies), sequential vs two host threads / HIP streams
+from adaptivepnp_sci_amd import shard
+yt, Phit, origt = synth.make_problem(512, 512, 16, 1)
+os.environ['SCIPNP_CONV_PRECISION'] = 'f16x3'
+
+
+def solve_tile(args, model):
+    y_t, Phi_t, _x0, orig_t = args
+    res = twoStageAdmm_denoise_bayer(np.ascontiguousarray(y_t), np.ascontiguousarray(Phi_t), denoiser='ffdnet_color',
+                                     iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255], X_orig=np.ascontiguousarray(orig_t),
+                                     model_denoise=model, logf=io.StringIO(), lr_=2e-6, interval_iter=15, update_=True,
+                                     update_per_iter=2)
+    return torch.from_numpy(res[1]).cuda()
+
+
+model = FFDNet(); model.load_state_dict(sd)
+outs = {}
+for nstreams in (1, 2, 1, 2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outs[nstreams] = shard.reconstruct_tiled(yt, Phit, 256, solve_tile, torch.device('cuda'), orig=origt, model=model, streams=nstreams)
+    torch.cuda.synchronize()
+    print(f'four 256x256x16 tiles, FFDNet 25 its + finetune, {nstreams} stream(s): {(time.perf_counter() - t0) * 1e3:.1f} ms')
+print('identical results:', bool(torch.equal(outs[1], outs[2])))
