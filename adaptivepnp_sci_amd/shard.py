@@ -120,10 +120,13 @@ def stitch_tiles(tiles, H, W, tile):
     return out
 
 
-def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None, streams=1):
+def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None, streams=2):
     """Tile a large cube, reconstruct the patches independently on the ranks of `group` (tile j on rank j % world, each
     with its own deep copy of `model`), gather them with ONE collective and stitch on rank `dst`.
     solve((y_t, Phi_t, x0_t, orig_t), model_copy) -> (tile, tile, B) tensor on `device`.
+    Two host threads / HIP streams per rank by default: 256 x 256 tiles give the conv kernels 1024 workgroups for 768
+    resident slots and a finetune event has host-side steps; measured on one MI355X, four 256x256x16 tiles with the
+    online finetune: 200-258 ms against 454-516 ms one after the other, identical results.
     Returns the (H, W, B) mosaic on rank dst, None elsewhere."""
     H, W, B = Phi.shape
     units = tile_cube(y, Phi, tile, x0, orig)
