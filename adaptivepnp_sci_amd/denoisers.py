@@ -43,11 +43,11 @@ def _unshuffle_to_c8(x, sigma):
 
 
 def ffdnet_forward_nchw(model, x, sigma):
-    """FFDNet forward on n frames: x (n,3,H,W) CUDA float32 -> (n,3,H,W)."""
+    """FFDNet forward on n frames: x (n,3,H,W) (colour network) or (n,1,H,W) (ffdnet_gray) CUDA float32, same shape out."""
     n, _, H, W = x.shape
     in_c8, h, w = _unshuffle_to_c8(x.float().contiguous(), sigma)
     eng = _engine_for(model, n, h, w, x.device)
-    out = ops.from_c8(eng.forward(in_c8), 12)
+    out = ops.from_c8(eng.forward(in_c8), eng.out_ch)
     return F.pixel_shuffle(out, 2)[..., :H, :W].contiguous()
 
 

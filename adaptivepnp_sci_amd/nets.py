@@ -34,7 +34,7 @@ class FFDNet(nn.Module):
         self._engine = None
 
     def forward(self, x, sigma):
-        """x (n,3,H,W) CUDA tensor, sigma (1,1,1,1) or float -> (n,3,H,W); HIP kernels only."""
+        """x (n,in_nc,H,W) CUDA tensor, sigma (1,1,1,1) or float -> (n,out_nc,H,W); HIP kernels only."""
         from .denoisers import ffdnet_forward_nchw
         return ffdnet_forward_nchw(self, x, float(sigma.reshape(-1)[0]) if torch.is_tensor(sigma) else float(sigma))
 
@@ -73,18 +73,20 @@ class FFDNetEngine:
         self.refresh(model)
         nc = self.nc
         self.scratch = [torch.empty(B * nc * M * N, dtype=torch.float32, device=device) for _ in range(2)]
-        self.in_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
-        self.in_c8s = (torch.empty(B, 2, 2, M, N, 8, dtype=torch.float16, device=device)
+        self.in_c8 = torch.empty(B, self.cin0 // 8, M, N, 8, dtype=torch.float32, device=device)
+        self.in_c8s = (torch.empty(B, self.cin0 // 8, 2, M, N, 8, dtype=torch.float16, device=device)
                        if self.precision == 'f16x3' else None)
-        self.out_c8 = torch.empty(B, 2, M, N, 8, dtype=torch.float32, device=device)
+        self.out_c8 = torch.empty(B, self.cout_last // 8, M, N, 8, dtype=torch.float32, device=device)
 
     def refresh(self, model):
         """(Re)pack the weights; call after every optimizer step of the online finetune."""
         layers = ffdnet_layers(model)
         self.nb = len(layers)
         self.nc = layers[0][0].shape[0]
-        if layers[0][0].shape[1] != 13 or layers[-1][0].shape[0] != 12 or self.nc % 8:
-            raise ValueError('FFDNetEngine supports the colour network (13 -> nc -> 12 channels, nc % 8 == 0)')
+        self.in_ch, self.out_ch = layers[0][0].shape[1], layers[-1][0].shape[0]
+        if (self.in_ch, self.out_ch) not in ((13, 12), (5, 4)) or self.nc % 8:
+            raise ValueError('FFDNetEngine supports the colour (13 -> nc -> 12) and grayscale (5 -> nc -> 4) networks, nc % 8 == 0')
+        self.cin0, self.cout_last = (self.in_ch + 7) // 8 * 8, (self.out_ch + 7) // 8 * 8
         # weights travel to the device in one upload and are packed there (scipnp_pack_conv3x3_device /
         # _split_device): both layouts are kept, the fp32 one serves the C entry scipnp_ffdnet_forward
         dev_t = ops.device_params([w for w, _ in layers] + [b for _, b in layers], torch.device(self.device))
@@ -92,8 +94,8 @@ class FFDNetEngine:
         split = self.precision == 'f16x3'
         self.packed, self.packed_split = [], ([] if split else None)
         for i in range(self.nb):
-            cin = 16 if i == 0 else self.nc
-            cout = 16 if i == self.nb - 1 else self.nc
+            cin = self.cin0 if i == 0 else self.nc
+            cout = self.cout_last if i == self.nb - 1 else self.nc
             self.packed.append(ops.pack_conv3x3_device(ws[i], bs[i], ops.packed_buffer(cin, cout, self.device, False), cin, cout))
             if split:
                 self.packed_split.append(ops.pack_conv3x3_split_device(ws[i], bs[i], ops.packed_buffer(cin, cout, self.device, True),
@@ -129,7 +131,7 @@ class FFDNetEngine:
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        ops.conv3x3_c8(buf[cur], self.packed[self.nb - 1], 16, relu=False, out=out_c8)
+        ops.conv3x3_c8(buf[cur], self.packed[self.nb - 1], self.cout_last, relu=False, out=out_c8)
         return out_c8
 
     def _forward_split(self, in_c8, out_c8, events):
@@ -150,11 +152,13 @@ class FFDNetEngine:
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        ops.conv3x3_c8s(buf[cur], pk[self.nb - 1], 16, relu=False, out=out_c8, f32_out=True)
+        ops.conv3x3_c8s(buf[cur], pk[self.nb - 1], self.cout_last, relu=False, out=out_c8, f32_out=True)
         return out_c8
 
     def forward_c_entry(self, in_c8=None, out_c8=None):
         """Same pass through the single C entry point scipnp_ffdnet_forward (what a C/C++ host would call)."""
+        if self.in_ch != 13:
+            raise _lib.ScipnpError('scipnp_ffdnet_forward is the colour network (13 -> nc -> 12)')
         in_c8 = self.in_c8 if in_c8 is None else in_c8
         out_c8 = self.out_c8 if out_c8 is None else out_c8
         lib = _lib.load()
@@ -168,8 +172,8 @@ class FFDNetEngine:
 
     def forward_c_entry_split(self, in_c8s=None, out_c8=None):
         """The split-fp16 pass through its single C entry point scipnp_ffdnet_forward_c8s."""
-        if self.precision != 'f16x3':
-            raise _lib.ScipnpError('engine was built with precision f32')
+        if self.precision != 'f16x3' or self.in_ch != 13:
+            raise _lib.ScipnpError('scipnp_ffdnet_forward_c8s needs the colour network and precision f16x3')
         in_c8s = self.in_c8s if in_c8s is None else in_c8s
         out_c8 = self.out_c8 if out_c8 is None else out_c8
         lib = _lib.load()

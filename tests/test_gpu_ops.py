@@ -713,3 +713,19 @@ def test_pm_project_with_more_than_16_frames(ops):
                          dev(np.ascontiguousarray(Phisum.transpose(2, 0, 1))), 0, np.float32(1 / 0.55), np.float32(0.55),
                          out=torch.empty_like(th_d))
     assert np.array_equal(out.cpu().numpy(), ref.numpy().transpose(2, 3, 0, 1))
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_ffdnet_gray_forward_vs_reference_golden(precision, monkeypatch):
+    """the grayscale FFDNet of the reference's model zoo (ffdnet_gray.pth: 5 -> 64 x 13 -> 4 channels, 15 layers) on the
+    HIP kernels; golden = the reference network class on the reference weights (odd image size included)"""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from adaptivepnp_sci_amd.nets import FFDNet
+    gw, g = load_gold('ffdnet_gray_weights'), load_gold('ffdnet_gray_forward')
+    net = FFDNet(in_nc=1, out_nc=1, nc=64, nb=15)
+    net.load_state_dict({k: torch.from_numpy(gw[k]) for k in gw.files})
+    for tag in ('2x64x96', '1x37x50'):
+        for s in (10, 40):
+            out = net(dev(g[f'in_{tag}']), s / 255.)
+            err = rel_l2(out.cpu().numpy(), g[f'out_{tag}_s{s}'])
+            assert err <= 2e-6, (tag, s, err)

@@ -192,3 +192,14 @@ def test_package_synthetic_weights_equal_the_oracle_ones():
         assert list(a) == list(b)
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_ffdnet_gray_forward_golden():
+    gw, g = load_gold('ffdnet_gray_weights'), load_gold('ffdnet_gray_forward')
+    net = ON.OracleFFDNet(1, 1, 64, 15)
+    net.load_state_dict({k: torch.from_numpy(gw[k]) for k in gw.files})
+    net.eval()
+    with torch.no_grad():
+        for tag, n in (('2x64x96', 2), ('1x37x50', 1)):
+            out = net(T(g[f'in_{tag}']), torch.full((n, 1, 1, 1), 40 / 255.))
+            assert rel_l2(out, g[f'out_{tag}_s40']) == 0

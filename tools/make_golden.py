@@ -251,6 +251,32 @@ def g_ffdnet():
     save('ffdnet_forward', **out)
 
 
+def g_ffdgray():
+    """FFDNet-gray (model_zoo/ffdnet_gray.pth: in_nc = out_nc = 1, nc = 64, nb = 15; two_stage_ADMM_Online_FFD_Warm.py:33-40):
+    forward of the reference network class on the reference weights, incl. an odd-sized image."""
+    net = RefFFDNet(in_nc=1, out_nc=1, nc=64, nb=15, act_mode='R')
+    sd = torch.load(os.path.join(ref_shim.REF, 'model_zoo', 'ffdnet_gray.pth'), map_location='cpu')
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    onet = ON.OracleFFDNet(1, 1, 64, 15)
+    onet.load_state_dict(sd)
+    onet.eval()
+    save('ffdnet_gray_weights', **{k: v.numpy() for k, v in sd.items()})
+    out = {}
+    rng = np.random.default_rng(19)
+    for tag, (n, H, W) in {'2x64x96': (2, 64, 96), '1x37x50': (1, 37, 50)}.items():
+        x = torch.from_numpy(rng.uniform(0, 1, (n, 1, H, W)).astype(np.float32))
+        out[f'in_{tag}'] = x
+        for s in (10, 40):
+            sig = torch.full((n, 1, 1, 1), s / 255.)
+            with torch.no_grad():
+                ref = net(x, sig)
+                mine = onet(x, sig)
+            check(f'ffdnet_gray {tag} sigma={s}', mine, ref)
+            out[f'out_{tag}_s{s}'] = ref
+    save('ffdnet_gray_forward', **out)
+
+
 def _tv_warm(y, Phi, its=40):
     o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [its], [0])
     return o['x_bayer']
@@ -493,7 +519,7 @@ def g_logs():
     save('log_text_16x16x4', y=y, Phi=Phi, orig=orig, **out)
 
 
-GROUPS = dict(logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+GROUPS = dict(ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
