@@ -265,17 +265,41 @@ def run_two_stage(scene, warm, denoiser, model_denoise, model_demosaic=None, sch
         rank = dist.get_rank() if dist.is_initialized() else 0
         dev = torch.device('cuda', torch.cuda.current_device())
         local, local_rgb, stats = {}, {}, {}
-        for i in _shard.partition(nmea, world, rank):
-            model_denoise.load_state_dict(pristine, strict=True)
+        mine = _shard.partition(nmea, world, rank)
+
+        def one(i):
+            model = copy.deepcopy(model_denoise)             # every unit starts from the pristine weights
+            model.load_state_dict(pristine, strict=True)
             t0 = time.time()
-            res = solve(i, model_denoise)
-            stats[i] = (res, time.time() - t0)
-            local[i] = torch.from_numpy(res[1]).to(dev)
-            local_rgb[i] = torch.from_numpy(res[0]).to(dev)
+            res = solve(i, model)
+            return i, res, time.time() - t0
+
+        # this rank's measurements on two host threads / HIP streams: the second stream covers the host-side steps
+        # (uploads, engine construction, read-backs, finetune events) of the first
+        import concurrent.futures as cf
+        cur = torch.cuda.current_stream()
+        pool_streams = [torch.cuda.Stream() for _ in range(min(2, max(1, len(mine))))]
+
+        def worker(j):
+            out = []
+            with torch.cuda.stream(pool_streams[j]):
+                for i in mine[j::len(pool_streams)]:
+                    out.append(one(i))
+            return out
+
+        for st_ in pool_streams:
+            st_.wait_stream(cur)
+        with cf.ThreadPoolExecutor(len(pool_streams)) as ex:
+            for part in ex.map(worker, range(len(pool_streams))):
+                for i, res, dt in part:
+                    stats[i] = (res, dt)
+                    local[i] = torch.from_numpy(res[1]).to(dev)
+                    local_rgb[i] = torch.from_numpy(res[0]).to(dev)
+        for st_ in pool_streams:
+            cur.wait_stream(st_)
         # ONE collective for the job: mosaic and colour cube of a unit travel in one (H, W, 4, nmask) slab
         slabs = {i: torch.cat([local_rgb[i], local[i][:, :, None, :]], 2).contiguous() for i in local}
         got = _shard.gather_units(slabs, nmea, (H, W, 4, nmask), dev)
-        model_denoise.load_state_dict(pristine, strict=True)
         if got is not None:
             for i, slab in enumerate(got):
                 rgb[i], v[:, :, i * nmask:(i + 1) * nmask] = slab[:, :, :3].cpu().numpy(), slab[:, :, 3].cpu().numpy()

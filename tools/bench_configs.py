@@ -124,3 +124,21 @@ for nstreams in (1, 2, 1, 2):
     torch.cuda.synchronize()
     print(f'four 256x256x16 tiles, FFDNet 25 its + finetune, {nstreams} stream(s): {(time.perf_counter() - t0) * 1e3:.1f} ms')
 print('identical results:', bool(torch.equal(outs[1], outs[2])))
+
+# configs[3] with several cubes per GPU: four independent 512x512x8 cubes, FFDNet [15,6,4] without finetune, one after
+# the other vs two host threads / HIP streams
+cubes = [synth.make_problem(512, 512, 8, s) for s in range(4)]
+
+
+def solve_cube(args, model):
+    y_c, Phi_c, orig_c = args
+    res = twoStageAdmm_denoise_bayer(y_c, Phi_c, denoiser='ffdnet_color', iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255],
+                                     X_orig=orig_c, model_denoise=model, logf=io.StringIO())
+    return torch.from_numpy(res[1]).cuda()
+
+
+for nstreams in (1, 2, 1, 2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    shard.reconstruct_sharded(cubes, solve_cube, (512, 512, 8), torch.device('cuda'), model=model, streams=nstreams)
+    torch.cuda.synchronize()
+    print(f'four 512x512x8 cubes, FFDNet 25 its, {nstreams} stream(s): {(time.perf_counter() - t0) * 1e3:.1f} ms')
