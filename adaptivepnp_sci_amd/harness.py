@@ -278,7 +278,9 @@ def run_two_stage(scene, warm, denoiser, model_denoise, model_demosaic=None, sch
         # (uploads, engine construction, read-backs, finetune events) of the first
         import concurrent.futures as cf
         cur = torch.cuda.current_stream()
-        pool_streams = [torch.cuda.Stream() for _ in range(min(2, max(1, len(mine))))]
+        # (the FastDVDnet finetune draws noise from the process-global NumPy generator: keep its units in order)
+        n_streams = 1 if (denoiser == 'fastdvd_color' and update) else 2
+        pool_streams = [torch.cuda.Stream() for _ in range(min(n_streams, max(1, len(mine))))]
 
         def worker(j):
             out = []
