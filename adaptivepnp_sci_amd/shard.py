@@ -56,7 +56,9 @@ def reconstruct_sharded(units, solve, unit_shape, device, model=None, dst=0, gro
 
     streams > 1: this rank's units are solved by that many host threads, each on its own HIP stream -- small units
     (256 x 256 tiles) leave CUs idle at the tail of every launch and stall on the host-side steps of a finetune event;
-    a second stream fills those gaps.  Results do not depend on it (units are independent, kernels deterministic)."""
+    a second stream fills those gaps.  Results do not depend on it (units are independent, kernels deterministic) --
+    except when `solve` draws from a process-global RNG, as the FastDVDnet finetune does with NumPy's: pass streams=1
+    there to keep the draws in unit order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = partition(len(units), world, rank)
