@@ -178,3 +178,32 @@ def test_largest_cube_1024x1024x16_untiled(solver, ffdnet_state_dict):
     for k in range(2):
         assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, ('ffdnet', k, rel_l2(tr.it[k], o['theta_iterates'][k]))
     assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+
+
+def test_config1_full_reference_schedule_with_online_finetune(solver, ffdnet_state_dict):
+    """configs[1](ii) exactly as the reference driver runs it on a mid-scale scene (two_stage_ADMM_Online_FFD_Warm.py:71-76):
+    sigma [25,12,6]/255 x [15,6,4] iterations, lr 2e-6, update_per_iter 2, interval_iter 15 -> one finetune event at k = 15,
+    512x512x8, free-running against the CPU oracle: final iterate, every PSNR of the trace, the finetuned weights"""
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=2)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [40], False, [0], logf=io.StringIO())[0]
+    sched = dict(sig=[25 / 255, 12 / 255, 6 / 255], its=[15, 6, 4])
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', sched['its'], False, sched['sig'], x0_bayer=warm,
+                                            X_orig=orig, model_denoise=net, logf=io.StringIO(), lr_=2e-6, interval_iter=15,
+                                            update_=True, update_per_iter=2)
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', sched['its'], sched['sig'], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                          lr=2e-6, inital_iter=1, interval_iter=15, update=True, update_per_iter=2)
+    assert rel_l2(res[1], o['x_bayer']) <= REL_TOL, rel_l2(res[1], o['x_bayer'])
+    assert len(res[4]) == 25 and np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+    sd, osd = net.state_dict(), o['model'].state_dict()
+    k0 = 'model.10.weight'
+    d_got, d_ref = (sd[k0] - ffdnet_state_dict[k0]).numpy(), (osd[k0] - ffdnet_state_dict[k0]).numpy()
+    assert np.abs(d_ref).max() > 0 and rel_l2(d_got, d_ref) < 2e-2
