@@ -207,3 +207,32 @@ def test_config1_full_reference_schedule_with_online_finetune(solver, ffdnet_sta
     k0 = 'model.10.weight'
     d_got, d_ref = (sd[k0] - ffdnet_state_dict[k0]).numpy(), (osd[k0] - ffdnet_state_dict[k0]).numpy()
     assert np.abs(d_ref).max() > 0 and rel_l2(d_got, d_ref) < 2e-2
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_deep_demosaicking_256x256x8(solver, ffdnet_state_dict, precision, monkeypatch):
+    """the reference drivers' default mode (deep_demosaicking=True) at a size with many tiles per layer: DDnet + FFDNet,
+    three iterations, per iterate against the oracle (synthetic DDnet weights)"""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle import nets as ON
+    from oracle import solver as OS
+    y, Phi, orig = synth.make_problem(256, 256, 8, seed=6)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [10], False, [0], logf=io.StringIO())[0]
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2, 1], False, [25 / 255, 12 / 255], x0_bayer=warm,
+                                            X_orig=orig, model_denoise=net, model_demosaic=synth.synth_ddnet(0),
+                                            logf=io.StringIO())
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    with torch.no_grad():
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2, 1], [25 / 255, 12 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                              model_demosaic=ON.synth_ddnet_weights(0))
+    for k in range(3):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], o['theta_iterates'][k]))
+    assert rel_l2(res[0], o['rgb']) <= REL_TOL
