@@ -237,6 +237,8 @@ def main():
         else:
             peak, kname, dtype = PEAK_FP32_MFMA, ('conv3x3_c8_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of '
                                                   '256x256, v_mfma_f32_32x32x2_f32)'), 'f32'
+        peak_meas = measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs' if precision == 'f16x3'
+                                 else 'mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
         line = {
             'metric': 'admm_iters_per_s', 'value': iters_per_s, 'unit': 'ADMM iterations/s',
             'frames_per_s': iters_per_s * B,
@@ -258,12 +260,9 @@ def main():
                          'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
                          # the ceiling MEASURED with a register-resident MFMA loop on random operands (no memory traffic):
                          # what the part sustains under its own clock management, vs the 2.5 PFLOP/s vendor figure
-                         'peak_measured': (measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs') if precision == 'f16x3'
-                                           else measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')),
+                         'peak_measured': peak_meas,
                          'matrix_pipe_frac_of_measured_peak': (
-                             achieved / 1e12 * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) /
-                             measured['mfma_f16_32x32x16_2wave_per_simd_TFLOPs' if precision == 'f16x3'
-                                      else 'mfma_f32_32x32x2_2wave_per_simd_TFLOPs']) if measured else None},
+                             achieved / 1e12 * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) / peak_meas) if peak_meas else None},
             # the Phi / Phi^T Phi projection step (north_star: HBM fraction), one launch per iteration, HIP events
             'phi_step': {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
                          'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
