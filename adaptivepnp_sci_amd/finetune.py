@@ -3,11 +3,13 @@
 ffdnet_online_finetune     <- packages/ffdnet/test_ffdnet_ipol.py:248-300 (branch `updata_=True`)
 fastdvdnet_online_finetune <- packages/fastdvdnet/test_fastdvdnet.py:343-451
 
-FFDNet: fully hand-written -- forward convs keep their activations, the loss gradient, the backward-data
-convolutions (conv3x3_c8 with transposed/flipped weights + ReLU mask), the weight/bias gradients (MFMA
-GEMM over pixels) and torch.optim.Adam's update are HIP kernels (csrc/finetune.hip, csrc/conv.hip).
-A fresh Adam state is created per call, like the reference (`torch.optim.Adam(model.parameters(), lr=lr_)`
-at :251); the module's parameters are updated in place.
+Both are fully hand-written: forward convolutions that keep their activations, the loss gradient, the backward-data
+convolutions (forward kernel with transposed / flipped weights and a ReLU-mask epilogue), the weight / bias gradients
+(MFMA GEMM with the pixels as the K dimension) and torch.optim.Adam's update are HIP kernels.  With the engine in
+precision 'f16x3' (default) everything convolution-shaped runs on the split-fp16 kernels (csrc/conv_split.hip,
+csrc/wgrad_split.hip), gradients travelling pre-scaled by a power of two; with 'f32' on csrc/conv.hip, csrc/finetune.hip.
+A fresh Adam state is created per call, like the reference (`torch.optim.Adam(model.parameters(), lr=lr_)` at :251); the
+module's parameters are updated in place and the engine continues on the device-packed updated weights.
 """
 import ctypes as C
 
@@ -118,10 +120,10 @@ class _FFDNetTrainer:
         _lib.check(lib.scipnp_ffdnet_loss_grad(None, None, None, None, None, M, N, B, C.byref(nb_), None), 'loss size')
         self.loss_part = torch.empty(nb_.value, dtype=torch.float64, device=dev)
         self.step = 0
-        # split-fp16 path (engine precision 'f16x3'): forward stash and backward-data convolutions on the fp16 MFMA with
-        # error-compensated operands; gradients travel pre-scaled by the power of two nearest 2*M*N (the measurement
-        # loss carries 1/(2MN), so the scaled output gradient is O(residual)) and are un-scaled, exactly, on their way
-        # into the fp32 weight / bias gradient kernels
+        # split-fp16 path (engine precision 'f16x3'): forward stash, backward-data convolutions and weight gradients on the
+        # fp16 MFMA with error-compensated operands; gradients travel pre-scaled by the power of two nearest 2*M*N (the
+        # measurement loss carries 1/(2MN), so the scaled output gradient is O(residual)) and are un-scaled, exactly, by
+        # the slab reduction of the weight / bias gradient kernels
         if self.split:
             f16 = torch.float16
             self.fwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(ci, co), dtype=torch.uint8, device=dev)
