@@ -7,8 +7,8 @@
  *     host passes PyTorch-ROCm allocations) and passes its HIP stream; every entry is asynchronous
  *     on that stream and may be captured in a hipGraph;
  *   - every entry returns 0 on success or a negative SCIPNP_E* code; scipnp_last_error() gives the
- *     text (thread-local).
- *   - all arrays are float32.  Two memory layouts appear:
+ *     text (thread-local).  The few HOST functions (weight packing from host arrays, scipnp_host_legacy_normal) say so.
+ *   - all arrays are float32 unless stated (c8s tensors and packed split weights are fp16 pairs).  Memory layouts:
  *       "reference layout": what the reference's Python functions hold --
  *           planes (M,N,B,4): quarter-resolution Bayer planes R,G1,G2,B in the LAST dim, frame next;
  *           mosaic (H,W,B), y (H,W), rgb cube (H,W,3,B) with H = 2M, W = 2N;
@@ -16,7 +16,9 @@
  *           state  [B][4][M][N]   (one contiguous M x N image per frame and Bayer plane),
  *           meas   [4][M][N]      (y and Phi_sum),
  *           rgb    [B][3][H][W]   (planar full-resolution colour frames),
- *           c8     [n][C/8][h][w][8]  (activations of the denoiser: 8-channel groups innermost).
+ *           c8     [n][C/8][h][w][8]  (fp32 activations of the denoiser: 8-channel groups innermost),
+ *           c8s    [n][C/8][2][h][w][8]  fp16: the same tensor as an error-compensated pair of planes, v = hi + lo'/2048
+ *                  (hi = fp16(v), lo' = fp16((v - hi)*2048)), the operand format of the split-fp16 MFMA convolutions.
  *
  * Each entry cites the reference code it replaces (paths relative to the reference repository).
  */
