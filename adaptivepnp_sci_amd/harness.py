@@ -337,6 +337,13 @@ def run_two_stage(scene, warm, denoiser, model_denoise, model_demosaic=None, sch
     return out
 
 
+def worker_init_fn(pid=0):
+    """the reference drivers' seeding (utilspy.py:22-25, called as worker_init_fn(0) at the top of every driver): the
+    FastDVDnet finetune draws its noise from the global NumPy generator seeded here"""
+    np.random.seed(42 + pid)
+    torch.manual_seed(42 + pid)
+
+
 # ------------------------------------------------------------------------------------------------ CLI
 def _load_model(denoiser, weights):
     if denoiser == 'ffdnet_color':
@@ -362,6 +369,7 @@ def main(argv=None):
     ap.add_argument('--no-update', action='store_true', help='disable the online finetune')
     ap.add_argument('--no-reuse-model', action='store_true')
     args = ap.parse_args(argv)
+    worker_init_fn(0)
     scene = load_scene(args.scene)
     os.makedirs(args.results, exist_ok=True)
     with open(os.path.join(args.results, 'log.txt'), 'a') as f:
