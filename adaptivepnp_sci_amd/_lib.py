@@ -39,6 +39,7 @@ SIGNATURES = {
     'scipnp_pm_project': (_int, [_vp] * 6 + [_int, _int, _int, _int, _flt, _flt, _vp]),
     'scipnp_tv_workspace_bytes': (_sz, [_int, _int, _int, _int]),
     'scipnp_tv_chambolle': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _flt, _flt, _int, _vp, _sz, _vp, _vp]),
+    'scipnp_tv_chambolle_ex': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _flt, _flt, _int, _vp, _sz, _vp, _int, _vp]),
     'scipnp_pm_dual_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _flt, _int, _int, _int,
                                      C.POINTER(_int), _vp]),
     'scipnp_pm_pre_denoise': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _flt, _vp]),

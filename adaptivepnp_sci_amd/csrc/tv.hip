@@ -176,6 +176,115 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     }
 }
 
+// ---- whole-plane variant for M, N <= 128: ONE launch for all n_iter_max iterations, one 1024-thread workgroup per
+// channel.  Thread (column, strip) keeps its R = ceil(M/8) rows of image, dual field and `out` in registers; row
+// neighbours inside a strip are register neighbours, column neighbours are wave neighbours (DPP shuffles); only the
+// strip and wave seams go through LDS.  The stop test is evaluated by every thread from the same 16 wave partials in
+// the same order.  Same float32 operations per pixel as tv_iter_kernel, so `out` is bit-identical; the fp64 energy
+// sums associate differently (per wave instead of per 32x32 tile) before they are rounded to float32.
+// Templated on the column count (128, or 64 for narrow planes: 16 strips) and on the register rows per thread.
+constexpr int TVP_THREADS = 1024, TVP_MAX = 128;
+
+template <int TVP_COLS, int TVP_R>
+__global__ void __launch_bounds__(TVP_THREADS)
+tv_plane_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta, int M,
+                int N, int n_iter, double weight, float tau_over_w, double eps, int32_t* __restrict__ stop_iter) {
+    constexpr int TVP_STRIPS = TVP_THREADS / TVP_COLS;
+    __shared__ float s_p0e[TVP_STRIPS + 1][TVP_COLS];   // [s+1]: p0 on the last row of strip s
+    __shared__ float s_oe[TVP_STRIPS + 1][TVP_COLS];    // [s]:   out on the first row of strip s
+    __shared__ float s_p1e[TVP_STRIPS][TVP_R];          // p1 of column 63 (read by column 64)
+    __shared__ float s_oce[TVP_STRIPS][TVP_R];          // out of column 64 (read by column 63)
+    __shared__ double s_red[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = tid & (TVP_COLS - 1), strip = tid / TVP_COLS;
+    const int R = (M + TVP_STRIPS - 1) / TVP_STRIPS;
+    const int r0 = strip * R;
+    const size_t chan = (size_t)blockIdx.x * M * N;
+    const float* xc = x + chan;
+    const float* bc = b ? b + chan : nullptr;
+
+    float v[TVP_R], p0[TVP_R], p1[TVP_R], out[TVP_R];
+    bool ok[TVP_R];
+#pragma unroll
+    for (int k = 0; k < TVP_R; ++k) {
+        const int r = r0 + k;
+        ok[k] = col < N && k < R && r < M;
+        v[k] = ok[k] ? tv_input(xc, bc, coef, (size_t)r * N + col) : 0.f;
+        p0[k] = 0.f;
+        p1[k] = 0.f;
+        out[k] = v[k];
+    }
+
+    double E0 = 0.0, Eprev = 0.0;
+    int stop_at = n_iter - 1;
+    for (int it = 0; it < n_iter; ++it) {
+        double a1 = 0.0, a2 = 0.0;
+        if (it > 0) {           // the seams of p were published before the barrier that closed iteration it-1
+#pragma unroll
+            for (int k = 0; k < TVP_R; ++k) {
+                float left = __shfl_up(p1[k], 1, 64);
+                if (lane == 0) left = s_p1e[strip][k];
+                float up = s_p0e[strip][col];
+                if (k > 0) up = p0[k > 0 ? k - 1 : 0];
+                float d = -(p0[k] + p1[k]);
+                if (r0 + k > 0) d = d + up;
+                if (col > 0) d = d + left;
+                out[k] = v[k] + d;
+                if (ok[k]) a1 += (double)(d * d);
+            }
+            if (it == n_iter - 1) break;      // only `out` of the last iteration is used
+        }
+        s_oe[strip][col] = out[0];
+        if (col == 64) {
+#pragma unroll
+            for (int k = 0; k < TVP_R; ++k) s_oce[strip][k] = out[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TVP_R; ++k) {
+            float right = __shfl_down(out[k], 1, 64);
+            if (lane == 63) right = s_oce[strip][k];
+            float down = s_oe[strip + 1][col];
+            if (k + 1 < TVP_R && k + 1 < R) down = out[k + 1 < TVP_R ? k + 1 : k];
+            const float g0 = (r0 + k < M - 1) ? (down - out[k]) : 0.f;
+            const float g1 = (col < N - 1) ? (right - out[k]) : 0.f;
+            float nrm = sqrtf(g0 * g0 + g1 * g1);
+            if (ok[k]) a2 += (double)nrm;
+            nrm = nrm * tau_over_w;
+            nrm = nrm + 1.f;
+            p0[k] = (p0[k] - 0.25f * g0) / nrm;
+            p1[k] = (p1[k] - 0.25f * g1) / nrm;
+            if (k == R - 1) s_p0e[strip + 1][col] = p0[k];
+            if (col == 63) s_p1e[strip][k] = p1[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a1 += __shfl_down(a1, off, 64);
+            a2 += __shfl_down(a2, off, 64);
+        }
+        if (lane == 0) { s_red[0][wave] = a1; s_red[1][wave] = a2; }
+        __syncthreads();
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s1 += s_red[0][i]; s2 += s_red[1][i]; }
+        double E = (double)(float)s1;
+        E += weight * (double)(float)s2;
+        E /= (double)((size_t)M * N);
+        if (it == 0) {
+            E0 = E;
+            Eprev = E;
+        } else if (fabs(Eprev - E) < eps * E0) {
+            stop_at = it;
+            break;
+        } else {
+            Eprev = E;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TVP_R; ++k)
+        if (ok[k]) theta[chan + (size_t)(r0 + k) * N + col] = out[k];
+    if (stop_iter && tid == 0) stop_iter[blockIdx.x] = stop_at;
+}
+
 __global__ void tv_fill_stop_kernel(int32_t* stop_iter, int C, int last) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C && stop_iter[c] < 0) stop_iter[c] = last;
@@ -195,6 +304,13 @@ size_t scipnp_tv_workspace_bytes(int M, int N, int C, int n_iter_max) {
 int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta, int M, int N, int C,
                         float weight, float eps, int n_iter_max, void* workspace, size_t workspace_bytes,
                         int32_t* stop_iter, scipnp_stream_t s) {
+    return scipnp_tv_chambolle_ex(x, b, coef, theta, M, N, C, weight, eps, n_iter_max, workspace, workspace_bytes, stop_iter,
+                                  0, s);
+}
+
+int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* theta, int M, int N, int C,
+                           float weight, float eps, int n_iter_max, void* workspace, size_t workspace_bytes,
+                           int32_t* stop_iter, int kernel, scipnp_stream_t s) {
     SCIPNP_REQUIRE(x && theta && workspace, "null pointer");
     SCIPNP_REQUIRE(M > 0 && N > 0 && C > 0 && C <= 65535 && n_iter_max > 0, "bad shape M=%d N=%d C=%d n_iter_max=%d", M, N, C, n_iter_max);
     SCIPNP_REQUIRE(weight > 0.f, "weight must be positive");
@@ -221,6 +337,21 @@ int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta
     const double eps_d = as_double(eps);
     const double weight_d = as_double(weight);
     const float tau_over_w = (float)(0.25 / weight_d);
+    const bool fits_plane = M <= TVP_MAX && N <= TVP_MAX;
+    SCIPNP_REQUIRE(kernel >= 0 && kernel <= 2 && (kernel != 2 || fits_plane), "kernel=%d not available for %d x %d planes", kernel, M, N);
+    if (fits_plane && kernel != 1) {
+        // rows per thread: ceil(M / strips), strips = 1024 / columns
+#define SCIPNP_TVP(COLS, R)                                                                                            \
+    hipLaunchKernelGGL((tv_plane_kernel<COLS, R>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, N, n_iter_max, \
+                       weight_d, tau_over_w, eps_d, stop_iter)
+        if (N <= 64) {
+            if (M <= 64) SCIPNP_TVP(64, 4); else SCIPNP_TVP(64, 8);
+        } else {
+            if (M <= 64) SCIPNP_TVP(128, 8); else SCIPNP_TVP(128, 16);
+        }
+#undef SCIPNP_TVP
+        return launch_status("tv_plane_kernel");
+    }
     for (int it = 0; it < n_iter_max; ++it) {
         if (it == 0)
             hipLaunchKernelGGL(tv_iter_kernel<true>, grid, block, 0, st, x, b, coef, theta, ws, it, M, N, C, weight_d,

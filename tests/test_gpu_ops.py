@@ -99,14 +99,15 @@ def test_layout_conversions_bit_exact(ops):
     assert torch.equal(ops.rgb_to_cube(rgb).cpu(), cube.cpu())
 
 
-def test_tv_chambolle_matches_skimage_golden(ops):
+@pytest.mark.parametrize('kernel', [1, 2], ids=['tiled', 'whole-plane'])
+def test_tv_chambolle_matches_skimage_golden(ops, kernel):
     g = load_gold('tv_chambolle')
     v = dev(g['v']).permute(2, 0, 1).contiguous()     # (C, M, N)
     C_, M, N = v.shape
     for key, w, n in (('w01_n5', 0.1, 5), ('w01_n50', 0.1, 50), ('w003_n5', 0.03, 5)):
         plan = ops.TvPlan(M, N, C_, n, v.device)
         out = torch.empty_like(v)
-        ops.tv_chambolle(v, None, 0.0, out, plan, w)
+        ops.tv_chambolle(v, None, 0.0, out, plan, w, kernel=kernel)
         ref = torch.from_numpy(g['out_' + key]).permute(2, 0, 1)
         stop = plan.stop_iter.cpu().numpy()
         assert (stop == g['stop_' + key]).all(), (key, stop, g['stop_' + key])   # incl. early-stopping channels
@@ -114,7 +115,8 @@ def test_tv_chambolle_matches_skimage_golden(ops):
         assert rel_l2(out.cpu().numpy(), ref.numpy()) == 0.0, key
 
 
-def test_tv_fused_input_and_ragged_size(ops):
+@pytest.mark.parametrize('kernel', [1, 2], ids=['tiled', 'whole-plane'])
+def test_tv_fused_input_and_ragged_size(ops, kernel):
     from oracle.tv_chambolle import tv_chambolle_multichannel
     rng = np.random.default_rng(4)
     x = rng.uniform(0, 2, (37, 45, 6)).astype(np.float32)
@@ -124,9 +126,36 @@ def test_tv_fused_input_and_ragged_size(ops):
     xs, bs = dev(x).permute(2, 0, 1).contiguous(), dev(b).permute(2, 0, 1).contiguous()
     plan = ops.TvPlan(37, 45, 6, 5, xs.device)
     out = torch.empty_like(xs)
-    ops.tv_chambolle(xs, bs, float(coef), out, plan, 0.1)
+    ops.tv_chambolle(xs, bs, float(coef), out, plan, 0.1, kernel=kernel)
     assert rel_l2(out.permute(1, 2, 0).cpu().numpy(), ref) == 0.0
     assert (plan.stop_iter.cpu().numpy() == stops).all()
+
+
+@pytest.mark.parametrize('shape', [(128, 128, 8), (127, 128, 3), (128, 65, 3), (64, 63, 4), (9, 130, 2), (1, 1, 2), (3, 200, 2),
+                                   (7, 5, 3), (100, 64, 5), (64, 100, 2), (65, 64, 2), (33, 17, 2)])
+@pytest.mark.parametrize('n_iter', [1, 2, 5, 40])
+def test_tv_whole_plane_kernel_equals_the_tiled_kernel(ops, shape, n_iter):
+    """planes up to 128 x 128 run all iterations in one launch (csrc/tv.hip tv_plane_kernel): same float32 operations per
+    pixel, so `out` and the stop iterations must be identical to the per-iteration tiled kernel at every size, seam and
+    iteration count; wider planes are refused by kernel=2 and fall to the tiled kernel under kernel=0"""
+    M, N, C_ = shape
+    rng = np.random.default_rng(M * 1000 + N)
+    x = dev(rng.uniform(0, 1, (C_, M, N)).astype(np.float32))
+    x[0] = x[0] * 0.02 + 0.5                          # a nearly flat channel: stops early
+    b = dev(rng.normal(0, 0.1, (C_, M, N)).astype(np.float32))
+    plan1, plan2 = ops.TvPlan(M, N, C_, n_iter, x.device), ops.TvPlan(M, N, C_, n_iter, x.device)
+    o1, o2 = torch.empty_like(x), torch.full_like(x, -7.0)
+    ops.tv_chambolle(x, b, -1.0, o1, plan1, 0.1, kernel=1)
+    if N > 128 or M > 128:
+        with pytest.raises(ValueError):              # SCIPNP_EINVAL
+            ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=2)
+        ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=0)
+    else:
+        ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=2)
+    assert torch.equal(o1, o2)
+    assert torch.equal(plan1.stop_iter, plan2.stop_iter)
+    if n_iter == 40 and M * N > 1:
+        assert int(plan1.stop_iter.min()) < 39          # the early stop was exercised
 
 
 @pytest.mark.parametrize('tag', ['16x16', '64x64', '8x24'])
