@@ -142,6 +142,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
+        local_rank %= max(1, torch.cuda.device_count())     # (a launcher may already have masked the devices per rank)
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
