@@ -87,6 +87,49 @@ __device__ __forceinline__ float torch_contig_sum(int nB, F term) {
     return f;
 }
 
+// The same two orders with the frame count known only at run time (any nB < 64), `term(i)` a memory load; T is float or
+// float4 (four independent sums).  The lane sums follow ATen's row_sum for ANY number of 8-float vectors: four
+// accumulators over the full groups of four vectors, the remaining vectors appended to accumulator 0, then
+// ((c0+c1)+c2)+c3 -- for up to four vectors that is the sequential sum of (2) above.  At nB >= 64 the strided order
+// enters the next level of ATen's cascade (level step 16 groups of four), which is not restated here.
+constexpr int TORCH_SUM_RT_MAX = 63;
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4_add(float a, float b) { return a + b; }
+
+template <typename T, typename F>
+__device__ __forceinline__ T torch_strided_sum_rt(int nB, T zero, F term) {
+    T a0 = zero, a1 = zero, a2 = zero, a3 = zero;
+    const int n4 = nB & ~3;
+    for (int i = 0; i < n4; i += 4) {
+        a0 = f4_add(a0, term(i));
+        a1 = f4_add(a1, term(i + 1));
+        a2 = f4_add(a2, term(i + 2));
+        a3 = f4_add(a3, term(i + 3));
+    }
+    for (int i = n4; i < nB; ++i) a0 = f4_add(a0, term(i));
+    return f4_add(f4_add(f4_add(a0, a1), a2), a3);
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ T torch_contig_sum_rt(int nB, T zero, F term) {
+    if (nB < 8) return torch_strided_sum_rt(nB, zero, term);
+    const int nv = nB >> 3, nq = nv >> 2;
+    T f = zero;
+    for (int i = 8 * nv; i < nB; ++i) f = f4_add(f, term(i));
+    for (int k = 0; k < 8; ++k) {
+        T c0 = zero, c1 = zero, c2 = zero, c3 = zero;
+        for (int i = 0; i < nq; ++i) {
+            c0 = f4_add(c0, term(8 * (4 * i) + k));
+            c1 = f4_add(c1, term(8 * (4 * i + 1) + k));
+            c2 = f4_add(c2, term(8 * (4 * i + 2) + k));
+            c3 = f4_add(c3, term(8 * (4 * i + 3) + k));
+        }
+        for (int j = 4 * nq; j < nv; ++j) c0 = f4_add(c0, term(8 * j + k));
+        f = f4_add(f, f4_add(f4_add(f4_add(c0, c1), c2), c3));
+    }
+    return f;
+}
+
 // block-wide sum of one double per thread (block size a multiple of 64, <= 1024; `tid` is the
 // linear thread id); result valid in thread 0.  Fixed tree + fixed wave order: deterministic.
 __device__ __forceinline__ double block_sum_double(double v, double* lds /* >= 16 doubles */, int tid, int nthreads) {

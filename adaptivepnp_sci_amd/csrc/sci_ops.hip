@@ -88,16 +88,83 @@ ref_layout_kernel(const float4* __restrict__ theta, const float4* __restrict__ b
     if (live) xout[idx] = r;
 }
 
+// Any other frame count (B < 64): one thread per quad walks its B float4 entries (contiguous in this layout) with the
+// run-time forms of the two torch summation orders; the projections read theta, b, Phi a second time for the output
+// (cache-served).  Same expressions, operation by operation, as ref_layout_kernel.
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+template <int MODE>
+__device__ __forceinline__ float4 ref_p(const float4* theta, const float4* bb, long long i, float c0) {
+    const float4 th = theta[i];
+    if (MODE == 2) return th;
+    const float4 bv = bb[i];
+    if (MODE == 0) return make_float4(th.x - c0 * bv.x, th.y - c0 * bv.y, th.z - c0 * bv.z, th.w - c0 * bv.w);
+    return make_float4(th.x + bv.x, th.y + bv.y, th.z + bv.z, th.w + bv.w);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+ref_layout_anyB_kernel(const float4* __restrict__ theta, const float4* __restrict__ bb,
+                       const float4* __restrict__ Phi, const float4* __restrict__ y,
+                       const float4* __restrict__ Phisum, float4* xout, float4* yout,
+                       long long nquad, int B, float c0, float c1) {
+    const long long quad = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (quad >= nquad) return;
+    const long long base = quad * B;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 4) {
+        float4 s = torch_strided_sum_rt(B, zero, [&](int i) { return Phi[base + i]; });
+        s.x = (s.x == 0.f) ? 1.f : s.x;
+        s.y = (s.y == 0.f) ? 1.f : s.y;
+        s.z = (s.z == 0.f) ? 1.f : s.z;
+        s.w = (s.w == 0.f) ? 1.f : s.w;
+        yout[quad] = s;
+        return;
+    }
+    if (MODE == 3) {
+        const float4 yy = y[quad];
+        for (int t = 0; t < B; ++t) xout[base + t] = f4_mul(yy, Phi[base + t]);
+        return;
+    }
+    const float4 yb = torch_contig_sum_rt(B, zero, [&](int i) { return f4_mul(ref_p<MODE>(theta, bb, base + i, c0), Phi[base + i]); });
+    if (MODE == 2) {
+        yout[quad] = yb;
+        return;
+    }
+    const float4 yy = y[quad];
+    const float4 ps = Phisum[quad];
+    float4 r;
+    if (MODE == 0)
+        r = make_float4((yy.x - yb.x) / (c1 + ps.x), (yy.y - yb.y) / (c1 + ps.y), (yy.z - yb.z) / (c1 + ps.z),
+                        (yy.w - yb.w) / (c1 + ps.w));
+    else
+        r = make_float4((yy.x - yb.x) / (ps.x + c1), (yy.y - yb.y) / (ps.y + c1), (yy.z - yb.z) / (ps.z + c1),
+                        (yy.w - yb.w) / (ps.w + c1));
+    for (int t = 0; t < B; ++t) {
+        const float4 p = ref_p<MODE>(theta, bb, base + t, c0);
+        const float4 ph = Phi[base + t];
+        if (MODE == 0)
+            xout[base + t] = make_float4(p.x + ph.x * r.x, p.y + ph.y * r.y, p.z + ph.z * r.z, p.w + ph.w * r.w);
+        else
+            xout[base + t] = make_float4(p.x + c0 * (r.x * ph.x), p.y + c0 * (r.y * ph.y), p.z + c0 * (r.z * ph.z),
+                                         p.w + c0 * (r.w * ph.w));
+    }
+}
+
 template <int MODE>
 static int launch_ref_layout(const float* theta, const float* b, const float* Phi, const float* y,
                              const float* Phisum, float* xout, float* yout, int M, int N, int B,
                              float c0, float c1, hipStream_t st) {
     SCIPNP_REQUIRE(M > 0 && N > 0, "M,N must be positive (got %d,%d)", M, N);
-    SCIPNP_REQUIRE(B == 1 || B == 2 || B == 4 || B == 8 || B == 16,
-                   "reference-layout kernels need B in {1,2,4,8,16} (got %d); use the plane-major entry", B);
+    SCIPNP_REQUIRE(B >= 1 && B <= TORCH_SUM_RT_MAX, "B = %d frames: 1 <= B <= %d", B, TORCH_SUM_RT_MAX);
     const long long nquad = (long long)M * N;
     const long long total = nquad * B;
     const int threads = 256;
+    if (!(B == 1 || B == 2 || B == 4 || B == 8 || B == 16)) {      // the shuffle kernel needs a power of two <= 16
+        hipLaunchKernelGGL((ref_layout_anyB_kernel<MODE>), dim3((unsigned)((nquad + threads - 1) / threads)), dim3(threads), 0,
+                           st, (const float4*)theta, (const float4*)b, (const float4*)Phi, (const float4*)y,
+                           (const float4*)Phisum, (float4*)xout, (float4*)yout, nquad, B, c0, c1);
+        return launch_status("ref_layout_anyB_kernel");
+    }
     const unsigned blocks = (unsigned)((total + threads - 1) / threads);
 #define SCIPNP_GO(LB)                                                                              \
     hipLaunchKernelGGL((ref_layout_kernel<LB, MODE>), dim3(blocks), dim3(threads), 0, st,           \
@@ -306,15 +373,91 @@ pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
     }
 }
 
+// 33..63 frames: the per-thread register arrays no longer fit; two passes over the frames (sum, then output), the second
+// served from cache.  T = float4 (four consecutive pixels) or float.
+template <typename T> __device__ __forceinline__ T pm_ld(const float* p, size_t o) { return *(const T*)(p + o); }
+__device__ __forceinline__ float f4_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float4 f4_sub_scaled(float4 a, float c, float4 b) {
+    return make_float4(a.x - c * b.x, a.y - c * b.y, a.z - c * b.z, a.w - c * b.w);
+}
+__device__ __forceinline__ float f4_sub_scaled(float a, float c, float b) { return a - c * b; }
+template <typename T> __device__ __forceinline__ T f4_zero();
+template <> __device__ __forceinline__ float f4_zero<float>() { return 0.f; }
+template <> __device__ __forceinline__ float4 f4_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+pm_project_anyB_kernel(const float* __restrict__ theta, const float* __restrict__ bb, const float* __restrict__ Phi,
+                       const float* __restrict__ y, const float* Phisum_in, float* Phisum_out, float* xout, long long Q,
+                       int B, float c0, float c1) {
+    constexpr int VEC = sizeof(T) / sizeof(float);
+    const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (q >= Q) return;
+    auto p_at = [&](int t) -> T {
+        const size_t o = (size_t)t * Q + q;
+        if (MODE == 0) return f4_sub_scaled(pm_ld<T>(theta, o), c0, pm_ld<T>(bb, o));
+        return f4_add(pm_ld<T>(theta, o), pm_ld<T>(bb, o));
+    };
+    T r;
+    float* rp = (float*)&r;
+    const T yv = pm_ld<T>(y, q);
+    const float* yp = (const float*)&yv;
+    if (MODE == 2) {
+        T s = torch_strided_sum_rt(B, f4_zero<T>(), [&](int i) { return pm_ld<T>(Phi, (size_t)i * Q + q); });
+        float* sp = (float*)&s;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) sp[v] = (sp[v] == 0.f) ? 1.f : sp[v];
+        *(T*)(Phisum_out + q) = s;
+        if (xout == nullptr) return;
+        r = yv;
+    } else {
+        const T yb = torch_contig_sum_rt(B, f4_zero<T>(), [&](int i) { return f4_mul(p_at(i), pm_ld<T>(Phi, (size_t)i * Q + q)); });
+        const float* ybp = (const float*)&yb;
+        const T sv = pm_ld<T>(Phisum_in, q);
+        const float* sp = (const float*)&sv;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            rp[v] = (MODE == 0) ? (yp[v] - ybp[v]) / (c1 + sp[v]) : (yp[v] - ybp[v]) / (sp[v] + c1);
+    }
+    for (int t = 0; t < B; ++t) {
+        const size_t o = (size_t)t * Q + q;
+        const T ph = pm_ld<T>(Phi, o);
+        const float* php = (const float*)&ph;
+        T ov;
+        float* op = (float*)&ov;
+        if (MODE == 2) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) op[v] = rp[v] * php[v];
+        } else {
+            const T p = p_at(t);
+            const float* pp = (const float*)&p;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                op[v] = (MODE == 0) ? (pp[v] + php[v] * rp[v]) : (pp[v] + c0 * (rp[v] * php[v]));
+        }
+        *(T*)(xout + o) = ov;
+    }
+}
+
 template <int MODE>
 static int launch_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
                              const float* Phisum_in, float* Phisum_out, float* x, int M, int N, int B,
                              float c0, float c1, hipStream_t st) {
-    SCIPNP_REQUIRE(M > 0 && N > 0 && B > 0 && B <= 32, "bad shape M=%d N=%d B=%d (B <= 32)", M, N, B);
+    SCIPNP_REQUIRE(M > 0 && N > 0 && B > 0 && B <= TORCH_SUM_RT_MAX, "bad shape M=%d N=%d B=%d (B <= %d)", M, N, B,
+                   TORCH_SUM_RT_MAX);
     const long long Q = 4LL * M * N;
-    const bool vec = (Q % 4 == 0) && aligned16(Phi) && aligned16(y) && aligned16(x) &&
+    const bool vec = (Q % 4 == 0) && aligned16(Phi) && aligned16(y) && (x == nullptr || aligned16(x)) &&
                      (MODE == 2 ? aligned16(Phisum_out) : (aligned16(theta) && aligned16(b) && aligned16(Phisum_in)));
     const int threads = 256;
+    if (B > 32) {
+        if (vec)
+            hipLaunchKernelGGL((pm_project_anyB_kernel<float4, MODE>), dim3((unsigned)((Q / 4 + threads - 1) / threads)),
+                               dim3(threads), 0, st, theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1);
+        else
+            hipLaunchKernelGGL((pm_project_anyB_kernel<float, MODE>), dim3((unsigned)((Q + threads - 1) / threads)),
+                               dim3(threads), 0, st, theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1);
+        return launch_status("pm_project_anyB_kernel");
+    }
 #define SCIPNP_GO(VEC, MAXB)                                                                        \
     hipLaunchKernelGGL((pm_project_kernel<VEC, MAXB, MODE>),                                         \
                        dim3((unsigned)((Q / VEC + threads - 1) / threads)), dim3(threads), 0, st,    \

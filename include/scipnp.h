@@ -61,7 +61,9 @@ int scipnp_bayer_merge(const float* planes, float* mosaic, int M, int N, int B, 
 /* two-stage ADMM Euclidean projection               -- dvp...:128-140
  *   p = theta - inv_rho*b ;  x = p + Phi*((y - sum_t p*Phi)/(alpha_rho + Phisum))
  * x may alias theta (the reference's first iteration does).  One quad (2x2 pixels x B frames) is one
- * 128-byte line for B = 8; the frame reduction is a wavefront shuffle.  B must be 1,2,4,8 or 16. */
+ * 128-byte line for B = 8; the frame reduction is a wavefront shuffle for B = 1,2,4,8,16 and a per-quad loop for
+ * any other B.  1 <= B <= 63 everywhere (A, At, phisum, both projections, the plane-major engine): the sums over
+ * frames reproduce PyTorch's CPU summation orders, which are restated up to 63 addends (csrc/common.hpp). */
 int scipnp_proj_twostage(const float* theta, const float* b, const float* Phi, const float* y,
                          const float* Phisum, float* x, int M, int N, int B,
                          float inv_rho, float alpha_rho, scipnp_stream_t s);
@@ -87,7 +89,8 @@ int scipnp_cube_to_rgb(const float* cube, float* rgb, int H, int W, int B, scipn
 int scipnp_pm_setup(const float* Phi, const float* y, float* Phisum, float* x0,
                     int M, int N, int B, scipnp_stream_t s);
 /* projection on plane-major state; mode 0 = two-stage (c0 = inv_rho, c1 = alpha_rho),
- * mode 1 = one-stage (c0 = lambda, c1 = gamma).  x may alias theta.        -- dvp...:128-140 / :389-391 */
+ * mode 1 = one-stage (c0 = lambda, c1 = gamma).  x may alias theta.        -- dvp...:128-140 / :389-391
+ * Up to 32 frames every tensor is read exactly once (frames held in registers); 33..63 frames take two passes. */
 int scipnp_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
                       const float* Phisum, float* x, int M, int N, int B, int mode,
                       float c0, float c1, scipnp_stream_t s);

@@ -49,11 +49,57 @@ def test_reference_layout_ops_bit_exact(ops, tag):
     assert torch.equal(th2.cpu(), torch.from_numpy(g['x_two_stage']))
 
 
-def test_reference_layout_rejects_odd_B(ops):
-    g = load_gold('ops_12x20x5')
-    Phi = dev(g['Phi'])
+def test_frame_count_limit(ops):
+    """the restated torch summation orders hold below 64 frames (ATen's cascade takes another level there): more is refused"""
+    Phi = torch.zeros(4, 4, 64, 4, device='cuda')
     with pytest.raises(ValueError):
         ops.phisum(Phi)
+    with pytest.raises(ValueError):
+        ops.pm_setup(torch.zeros(64, 4, 4, 4, device='cuda'), torch.zeros(4, 4, 4, device='cuda'))
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 23, 24, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63])
+def test_any_frame_count_bit_exact_against_torch_orders(ops, B):
+    """Phi_sum (strided torch.sum), A_ (contiguous torch.sum of the fresh product), At_ and both projections, in the
+    reference's (M,N,B,4) layout and in the plane-major engine, for every class of frame count: below one 8-float vector,
+    whole vectors, vectors + tail, more than four vectors (ATen row_sum's four accumulators), with real-valued masks so
+    that the summation order matters.  Oracle = the reference's own torch expressions on the CPU (oracle/sci_ops.py)."""
+    from oracle import sci_ops as OO
+    rng = np.random.default_rng(100 + B)
+    M, N = 6, 10
+    T = torch.from_numpy
+    theta = rng.random((M, N, B, 4), np.float32)
+    b = (0.2 * rng.standard_normal((M, N, B, 4))).astype(np.float32)
+    Phi = (rng.random((M, N, B, 4)) * (rng.random((M, N, B, 4)) < 0.7)).astype(np.float32)
+    Phi[0, 0] = 0                                        # an unsampled quad: Phi_sum -> 1
+    y = (rng.random((M, N, 4)) * B / 2).astype(np.float32)
+    Ps = torch.zeros(M, N, 4)
+    for ib in range(4):
+        Ps[..., ib] = torch.sum(T(Phi)[..., ib], dim=2)     # dvp...:72
+    Ps[Ps == 0] = 1
+    A_ref = torch.stack([OO.forward_A(T(theta)[..., ib], T(Phi)[..., ib]) for ib in range(4)], -1)
+    At_ref = torch.stack([OO.transpose_At(T(y)[..., ib], T(Phi)[..., ib]) for ib in range(4)], -1)
+    two = OO.project_two_stage(T(theta), T(b), T(Phi), T(y), Ps, 0.55, 1.0)
+    one = OO.project_one_stage(T(theta), T(b), T(Phi), T(y), Ps, 1.0, 0.01)
+    # reference layout
+    th_d, b_d, Phi_d, y_d = dev(theta), dev(b), dev(Phi), dev(y)
+    Ps_d = ops.phisum(Phi_d)
+    assert torch.equal(Ps_d.cpu(), Ps)
+    assert torch.equal(ops.A_(th_d, Phi_d).cpu(), A_ref)
+    assert torch.equal(ops.At_(y_d, Phi_d).cpu(), At_ref)
+    assert torch.equal(ops.proj_twostage(th_d, b_d, Phi_d, y_d, Ps_d, np.float32(1 / 0.55), np.float32(0.55)).cpu(), two)
+    assert torch.equal(ops.proj_onestage(th_d, b_d, Phi_d, y_d, Ps_d, 1.0, 0.01).cpu(), one)
+    # plane-major engine
+    th_s, b_s, Phi_s = (planes_to_state(t) for t in (th_d, b_d, Phi_d))
+    y_s = y_d.permute(2, 0, 1).contiguous()
+    Ps_s, x0 = ops.pm_setup(Phi_s, y_s)
+    assert torch.equal(Ps_s.cpu(), Ps.permute(2, 0, 1))
+    assert torch.equal(state_to_planes(x0).cpu(), At_ref)
+    out = torch.empty_like(th_s)
+    ops.pm_project(th_s, b_s, Phi_s, y_s, Ps_s, 0, np.float32(1 / 0.55), np.float32(0.55), out)
+    assert torch.equal(state_to_planes(out).cpu(), two)
+    ops.pm_project(th_s, b_s, Phi_s, y_s, Ps_s, 1, 1.0, 0.01, out)
+    assert torch.equal(state_to_planes(out).cpu(), one)
 
 
 @pytest.mark.parametrize('tag', ['8x8x8', '32x32x8', '12x20x5'])
@@ -81,7 +127,7 @@ def test_layout_conversions_bit_exact(ops):
     g = load_gold('bayer_12x20x5')
     mos = dev(g['mosaic'])
     rng = np.random.default_rng(0)
-    # reference layout split/merge need B in {1,2,4,8,16}: use an 8-frame cube
+    # reference layout split/merge on an 8-frame cube
     mos8 = dev(rng.uniform(size=(12, 20, 8)).astype(np.float32))
     from oracle import sci_ops as OO
     pl = ops.bayer_split(mos8)

@@ -308,7 +308,8 @@ def test_deep_demosaicking_iterates(solver, ffdnet_state_dict, precision, monkey
     assert rel_l2(res[0], g['rgb_fastdvd']) <= REL_TOL
 
 
-@pytest.mark.parametrize('shape', [(40, 52, 5), (24, 72, 11), (68, 36, 16), (8, 12, 1), (12, 8, 2), (20, 28, 3), (16, 16, 32)])
+@pytest.mark.parametrize('shape', [(40, 52, 5), (24, 72, 11), (68, 36, 16), (8, 12, 1), (12, 8, 2), (20, 28, 3), (16, 16, 32),
+                                   (16, 20, 40), (12, 12, 63)])
 def test_ragged_cubes_match_the_oracle(solver, ffdnet_state_dict, shape):
     """frame sizes that are not multiples of the kernels' 8x32 / 16-pixel tiles and frame counts other than 8 (the
     torch summation-order emulation of A_ / Phi_sum depends on B): TV one-stage, TV two-stage and FFDNet two-stage
