@@ -130,6 +130,11 @@ __device__ __forceinline__ T torch_contig_sum_rt(int nB, T zero, F term) {
     return f;
 }
 
+// tv.hip: Chambolle TV + ADMM dual update of planes up to 128 x 128 in one launch (used by iterate.hip)
+bool tv_plane_dual_fits(int M, int N, int C, int nfill, bool want_sse);
+int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int N, int C, float weight, float eps,
+                  int n_iter_max, const float* orig, double* sse_part, int which, float sign, int nfill, hipStream_t st);
+
 // block-wide sum of one double per thread (block size a multiple of 64, <= 1024; `tid` is the
 // linear thread id); result valid in thread 0.  Fixed tree + fixed wave order: deterministic.
 __device__ __forceinline__ double block_sum_double(double v, double* lds /* >= 16 doubles */, int tid, int nthreads) {

@@ -185,10 +185,21 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
 // Templated on the column count (128, or 64 for narrow planes: 16 strips) and on the register rows per thread.
 constexpr int TVP_THREADS = 1024, TVP_MAX = 128;
 
-template <int TVP_COLS, int TVP_R>
+// DUAL: the ADMM dual update rides in the epilogue (sci_ops.hip pm_dual_update_kernel, same expressions): theta =
+// clip(out, 0, 1), b +-= x - theta, and the channel's sum of (orig - report)^2 goes to sse_part[channel]; entries
+// [C, nfill) are zeroed so that a caller summing the nfill partials of the stand-alone kernel's grid gets the same total.
+struct TvDual {
+    float* b;               // the same memory as the kernel's (read-only) `b` input, written in the epilogue
+    const float* orig;
+    double* sse_part;
+    int which, nfill;
+    float sign;
+};
+
+template <int TVP_COLS, int TVP_R, bool DUAL>
 __global__ void __launch_bounds__(TVP_THREADS)
-tv_plane_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta, int M,
-                int N, int n_iter, double weight, float tau_over_w, double eps, int32_t* __restrict__ stop_iter) {
+tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
+                int N, int n_iter, double weight, float tau_over_w, double eps, int32_t* __restrict__ stop_iter, TvDual dual) {
     constexpr int TVP_STRIPS = TVP_THREADS / TVP_COLS;
     __shared__ float s_p0e[TVP_STRIPS + 1][TVP_COLS];   // [s+1]: p0 on the last row of strip s
     __shared__ float s_oe[TVP_STRIPS + 1][TVP_COLS];    // [s]:   out on the first row of strip s
@@ -279,10 +290,94 @@ tv_plane_kernel(const float* __restrict__ x, const float* __restrict__ b, float 
             Eprev = E;
         }
     }
-#pragma unroll
-    for (int k = 0; k < TVP_R; ++k)
-        if (ok[k]) theta[chan + (size_t)(r0 + k) * N + col] = out[k];
     if (stop_iter && tid == 0) stop_iter[blockIdx.x] = stop_at;
+    if (!DUAL) {
+#pragma unroll
+        for (int k = 0; k < TVP_R; ++k)
+            if (ok[k]) theta[chan + (size_t)(r0 + k) * N + col] = out[k];
+        return;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < TVP_R; ++k) {
+        if (ok[k]) {
+            const size_t o = chan + (size_t)(r0 + k) * N + col;
+            const float xv = x[o];
+            const float th = fminf(fmaxf(out[k], 0.f), 1.f);
+            const float d = xv - th;
+            const float bo = dual.b[o];
+            dual.b[o] = (dual.sign > 0.f) ? (bo + d) : (bo - d);
+            theta[o] = th;
+            if (dual.sse_part) {
+                const float e = dual.orig[o] - (dual.which == 0 ? th : xv);
+                acc += (double)(e * e);
+            }
+        }
+    }
+    if (dual.sse_part) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        __syncthreads();                      // (the stop test's readers of s_red are done)
+        if (lane == 0) s_red[0][wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += s_red[0][i];
+            dual.sse_part[blockIdx.x] = t;
+        }
+        if (blockIdx.x == 0)
+            for (int i = (int)gridDim.x + tid; i < dual.nfill; i += TVP_THREADS) dual.sse_part[i] = 0.0;
+    }
+}
+
+// the shortest decimal that round-trips a float32: weight and eps are Python floats (doubles) in the reference and
+// promote its float32 sums to double; they reach this ABI as float32 (0.1f -> 0.1, 2e-4f -> 2e-4)
+static double as_double(float f) {
+    for (int prec = 1; prec <= 9; ++prec) {
+        char buf[40];
+        double d = 0.0;
+        snprintf(buf, sizeof buf, "%.*g", prec, (double)f);
+        sscanf(buf, "%lf", &d);
+        if ((float)d == f) return d;
+    }
+    return (double)f;
+}
+
+static int tv_plane_launch(const float* x, const float* b, float coef, float* theta, int M, int N, int C, double weight_d,
+                           float tau_over_w, double eps_d, int n_iter_max, int32_t* stop_iter, const TvDual* dual,
+                           hipStream_t st) {
+    // rows per thread: ceil(M / strips), strips = 1024 / columns
+    const TvDual d = dual ? *dual : TvDual{};
+#define SCIPNP_TVP(COLS, R)                                                                                             \
+    do {                                                                                                                \
+        if (dual)                                                                                                       \
+            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, true>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
+                               N, n_iter_max, weight_d, tau_over_w, eps_d, stop_iter, d);                                \
+        else                                                                                                            \
+            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, false>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
+                               N, n_iter_max, weight_d, tau_over_w, eps_d, stop_iter, d);                                \
+    } while (0)
+    if (N <= 64) {
+        if (M <= 64) SCIPNP_TVP(64, 4); else SCIPNP_TVP(64, 8);
+    } else {
+        if (M <= 64) SCIPNP_TVP(128, 8); else SCIPNP_TVP(128, 16);
+    }
+#undef SCIPNP_TVP
+    return launch_status("tv_plane_kernel");
+}
+
+// TV step + dual update of one ADMM-TV iteration in ONE launch (iterate.hip); false if the planes do not fit the
+// whole-plane kernel or the caller's sse_part (sized for pm_dual_update's grid, `nfill` entries) has fewer than C entries
+bool tv_plane_dual_fits(int M, int N, int C, int nfill, bool want_sse) {
+    return M <= TVP_MAX && N <= TVP_MAX && (!want_sse || C <= nfill);
+}
+
+int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int N, int C, float weight, float eps,
+                  int n_iter_max, const float* orig, double* sse_part, int which, float sign, int nfill, hipStream_t st) {
+    const double weight_d = as_double(weight);
+    TvDual d;
+    d.b = b; d.orig = orig; d.sse_part = sse_part; d.which = which; d.nfill = nfill; d.sign = sign;
+    return tv_plane_launch(x, b, coef, theta, M, N, C, weight_d, (float)(0.25 / weight_d), as_double(eps), n_iter_max,
+                           nullptr, &d, st);
 }
 
 __global__ void tv_fill_stop_kernel(int32_t* stop_iter, int C, int last) {
@@ -321,19 +416,6 @@ int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* th
     hipStream_t st = (hipStream_t)s;
     const dim3 block(TV_TS, TV_TY);
     const dim3 grid((N + TV_TS - 1) / TV_TS, (M + TV_TS - 1) / TV_TS, C);
-    // weight and eps are Python floats (doubles) in the reference and promote its float32 sums to
-    // double; they reach this ABI as float32, so recover the double through the shortest decimal
-    // that round-trips (0.1f -> 0.1, 2e-4f -> 2e-4).
-    auto as_double = [](float f) {
-        for (int prec = 1; prec <= 9; ++prec) {
-            char buf[40];
-            double d = 0.0;
-            snprintf(buf, sizeof buf, "%.*g", prec, (double)f);
-            sscanf(buf, "%lf", &d);
-            if ((float)d == f) return d;
-        }
-        return (double)f;
-    };
     const double eps_d = as_double(eps);
     const double weight_d = as_double(weight);
     const float tau_over_w = (float)(0.25 / weight_d);
@@ -341,16 +423,7 @@ int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* th
     SCIPNP_REQUIRE(kernel >= 0 && kernel <= 2 && (kernel != 2 || fits_plane), "kernel=%d not available for %d x %d planes", kernel, M, N);
     if (fits_plane && kernel != 1) {
         // rows per thread: ceil(M / strips), strips = 1024 / columns
-#define SCIPNP_TVP(COLS, R)                                                                                            \
-    hipLaunchKernelGGL((tv_plane_kernel<COLS, R>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, N, n_iter_max, \
-                       weight_d, tau_over_w, eps_d, stop_iter)
-        if (N <= 64) {
-            if (M <= 64) SCIPNP_TVP(64, 4); else SCIPNP_TVP(64, 8);
-        } else {
-            if (M <= 64) SCIPNP_TVP(128, 8); else SCIPNP_TVP(128, 16);
-        }
-#undef SCIPNP_TVP
-        return launch_status("tv_plane_kernel");
+        return tv_plane_launch(x, b, coef, theta, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, stop_iter, nullptr, st);
     }
     for (int it = 0; it < n_iter_max; ++it) {
         if (it == 0)

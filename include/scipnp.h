@@ -381,10 +381,14 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
 
 /* ADMM-TV iteration of either solver (dvp...:121-160, :265-271 two-stage; :385-407, :500-509 one-stage):
  * two_stage != 0: c0 = rho, c1 = alpha (theta = TV(x + b/rho), b += x - theta);
- * two_stage == 0: c0 = lambda, c1 = gamma (theta = TV(x - b), b -= x - theta). */
+ * two_stage == 0: c0 = lambda, c1 = gamma (theta = TV(x - b), b -= x - theta).
+ * Planes up to 128 x 128 (cubes up to 256 x 256): two launches, the projection and one kernel for all TV iterations plus
+ * the dual update (theta_raw is then left untouched); larger planes: projection, a launch per TV iteration, dual update.
+ * sse_part must hold the partials of scipnp_pm_dual_update's grid (size query: scipnp_sse_partials); all of them are
+ * written (the fused kernel zero-fills the entries it does not use), *nblocks receives their number. */
 typedef struct {
     int M, N, B, two_stage;
-    float *theta, *b, *x, *theta_raw;   /* state [B][4][M][N] */
+    float *theta, *b, *x, *theta_raw;   /* state [B][4][M][N]; theta_raw: scratch for the unclipped TV output */
     const float *Phi, *y, *Phisum;
     float c0, c1, tv_weight;            /* tv_weight = 0.1 in the reference */
     int tv_iters;                       /* n_iter_max = 5 in the reference */
