@@ -21,10 +21,13 @@
 // global memory and LDS (bank-conflict free).
 //
 // Structure (as conv.hip): workgroup = 4 waves = 8x32 output pixels x (32*COB) channels, wave = 2 rows; K loop over
-// the input channel groups; per group the input halo tile (both planes) and the weight slab are staged into one of
-// two LDS buffers by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; lanes outside the
-// image fetch zeros through the buffer descriptor's bounds check), issued one group ahead; fragments are read with
-// ds_read_b128; one s_waitcnt vmcnt(0) + barrier per group.  168 VGPRs, 80 KiB LDS -> 2 workgroups per CU.
+// the input channel groups; per group the input halo tile (both planes) and the weight slab are staged into LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; lanes outside the image fetch zeros through
+// the buffer descriptor's bounds check); fragments are read with ds_read_b128.  Dispatched form for stride 1 (WS = 1):
+// the input tile is double-buffered and fetched one group ahead, the weight slab has ONE buffer that is refilled
+// between two barriers after each group -- 168 VGPRs, 51 KiB LDS -> 3 workgroups (12 waves) per CU.  Stride-2 layers and
+// flag 0x200 keep both regions double-buffered (one barrier per group, 77 KiB for COB = 3 -> 2 workgroups per CU).
+// Per group and wave: 84 MFMAs, 60 ds_read_b128, 60 v_pk_mul_f16 (the 2^11 of the hi x hi weight fragments).
 // Epilogues: split again to c8s (+ReLU), or fp32 c8 (network tails), or fp32 c8 with PixelShuffle(2) folded into the
 // store; stride 1 or 2.
 #include "common.hpp"
