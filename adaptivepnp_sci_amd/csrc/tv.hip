@@ -298,18 +298,25 @@ tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
         return;
     }
     double acc = 0.0;
+    // all loads first: b is read and written through the same pointer, so a load placed after a store would wait for it
+    float xv[TVP_R], bo[TVP_R], og[TVP_R];
+#pragma unroll
+    for (int k = 0; k < TVP_R; ++k) {
+        const size_t o = chan + (size_t)(r0 + k) * N + col;
+        xv[k] = ok[k] ? x[o] : 0.f;
+        bo[k] = ok[k] ? dual.b[o] : 0.f;
+        og[k] = (ok[k] && dual.sse_part) ? dual.orig[o] : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < TVP_R; ++k) {
         if (ok[k]) {
             const size_t o = chan + (size_t)(r0 + k) * N + col;
-            const float xv = x[o];
             const float th = fminf(fmaxf(out[k], 0.f), 1.f);
-            const float d = xv - th;
-            const float bo = dual.b[o];
-            dual.b[o] = (dual.sign > 0.f) ? (bo + d) : (bo - d);
+            const float d = xv[k] - th;
+            dual.b[o] = (dual.sign > 0.f) ? (bo[k] + d) : (bo[k] - d);
             theta[o] = th;
             if (dual.sse_part) {
-                const float e = dual.orig[o] - (dual.which == 0 ? th : xv);
+                const float e = og[k] - (dual.which == 0 ? th : xv[k]);
                 acc += (double)(e * e);
             }
         }
