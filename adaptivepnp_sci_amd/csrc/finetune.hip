@@ -152,7 +152,7 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, float* __restric
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = co_count * Cin_real * 9;
     if (idx >= total) return;
-    const int tap = idx % 9, ci = (idx / 9) % Cin_real, co = idx / (9 * Cin_real);
+    const int ci = idx % Cin_real, co = (idx / Cin_real) % co_count, tap = idx / (Cin_real * co_count);   // coalesced slab reads
     const size_t stride = (size_t)9 * coP * ciP;
     const float* p = slabs + ((size_t)tap * coP + co) * ciP + ci;
     float s = 0.f;

@@ -177,7 +177,9 @@ wgrad_reduce_scaled_kernel(const float* __restrict__ slabs, int nslab, float* __
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = co_count * Cin_real * 9;
     if (idx >= total) return;
-    const int tap = idx % 9, ci = (idx / 9) % Cin_real, co = idx / (9 * Cin_real);
+    // ci fastest: the lanes of a wave read consecutive floats of one slab row (the slab layout's fastest index); the
+    // 36-byte-strided write of dW happens once, the slabs are read nslab times
+    const int ci = idx % Cin_real, co = (idx / Cin_real) % co_count, tap = idx / (Cin_real * co_count);
     const size_t stride = (size_t)9 * coP * ciP;
     const float* p = slabs + ((size_t)tap * coP + co) * ciP + ci;
     float s = 0.f;
