@@ -49,7 +49,7 @@ def _upload_flat(flat_dev, srcs):
             flat_dev[off:off + t.numel()].copy_(t.reshape(-1))
             off += t.numel()
     else:
-        flat_dev.copy_(torch.cat([t.reshape(-1).to(torch.float32) for t in srcs]))
+        flat_dev.copy_(torch.from_numpy(ops.host_flat(srcs)))
 
 
 def _download_flat(flat_dev, dsts):
@@ -61,11 +61,15 @@ def _download_flat(flat_dev, dsts):
                 t.copy_(flat_dev[off:off + t.numel()].view(t.shape))
                 off += t.numel()
         else:
-            host = flat_dev.cpu()
+            host = flat_dev.cpu().numpy()
             off = 0
-            for t in dsts:
-                t.copy_(host[off:off + t.numel()].view(t.shape))
-                off += t.numel()
+            for t in dsts:                      # NumPy copies: see ops.host_flat on why not Tensor.copy_
+                n = t.numel()
+                if t.dtype == torch.float32 and t.is_contiguous():
+                    np.copyto(t.detach().numpy().reshape(-1), host[off:off + n])
+                else:
+                    t.copy_(torch.from_numpy(host[off:off + n]).view(t.shape))
+                off += n
 
 
 def _carve(flat, like):

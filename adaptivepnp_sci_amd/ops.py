@@ -345,6 +345,15 @@ def pack_conv3x3_split_device(w, bias, packed, Cin, Cout, transpose=False, scale
     return packed
 
 
+def host_flat(tensors):
+    """host tensors -> one flat float32 NumPy array.  NumPy's single-threaded copy on purpose: a CPU-side torch.cat /
+    copy_ of a tensor above ATen's grain size wakes the whole intra-op thread pool (one thread per visible core), whose
+    idle spinning can exhaust a container's CPU quota and get the launching thread throttled for tens of milliseconds
+    (measured on the MI355X boxes: 256 visible cores, a 16-CPU cgroup quota, 50-90 ms stalls after every finetune event)"""
+    return np.concatenate([np.asarray(t.detach().numpy(), dtype=np.float32).reshape(-1) for t in tensors]) if tensors \
+        else np.zeros(0, np.float32)
+
+
 def device_params(tensors, device):
     """float32 contiguous device copies of a list of parameter tensors: tensors already on `device` are used as they
     are, host tensors travel in ONE flat upload (per-tensor pageable copies cost ~0.3 ms each)."""
@@ -352,7 +361,7 @@ def device_params(tensors, device):
     host = [i for i, t in enumerate(ts) if not t.is_cuda]
     out = [None if not t.is_cuda else t.to(device, F32).contiguous() for t in ts]
     if host:
-        flat = torch.cat([ts[i].reshape(-1).to(torch.float32) for i in host]).to(device)
+        flat = torch.from_numpy(host_flat([ts[i] for i in host])).to(device)
         off = 0
         for i in host:
             out[i] = flat[off:off + ts[i].numel()].view(ts[i].shape)
