@@ -150,6 +150,34 @@ def check(rc, what):
 _gpu_ok = False
 
 
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask capped by the container's cgroup-v2 CPU quota"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cap_host_threads():
+    """PyTorch sizes its intra-op pool by the VISIBLE cores.  Where the container's CPU quota is smaller (the MI355X boxes:
+    256 visible, 16 allowed) every CPU-side tensor op above ATen's grain size -- a deepcopy of the denoiser, a
+    load_state_dict -- wakes the whole pool, its idle spinning exhausts the quota and the thread that launches the kernels
+    is throttled for 50-90 ms (/sys/fs/cgroup/cpu.stat nr_throttled).  Lower (never raise) the pool to what the
+    container can run; SCIPNP_KEEP_TORCH_THREADS=1 leaves it alone."""
+    import os
+    import torch
+    if os.environ.get('SCIPNP_KEEP_TORCH_THREADS'):
+        return
+    n = usable_cpus()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+
+
 def require_gpu():
     global _gpu_ok
     if _gpu_ok:
@@ -157,6 +185,7 @@ def require_gpu():
     import torch
     if torch.cuda.is_available():
         _gpu_ok = True
+        cap_host_threads()
         return
     if not torch.cuda.is_available():
         raise ScipnpError('no MI355X/ROCm device visible: the scipnp hot path runs only on the GPU '

@@ -29,7 +29,8 @@ from statistics import mean
 import numpy as np
 import torch
 
-from . import shard as _shard
+from . import _lib, shard as _shard
+from ._lib import usable_cpus      # noqa: F401  (re-exported: drivers cap torch.set_num_threads() with it)
 from .solver import admm_denoise_bayer_demosaic_pre, twoStageAdmm_denoise_bayer
 
 MAXB = 255.
@@ -337,21 +338,6 @@ def run_two_stage(scene, warm, denoiser, model_denoise, model_demosaic=None, sch
     return out
 
 
-def usable_cpus():
-    """CPUs this process may really use: its affinity mask capped by the container's cgroup-v2 CPU quota.  PyTorch sizes
-    its intra-op pool by the VISIBLE cores; when that exceeds the quota (256 vs 16 on the MI355X boxes), the pool's idle
-    spinning after any CPU-side tensor op exhausts the quota and the kernel-launching thread is throttled for tens of
-    milliseconds -- drivers of this library should cap torch.set_num_threads() at this number."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
-
-
 def worker_init_fn(pid=0):
     """the reference drivers' seeding (utilspy.py:22-25, called as worker_init_fn(0) at the top of every driver): the
     FastDVDnet finetune draws its noise from the global NumPy generator seeded here"""
@@ -385,7 +371,7 @@ def main(argv=None):
     ap.add_argument('--no-reuse-model', action='store_true')
     args = ap.parse_args(argv)
     worker_init_fn(0)
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus())))      # see usable_cpus
+    _lib.cap_host_threads()
     scene = load_scene(args.scene)
     os.makedirs(args.results, exist_ok=True)
     with open(os.path.join(args.results, 'log.txt'), 'a') as f:

@@ -54,11 +54,11 @@ def reconstruct_sharded(units, solve, unit_shape, device, model=None, dst=0, gro
     unit_shape on `device`.  Every unit gets its own deep copy of `model` so that the online finetune of one
     unit cannot leak into another (parity-exact sharding).
 
-    streams > 1: this rank's units are solved by that many host threads, each on its own HIP stream -- small units
-    (256 x 256 tiles) leave CUs idle at the tail of every launch and stall on the host-side steps of a finetune event;
-    a second stream fills those gaps.  Results do not depend on it (units are independent, kernels deterministic) --
-    except when `solve` draws from a process-global RNG, as the FastDVDnet finetune does with NumPy's: pass streams=1
-    there to keep the draws in unit order."""
+    streams > 1: this rank's units are solved by that many host threads, each on its own HIP stream.  Results do not
+    depend on it (units are independent, kernels deterministic) -- except when `solve` draws from a process-global RNG,
+    as the FastDVDnet finetune does with NumPy's (keep streams=1 there so the draws stay in unit order).  It is an option,
+    not the default: with the host side free of stalls (see _lib.cap_host_threads) one stream already keeps the GPU busy
+    -- four 256 x 256 x 16 tiles with the online finetune take 191-237 ms on one stream and 208-271 ms on two."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = partition(len(units), world, rank)
@@ -122,13 +122,11 @@ def stitch_tiles(tiles, H, W, tile):
     return out
 
 
-def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None, streams=2):
+def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=None, dst=0, group=None, streams=1):
     """Tile a large cube, reconstruct the patches independently on the ranks of `group` (tile j on rank j % world, each
     with its own deep copy of `model`), gather them with ONE collective and stitch on rank `dst`.
     solve((y_t, Phi_t, x0_t, orig_t), model_copy) -> (tile, tile, B) tensor on `device`.
-    Two host threads / HIP streams per rank by default: 256 x 256 tiles give the conv kernels 1024 workgroups for 768
-    resident slots and a finetune event has host-side steps; measured on one MI355X, four 256x256x16 tiles with the
-    online finetune: 200-258 ms against 454-516 ms one after the other, identical results.
+    `streams`: as reconstruct_sharded (one stream keeps the GPU busy: ~48 ms per 256x256x16 tile with the online finetune).
     Returns the (H, W, B) mosaic on rank dst, None elsewhere."""
     H, W, B = Phi.shape
     units = tile_cube(y, Phi, tile, x0, orig)

@@ -58,14 +58,8 @@ def load_weights():
 
 
 def _usable_cpus():
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:                                             # cgroup v2 CPU quota of the container, if any
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
+    from adaptivepnp_sci_amd._lib import usable_cpus
+    return usable_cpus()
 
 
 def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosaic=None, gpu_psnr=None):
