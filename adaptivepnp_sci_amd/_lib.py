@@ -173,7 +173,8 @@ def cap_host_threads():
     import torch
     if os.environ.get('SCIPNP_KEEP_TORCH_THREADS'):
         return
-    n = usable_cpus()
+    # one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the ranks of a node share the quota
+    n = max(1, usable_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
 

@@ -129,10 +129,10 @@ def main():
     # PyTorch sizes its intra-op pool by the visible cores (256 on the MI355X boxes) while the container's CPU quota is 16:
     # any CPU-side tensor op above the grain size wakes the pool, whose idle spinning exhausts the quota and gets this
     # (launching) thread throttled for tens of milliseconds -- keep the pool inside the quota
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cpus())))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cpus() // max(1, world))))   # ranks share the quota
     dist = None
     if world > 1 or os.environ.get('SCIPNP_BENCH_FORCE_DIST'):       # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
