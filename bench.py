@@ -278,7 +278,11 @@ def main():
                                                 gpu_psnr=psnr)
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line))
+        # RCCL (NCCL_DEBUG=VERSION on the boxes) writes its banner to the C-level stdout buffer: flush it first so that the
+        # JSON line is the last thing this rank prints
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
