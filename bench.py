@@ -170,6 +170,8 @@ def main():
     if dist is not None:
         # untimed: the first gather sets up RCCL's point-to-point connections over xGMI
         shard.gather_units({rank: run.result_mosaic()}, world, (H, W, B), dev, dst=0)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # every rank's RCCL banner (NCCL_DEBUG=VERSION) leaves its C stdout buffer now
     events = []
     run.profile_events = events
     phi_events = []
