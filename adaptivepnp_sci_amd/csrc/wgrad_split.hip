@@ -182,8 +182,18 @@ wgrad_reduce_scaled_kernel(const float* __restrict__ slabs, int nslab, float* __
     const int ci = idx % Cin_real, co = (idx / Cin_real) % co_count, tap = idx / (Cin_real * co_count);
     const size_t stride = (size_t)9 * coP * ciP;
     const float* p = slabs + ((size_t)tap * coP + co) * ciP + ci;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += p[(size_t)k * stride];
+    // four interleaved partial sums (slab k -> accumulator k % 4), then ((s0+s1)+s2)+s3: a fixed order, and four loads in
+    // flight per lane instead of a chain of nslab dependent ones
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nslab; k += 4) {
+        s0 += p[(size_t)k * stride];
+        s1 += p[(size_t)(k + 1) * stride];
+        s2 += p[(size_t)(k + 2) * stride];
+        s3 += p[(size_t)(k + 3) * stride];
+    }
+    for (; k < nslab; ++k) s0 += p[(size_t)k * stride];
+    const float s = ((s0 + s1) + s2) + s3;
     dW[((size_t)(co0 + co) * Cin_real + ci) * 9 + tap] = s * scale;
 }
 
