@@ -345,6 +345,16 @@ def pack_conv3x3_split_device(w, bias, packed, Cin, Cout, transpose=False, scale
     return packed
 
 
+def to_host(t):
+    """device tensor -> NumPy array through a page-locked buffer of PyTorch's caching host allocator (the array keeps the
+    buffer alive; it returns to the cache when the array is dropped).  A pageable `.cpu()` of the 25 MiB RGB cube + 8 MiB
+    mosaic of a 512 x 512 x 8 reconstruction takes 3.8 ms on the MI355X boxes, this 0.6 ms (tools/probes/d2h_probe.py)."""
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return h.numpy()
+
+
 def host_flat(tensors):
     """host tensors -> one flat float32 NumPy array.  NumPy's single-threaded copy on purpose: a CPU-side torch.cat /
     copy_ of a tensor above ATen's grain size wakes the whole intra-op thread pool (one thread per visible core), whose

@@ -414,11 +414,11 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
     _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True, run.orig is None)
-    x_bayer_np = run.result_mosaic().cpu().numpy()
+    x_bayer_np = ops.to_host(run.result_mosaic())
     psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
         return x_bayer_np, psnr_, ssim_, psnr_all
-    return ops.rgb_to_cube(run.out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model_denoise, model_demosaic
+    return ops.to_host(ops.rgb_to_cube(run.out_rgb)), x_bayer_np, psnr_, ssim_, psnr_all, model_denoise, model_demosaic
 
 
 def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
@@ -440,11 +440,11 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     _run_schedule(run, sigma, iter_max)
     psnr_all = run.psnr_all()
     _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, False)
-    x_bayer_np = run.result_mosaic().cpu().numpy()
+    x_bayer_np = ops.to_host(run.result_mosaic())
     psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
         return x_bayer_np, psnr_, ssim_, psnr_all
-    return ops.rgb_to_cube(run.out_rgb).cpu().numpy(), x_bayer_np, psnr_, ssim_, psnr_all, model
+    return ops.to_host(ops.rgb_to_cube(run.out_rgb)), x_bayer_np, psnr_, ssim_, psnr_all, model
 
 
 def admm_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
