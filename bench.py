@@ -21,7 +21,6 @@ The JSON line also carries
                  very iterations the GPU ran and the line carries their parity (`cpu_baseline.parity`).
 """
 import argparse
-import io
 import json
 import os
 import sys

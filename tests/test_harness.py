@@ -1,6 +1,5 @@
 """Scene harness: on-disk formats and schedules on CPU; the per-measurement drivers with model
 carry-over against the oracle on the GPU."""
-import copy
 import io
 import os
 
@@ -9,7 +8,7 @@ import pytest
 import torch
 
 from adaptivepnp_sci_amd import harness, synth
-from conftest import load_gold, rel_l2
+from conftest import rel_l2
 
 
 def _scene_arrays(H=32, W=32, nmask=8, nmea=2, seed=3):

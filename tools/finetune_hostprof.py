@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: cProfile of one FastDVDnet online-finetune event (host-side cost of the launch sequence)."""
 import cProfile, os, pstats, sys
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import synth
 from adaptivepnp_sci_amd.solver import AdmmRun

@@ -2,7 +2,7 @@
 """ON THE GPU BOX: the Chambolle TV step, tiled kernel (a launch per iteration) vs whole-plane kernel (one launch), and the
 ADMM-TV iteration / whole call built on it (configs[0])."""
 import io, os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import ops, synth, admm_denoise_bayer_demosaic_pre
 from adaptivepnp_sci_amd.solver import AdmmRun
