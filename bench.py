@@ -95,7 +95,11 @@ def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosa
         t0 = time.perf_counter()
         o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
         dt = time.perf_counter() - t0
-    out = dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port',
+    try:
+        cpu_model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except Exception:
+        cpu_model = 'unknown'
+    out = dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port', cpu_model=cpu_model,
                sample=f'{iters} two-stage ADMM+FFDNet iteration(s) of the same 512x512x8 cube (sigma 25/255, TV warm '
                       f'start), PyTorch-CPU oracle, {cores} of {usable} usable CPU threads, {dt:.1f} s')
     # one iteration on ONE thread (SURVEY 8d asks for both figures), if it fits the sample budget
