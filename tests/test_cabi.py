@@ -128,3 +128,39 @@ def test_signatures_mirror_the_reference():
                    'logf', 'useGPU', 'device', 'update_', 'update_per_iter']
     d = inspect.signature(twoStageAdmm_denoise_bayer).parameters
     assert d['iter_max'].default == 50 and d['lr_'].default == 1e-6 and d['interval_iter'].default == 5
+
+
+def test_host_thread_cap(monkeypatch):
+    """the package lowers (never raises) PyTorch's intra-op pool to the CPUs the container may use -- affinity mask and
+    cgroup quota, shared by the ranks of a node -- and SCIPNP_KEEP_TORCH_THREADS opts out"""
+    import torch
+    from adaptivepnp_sci_amd import _lib
+    n = _lib.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setenv('SCIPNP_KEEP_TORCH_THREADS', '1')
+        torch.set_num_threads(before)
+        _lib.cap_host_threads()
+        assert torch.get_num_threads() == before
+        monkeypatch.delenv('SCIPNP_KEEP_TORCH_THREADS')
+        monkeypatch.setenv('LOCAL_WORLD_SIZE', str(4 * n))           # more ranks than CPUs: one thread each
+        _lib.cap_host_threads()
+        assert torch.get_num_threads() == 1
+        torch.set_num_threads(1)
+        monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+        _lib.cap_host_threads()
+        assert torch.get_num_threads() == 1                          # never raised
+    finally:
+        torch.set_num_threads(before)
+
+
+def test_host_flat_matches_torch_cat():
+    import numpy as np
+    import torch
+    from adaptivepnp_sci_amd import ops
+    ts = [torch.randn(3, 4), torch.randn(5).double(), torch.randn(6, 2).t(), torch.nn.Parameter(torch.randn(2, 2, 3, 3))]
+    ref = torch.cat([t.detach().reshape(-1).float() for t in ts]).numpy()
+    got = ops.host_flat(ts)
+    assert got.dtype == np.float32 and np.array_equal(got, ref)
+    assert ops.host_flat([]).shape == (0,)
