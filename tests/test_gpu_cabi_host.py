@@ -64,3 +64,34 @@ def test_plain_c_host_reconstructs_like_the_python_solver(tmp_path):
     ref = twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [iters], False, [float(sigma)], x0_bayer=warm,
                                      model_denoise=net, logf=io.StringIO())[1]
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
+def test_the_ctypes_stub_of_integration_md_runs_as_written():
+    """INTEGRATION.md section 2 shows the binding a maintainer of the reference would add to utilspy.py and to the projection
+    loop: execute that code block verbatim (only the library path is made absolute) against the reference's own
+    expressions (oracle/sci_ops.py) -- bit-exact, including the in-place call where xall aliases theta_all"""
+    import re
+    import numpy as np
+    import torch
+    from oracle import sci_ops as OO
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = re.search(r"```python\n(import ctypes, torch\n.*?)```", text, re.S).group(1)
+    block = block.replace("'libscipnp.so'", repr(os.path.join(ROOT, 'adaptivepnp_sci_amd', 'libscipnp.so')))
+    ns = {}
+    exec(compile(block, 'INTEGRATION.md', 'exec'), ns)
+    rng = np.random.default_rng(12)
+    M, N, B = 12, 20, 8
+    T = lambda a: torch.from_numpy(a)               # noqa: E731
+    theta, b = rng.random((M, N, B, 4), np.float32), (0.2 * rng.standard_normal((M, N, B, 4))).astype(np.float32)
+    Phi = (rng.random((M, N, B, 4)) < 0.5).astype(np.float32)
+    y = (rng.random((M, N, 4)) * B / 2).astype(np.float32)
+    Ps = Phi.sum(2)
+    Ps[Ps == 0] = 1
+    dev = lambda a: T(a).cuda()                     # noqa: E731
+    A_ref = torch.stack([OO.forward_A(T(theta)[..., ib], T(Phi)[..., ib]) for ib in range(4)], -1)
+    assert torch.equal(ns['A_all'](dev(theta), dev(Phi)).cpu(), A_ref)
+    ref = OO.project_two_stage(T(theta), T(b), T(Phi), T(y), T(Ps), 0.55, 1.0)
+    th = dev(theta)
+    ns['project_all'](th, dev(b), dev(Phi), dev(y), dev(Ps), 0.55, 1.0, th)         # in place, as at k = 0
+    assert torch.equal(th.cpu(), ref)
