@@ -19,9 +19,15 @@
 
 namespace scipnp {
 
-constexpr int TV_TS = 32;        // tile edge
-constexpr int TV_TY = 8;         // block = 32 x 8 threads, 4 rows per thread
-constexpr int TV_RPT = TV_TS / TV_TY;
+// Tile = 16 rows x 256 columns (block = 256 x 4 threads, 4 rows per thread).  Wide and flat on purpose: a halo ROW is one
+// contiguous KiB per array, a halo COLUMN is one 128-byte line per element -- with 32 x 32 tiles the five column halos
+// made the kernel fetch 2.65x its algorithmic reads (88.7 MB against 33.5 MB per launch at 512 x 512 x 8, rocprofv3
+// FETCH_SIZE, profiles/r01h_pmc_traffic.json) at the HBM ceiling; quarter-resolution planes up to 256 wide now have no
+// column halo at all.
+constexpr int TV_TSX = 256;      // tile columns
+constexpr int TV_TSY = 16;       // tile rows
+constexpr int TV_TY = 4;
+constexpr int TV_RPT = TV_TSY / TV_TY;
 
 struct TvWorkspace {
     float* p[2];        // ping-pong dual field: [2][C][M][N] each (component-major)
@@ -34,7 +40,7 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 
 static size_t tv_layout(int M, int N, int C, int n_iter, void* base, TvWorkspace* ws) {
     const size_t img = (size_t)C * M * N;
-    const int nblk = ((M + TV_TS - 1) / TV_TS) * ((N + TV_TS - 1) / TV_TS);
+    const int nblk = ((M + TV_TSY - 1) / TV_TSY) * ((N + TV_TSX - 1) / TV_TSX);
     size_t off = 0;
     char* b = (char*)base;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return b ? b + o : nullptr; };
@@ -69,15 +75,15 @@ __device__ __forceinline__ float tv_out_at(const float* __restrict__ x, const fl
 }
 
 template <bool FIRST>
-__global__ void __launch_bounds__(TV_TS* TV_TY)
+__global__ void __launch_bounds__(TV_TSX* TV_TY)
 tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta,
                TvWorkspace ws, int it, int M, int N, int C, double weight, float tau_over_w, double eps,
                int32_t* stop_iter) {
-    __shared__ float s_out[TV_TS + 1][TV_TS + 1];
+    __shared__ float s_out[TV_TSY + 1][TV_TSX + 1];
     __shared__ double red[16];
     __shared__ int s_stop;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * TV_TS + tx;
+    const int tid = ty * TV_TSX + tx;
     const int c = blockIdx.z;
     const int ntx = gridDim.x, nty = gridDim.y;
     const int nblk = ntx * nty;
@@ -89,9 +95,9 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
         // ---- evaluate iteration it-1 for this channel (skimage's stop test), identically in every block
         const double* part = ws.partial + ((size_t)(it - 1) * C + c) * nblk * 2;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = tid; k < nblk; k += TV_TS * TV_TY) { s1 += part[2 * k]; s2 += part[2 * k + 1]; }
-        s1 = block_sum_double(s1, red, tid, TV_TS * TV_TY);
-        s2 = block_sum_double(s2, red, tid, TV_TS * TV_TY);
+        for (int k = tid; k < nblk; k += TV_TSX * TV_TY) { s1 += part[2 * k]; s2 += part[2 * k + 1]; }
+        s1 = block_sum_double(s1, red, tid, TV_TSX * TV_TY);
+        s2 = block_sum_double(s2, red, tid, TV_TSX * TV_TY);
         if (tid == 0) {
             // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
             double E = (double)(float)s1;
@@ -121,7 +127,7 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     const float* p1 = p0 + (size_t)C * img;
     float* q0 = ws.p[it & 1] + chan;
     float* q1 = q0 + (size_t)C * img;
-    const int r0 = blockIdx.y * TV_TS, c0 = blockIdx.x * TV_TS;
+    const int r0 = blockIdx.y * TV_TSY, c0 = blockIdx.x * TV_TSX;
     const int col = c0 + tx;
     const float* xc = x + chan;
     const float* bc = b ? b + chan : nullptr;
@@ -137,12 +143,12 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     // right halo column (tx == 0 threads of each row group) and bottom halo row (ty == 0 row)
     float dummy;
     if (tx < TV_RPT) {
-        const int lr = ty * TV_RPT + tx, r = r0 + lr, cc = c0 + TV_TS;
-        if (r < M && cc < N) s_out[lr][TV_TS] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, cc, N, &dummy);
+        const int lr = ty * TV_RPT + tx, r = r0 + lr, cc = c0 + TV_TSX;
+        if (r < M && cc < N) s_out[lr][TV_TSX] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, cc, N, &dummy);
     }
     if (ty == TV_TY - 1) {
-        const int r = r0 + TV_TS;
-        if (r < M && col < N) s_out[TV_TS][tx] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, col, N, &dummy);
+        const int r = r0 + TV_TSY;
+        if (r < M && col < N) s_out[TV_TSY][tx] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, col, N, &dummy);
     }
     __syncthreads();
 
@@ -167,8 +173,8 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
             theta[chan + o] = out;
         }
     }
-    acc1 = block_sum_double(acc1, red, tid, TV_TS * TV_TY);
-    acc2 = block_sum_double(acc2, red, tid, TV_TS * TV_TY);
+    acc1 = block_sum_double(acc1, red, tid, TV_TSX * TV_TY);
+    acc2 = block_sum_double(acc2, red, tid, TV_TSX * TV_TY);
     if (tid == 0) {
         double* part = ws.partial + (((size_t)it * C + c) * nblk + blk) * 2;
         part[0] = acc1;
@@ -181,7 +187,7 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
 // neighbours inside a strip are register neighbours, column neighbours are wave neighbours (DPP shuffles); only the
 // strip and wave seams go through LDS.  The stop test is evaluated by every thread from the same 16 wave partials in
 // the same order.  Same float32 operations per pixel as tv_iter_kernel, so `out` is bit-identical; the fp64 energy
-// sums associate differently (per wave instead of per 32x32 tile) before they are rounded to float32.
+// sums associate differently (per wave instead of per tile) before they are rounded to float32.
 // Templated on the column count (128, or 64 for narrow planes: 16 strips) and on the register rows per thread.
 constexpr int TVP_THREADS = 1024, TVP_MAX = 128;
 
@@ -421,8 +427,8 @@ int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* th
     const size_t need = tv_layout(M, N, C, n_iter_max, workspace, &ws);
     if (workspace_bytes < need) return fail(SCIPNP_EWORKSPACE, "TV workspace too small: %zu < %zu", workspace_bytes, need);
     hipStream_t st = (hipStream_t)s;
-    const dim3 block(TV_TS, TV_TY);
-    const dim3 grid((N + TV_TS - 1) / TV_TS, (M + TV_TS - 1) / TV_TS, C);
+    const dim3 block(TV_TSX, TV_TY);
+    const dim3 grid((N + TV_TSX - 1) / TV_TSX, (M + TV_TSY - 1) / TV_TSY, C);
     const double eps_d = as_double(eps);
     const double weight_d = as_double(weight);
     const float tau_over_w = (float)(0.25 / weight_d);

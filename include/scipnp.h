@@ -107,7 +107,7 @@ int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta
                         void* workspace, size_t workspace_bytes, int32_t* stop_iter,
                         scipnp_stream_t s);
 /* the same with the kernel named: 0 = as scipnp_tv_chambolle chooses (planes up to 128 x 128: all iterations in ONE
- * launch, a workgroup per channel holding its plane in registers; larger planes: one launch of 32 x 32 tiles per
+ * launch, a workgroup per channel holding its plane in registers; larger planes: one launch of 16 x 256 tiles per
  * iteration), 1 = the tiled kernel, 2 = the whole-plane kernel (SCIPNP_EINVAL if the plane does not fit). */
 int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* theta,
                            int M, int N, int C, float weight, float eps, int n_iter_max,
