@@ -65,7 +65,17 @@ conv3x3_wgrad_split_kernel(const char* __restrict__ act, const char* __restrict_
     const int lane = tid & 63, tap = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int ky = tap / 3, kx = tap - 3 * ky;
-    const int cib = blockIdx.y;
+    // (slab, input-channel block) of this workgroup.  The ncib blocks of one slab walk the same tiles at the same time and
+    // read the same dZ; workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so when the slab count is a
+    // multiple of 8 the linear id is remapped such that the blocks of a slab share an XCD and dZ is fetched from HBM once
+    // per slab instead of once per block (measured before: 888 MB per launch against 402 MB algorithmic at 96 channels)
+    int slab_id = blockIdx.x, cib = blockIdx.y;
+    const int nslab = gridDim.x, ncib = gridDim.y;
+    if (ncib > 1 && (nslab & 7) == 0) {
+        const int L = blockIdx.x + nslab * blockIdx.y, j = L >> 3;
+        slab_id = (L & 7) + 8 * (j / ncib);
+        cib = j % ncib;
+    }
     const size_t HW = (size_t)H * W;
     const int tiles_x = (W + WS_TW - 1) / WS_TW, tiles_y = (H + WS_TR - 1) / WS_TR;
     const int tiles = n_img * tiles_y * tiles_x;
@@ -133,15 +143,15 @@ conv3x3_wgrad_split_kernel(const char* __restrict__ act, const char* __restrict_
     const int a_lane = grp_sel * WS_GD + (8 * lh + q) * 16 + 8 * (p & 1);
     const int b_lane = Cfg::ACT_BASE + grp_sel * WS_GA + ((ky * WS_AW + kx) + 8 * lh + q) * 16 + 8 * (p & 1);
 
-    int tile = blockIdx.x;
+    int tile = slab_id;
     if (tile < tiles) fetch(tile);
-    for (; tile < tiles; tile += gridDim.x) {
+    for (; tile < tiles; tile += nslab) {
         __syncthreads();                                    // previous tile's reads are done
 #pragma unroll
         for (int k = 0; k < Cfg::ITERS; ++k)
             if (s_lds[k] >= 0) *(uint4*)(smem_w + s_lds[k]) = stage[k];
         __syncthreads();
-        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);      // in flight while this tile is consumed
+        if (tile + nslab < tiles) fetch(tile + nslab);      // in flight while this tile is consumed
 #pragma unroll
         for (int ks = 0; ks < WS_PX / 16; ++ks) {
             const int r = ks >> 1, c0 = 16 * (ks & 1);
@@ -158,8 +168,8 @@ conv3x3_wgrad_split_kernel(const char* __restrict__ act, const char* __restrict_
         }
     }
     // C[row = co_local][col = ci_local]: row = (r&3) + 8*(r>>2) + 4*lh, col = li
-    const int coP = 32 * COB, ciP = 32 * gridDim.y;
-    float* slab = slabs + ((size_t)blockIdx.x * 9 + tap) * coP * ciP;
+    const int coP = 32 * COB, ciP = 32 * ncib;
+    float* slab = slabs + ((size_t)slab_id * 9 + tap) * coP * ciP;
 #pragma unroll
     for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
