@@ -225,6 +225,18 @@ def main():
         phi_large = {'cube': [Hl, Hl, Bl], 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'achieved': lb / ls / 1e9,
                      'unit': 'GB/s', 'frac': lb / ls / 8e12}
         del th, bb, ph, yy, ps, xo
+        # and on the bench's own 512 x 512 x 8 state, 50 launches between one event pair (no per-launch event overhead)
+        xs = torch.empty_like(run.x)
+        for _ in range(3):
+            ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
+        e1.record()
+        torch.cuda.synchronize()
+        phi_b2b_s = e0.elapsed_time(e1) / 50 * 1e-3
+        del xs
     body_ms = [a.elapsed_time(b) for a, b in events]
     body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
     psnr = run.psnr_all()
@@ -272,6 +284,8 @@ def main():
                          'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
                          'achieved': phi_bytes / phi_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': phi_bytes / phi_s / 8e12,
                          'peak_measured': measured.get('hbm_read_GBs'), 'large_state': phi_large,
+                         'back_to_back': {'launches': 50, 'launch_us': phi_b2b_s * 1e6, 'achieved': phi_bytes / phi_b2b_s / 1e9,
+                                          'frac': phi_bytes / phi_b2b_s / 8e12},
                          'note': 'event pair around one ~10 us launch includes ~2-3 us of event/launch overhead; rocprofv3 '
                                  'kernel time is in profiles/'},
             'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None],
