@@ -91,38 +91,6 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     const size_t img = (size_t)M * N;
     const size_t chan = (size_t)c * img;
 
-    if (!FIRST) {
-        // ---- evaluate iteration it-1 for this channel (skimage's stop test), identically in every block
-        const double* part = ws.partial + ((size_t)(it - 1) * C + c) * nblk * 2;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = tid; k < nblk; k += TV_TSX * TV_TY) { s1 += part[2 * k]; s2 += part[2 * k + 1]; }
-        s1 = block_sum_double(s1, red, tid, TV_TSX * TV_TY);
-        s2 = block_sum_double(s2, red, tid, TV_TSX * TV_TY);
-        if (tid == 0) {
-            // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
-            double E = (double)(float)s1;
-            E += weight * (double)(float)s2;           // `weight` is the Python double of the reference: see host
-            E /= (double)img;
-            int stopped = 0;
-            if (it - 1 >= 1) {
-                const int was = ws.stopped[(size_t)(it - 2) * C + c];
-                const double E0 = ws.energy[c];
-                const double Eprev = ws.energy[(size_t)(it - 2) * C + c];
-                stopped = was || (fabs(Eprev - E) < eps * E0);
-                if (stopped && !was && stop_iter && blk == 0) stop_iter[c] = it - 1;
-            }
-            if (blk == 0) {
-                ws.energy[(size_t)(it - 1) * C + c] = E;
-                ws.stopped[(size_t)(it - 1) * C + c] = stopped;
-            }
-            s_stop = stopped;
-        }
-        __syncthreads();
-        if (s_stop) return;
-    } else if (stop_iter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        stop_iter[c] = -1;  // patched to n_iter_max-1 by the host wrapper's last launch (see below)
-    }
-
     const float* p0 = ws.p[(it + 1) & 1] + chan;          // written by iteration it-1
     const float* p1 = p0 + (size_t)C * img;
     float* q0 = ws.p[it & 1] + chan;
@@ -150,7 +118,43 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
         const int r = r0 + TV_TSY;
         if (r < M && col < N) s_out[TV_TSY][tx] = tv_out_at<FIRST>(xc, bc, coef, p0, p1, r, col, N, &dummy);
     }
+    if (!FIRST) {
+        // ---- evaluate iteration it-1 for this channel (skimage's stop test), identically in every block: wave 0 sums the
+        // channel's block partials (lane l takes k = l, l+64, ... in order, then a fixed shuffle tree) while the tile
+        // loads issued above are in flight; one barrier publishes the tile and the decision
+        if (tid < 64) {
+            const double* part = ws.partial + ((size_t)(it - 1) * C + c) * nblk * 2;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = tid; k < nblk; k += 64) { s1 += part[2 * k]; s2 += part[2 * k + 1]; }
+            for (int off = 32; off > 0; off >>= 1) {
+                s1 += __shfl_down(s1, off, 64);
+                s2 += __shfl_down(s2, off, 64);
+            }
+            if (tid == 0) {
+                // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
+                double E = (double)(float)s1;
+                E += weight * (double)(float)s2;           // `weight` is the Python double of the reference: see host
+                E /= (double)img;
+                int stopped = 0;
+                if (it - 1 >= 1) {
+                    const int was = ws.stopped[(size_t)(it - 2) * C + c];
+                    const double E0 = ws.energy[c];
+                    const double Eprev = ws.energy[(size_t)(it - 2) * C + c];
+                    stopped = was || (fabs(Eprev - E) < eps * E0);
+                    if (stopped && !was && stop_iter && blk == 0) stop_iter[c] = it - 1;
+                }
+                if (blk == 0) {
+                    ws.energy[(size_t)(it - 1) * C + c] = E;
+                    ws.stopped[(size_t)(it - 1) * C + c] = stopped;
+                }
+                s_stop = stopped;
+            }
+        }
+    } else if (stop_iter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        stop_iter[c] = -1;  // patched to n_iter_max-1 by the host wrapper's last launch (see below)
+    }
     __syncthreads();
+    if (!FIRST && s_stop) return;
 
     double acc1 = 0.0, acc2 = 0.0;
 #pragma unroll
