@@ -179,6 +179,17 @@ def cap_host_threads():
         torch.set_num_threads(n)
 
 
+def stream_ptr():
+    """the current HIP stream of the current device as a C pointer argument.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~8 us); the raw-handle query PyTorch uses internally costs a fraction of that,
+    which matters where a kernel launch is a ctypes call of a few microseconds"""
+    import torch
+    get = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if get is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(get(torch.cuda.current_device()))
+
+
 def require_gpu():
     global _gpu_ok
     if _gpu_ok:

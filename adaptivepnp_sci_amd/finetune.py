@@ -23,7 +23,7 @@ F32 = torch.float32
 
 
 def _s():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _ptr(t):

@@ -166,7 +166,7 @@ class FFDNetEngine:
         rc = lib.scipnp_ffdnet_forward(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), self._ptrs,
                                        self.nb, self.nc, C.c_void_p(self.scratch[0].data_ptr()),
                                        C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                       _lib.stream_ptr())
         _lib.check(rc, 'scipnp_ffdnet_forward')
         return out_c8
 
@@ -182,6 +182,6 @@ class FFDNetEngine:
         rc = lib.scipnp_ffdnet_forward_c8s(C.c_void_p(in_c8s.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, self.nb,
                                            self.nc, C.c_void_p(self.scratch[0].data_ptr()),
                                            C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                           _lib.stream_ptr())
         _lib.check(rc, 'scipnp_ffdnet_forward_c8s')
         return out_c8

@@ -13,7 +13,7 @@ F32 = torch.float32
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _p(t, name='tensor', dtype=F32):

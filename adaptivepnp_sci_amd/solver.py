@@ -158,7 +158,7 @@ class AdmmRun:
             part = self._new_sse(ops.sse_nblocks(self.x.numel())) if self.iqa else None
             self._tv_args.sse_part = 0 if part is None else part.data_ptr()
             _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(self._tv_args), None,
-                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                          _lib.stream_ptr()),
                        'scipnp_admm_tv_iterate')
             if ITERATE_HOOK is not None:
                 ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
