@@ -164,3 +164,14 @@ def test_host_flat_matches_torch_cat():
     got = ops.host_flat(ts)
     assert got.dtype == np.float32 and np.array_equal(got, ref)
     assert ops.host_flat([]).shape == (0,)
+
+
+def test_bench_cli_contract():
+    """the driver calls `python bench.py --gpus N --steps K --warmup W`: the flags must exist (no GPU needed to parse them)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--help'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in r.stdout
