@@ -69,7 +69,8 @@ class AdmmRun:
 
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
-                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None):
+                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None,
+                 conv_precision=None):
         if str(denoiser).lower() not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         denoiser = denoiser.lower()                # the reference compares denoiser.lower() (:146, :164, :214)
@@ -136,17 +137,17 @@ class AdmmRun:
             self.w = torch.zeros_like(self.x_rgb) if two_stage else None
             self.out_store = torch.empty_like(self.x_rgb)
             if denoiser == 'ffdnet_color':
-                self.eng = FFDNetEngine(model, B, M, N, self.device)
+                self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
             else:
                 from .fastdvd import FastDVDEngine
-                self.eng = FastDVDEngine(model, B, H, W, self.device)
+                self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision)
                 self.rgb_w = torch.empty_like(self.x_rgb)
             self.dd = None
             if model_demosaic is not None:       # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
                 if not two_stage:
                     raise ValueError('model_demosaic is an argument of the two-stage solver only (as in the reference)')
                 from .ddnet import DDnetEngine
-                self.dd = DDnetEngine(model_demosaic, B, H, W, self.device)
+                self.dd = DDnetEngine(model_demosaic, B, H, W, self.device, precision=conv_precision)
                 self.dd_planes = torch.empty_like(x0)
                 self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
 

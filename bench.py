@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: ADMM iterations/s (and reconstructed frames/s) of the two-stage PnP-ADMM +
-FFDNet-colour solver on a 512x512x8 Bayer cube per GPU (BASELINE.json configs[1]).  The FFDNet convolutions run
-on the error-compensated split-fp16 MFMA kernels by default (per-iterate parity <= 1e-5 verified by the GPU tests);
-SCIPNP_CONV_PRECISION=f32 selects the fp32 MFMA kernels.
+FFDNet-colour solver on a 512x512x8 Bayer cube per GPU (BASELINE.json configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher: this process starts N rank processes itself (one per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in their environment) BEFORE it touches the GPU, waits for them and relays rank 0's
+JSON line; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one of
+the ranks.  `--gpus` must equal the number of ranks (non-zero exit otherwise).
 
 One step = one ADMM iteration over one cube (projection, mosaic+Malvar+w fusion, FFDNet on 8 frames,
 theta/b/w updates, on-device PSNR partials) -- exactly `AdmmRun.step`, the code path behind
@@ -12,18 +15,34 @@ theta/b/w updates, on-device PSNR partials) -- exactly `AdmmRun.step`, the code 
 rank reconstructs its own cube (weak scaling, no collective inside the solve) and the (H,W,B)
 mosaics are gathered to rank 0 with ONE RCCL gather at the end of the timed region.
 
+The SAME invocation times both convolution precisions on the same cube:
+  headline (`value`, `dtype: "f32"`) : the FFDNet convolutions in fp32 arithmetic on the fp32 MFMA
+                 (the reference's precision);
+  `fast_path`  : the library default, error-compensated split-fp16 operands on the fp16 MFMA (22 significant
+                 bits per operand, fp32 accumulation; meets the 1e-5 / 1e-4 dB gates but is narrower than fp32,
+                 so it is reported beside the headline, not as it).
 The JSON line also carries
   roofline     : the dominant kernel (FFDNet body layer conv3x3), ALGORITHMIC FLOP/s measured with
-                 HIP events around the body-layer launches inside the timed region;
-  phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch (events inside the timed region);
+                 HIP events around the body-layer launches inside the timed region; `traffic` from rocprofv3
+                 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes) run as child processes of this
+                 invocation when rocprofv3 is available, else from the committed profile it names;
+  phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch;
+  configs      : the other single-GPU BASELINE configurations (ADMM-TV 256x256x8, FastDVDnet 512x512x8,
+                 a 256x256x16 tile with the online finetune): ms/iteration, dominant kernel, algorithmic
+                 fraction and parity against the CPU oracle for <= 3 iterations;
   cpu_baseline : the CPU oracle (bit-exact restatement of the reference) timed on this host on a
                  bounded sample of the same workload (rank 0, N=1 only); when the budget allows it runs the
                  very iterations the GPU ran and the line carries their parity (`cpu_baseline.parity`).
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,13 +56,54 @@ B = 8
 SIGMA = 25 / 255
 NB, NC = 12, 96
 BODY_FLOP_PER_LAUNCH = 2.0 * 9 * NC * NC * (H // 2) * (W // 2) * B              # one body layer, 8 frames
+BODY_BYTES_PER_LAUNCH = 2.0 * B * NC * (H // 2) * (W // 2) * 4                  # activations read once + written once
 FFDNET_FLOP_PER_ITER = 2.0 * 9 * (13 * NC + (NB - 2) * NC * NC + NC * 12) * (H // 2) * (W // 2) * B
 PEAK_FP32_MFMA = 157.3e12                                                       # MI355X_MICROARCH.md
 PEAK_F16_MFMA = 2500e12                                                         # dense f16/bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM = 8e12
 # split-fp16 kernel: 14 MFMA 32x32x16 (32768 FLOP each) per (8 in-ch x 9 taps x 32x32 outputs) = 147456 algorithmic FLOP
 SPLIT_EXEC_PER_ALGO = 14 * 32768 / 147456.0
+PRECISIONS = ('f32', 'f16x3')
 
 
+# ------------------------------------------------------------------------------------------------ rank launcher
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (rank i on GPU i).  Runs before this process has made any HIP call:
+    the parent only waits and relays, it never initialises the GPU and never exec()s."""
+    have = torch.cuda.device_count()                     # (counting devices does not initialise HIP on this image)
+    if have < n and not os.environ.get('SCIPNP_BENCH_SHARE_GPU'):     # (test hook: ranks share GPUs, with SCIPNP_BENCH_BACKEND=gloo)
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) visible', file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SCIPNP_BENCH_SPAWNED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    lines = out0.splitlines()
+    jl = [l for l in lines if l.startswith('{')]
+    for l in lines:
+        if not (jl and l is jl[-1]):
+            print(l, file=sys.stderr)                    # RCCL banners etc.
+    if any(rcs) or not jl:
+        print(f'bench.py: rank exit codes {rcs}', file=sys.stderr)
+        return max([abs(c) for c in rcs] + [1])
+    print(jl[-1], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def load_weights():
     from adaptivepnp_sci_amd.nets import FFDNet
     net = FFDNet()
@@ -61,28 +121,48 @@ def _usable_cpus():
     return usable_cpus()
 
 
-def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosaic=None, gpu_psnr=None):
-    """The CPU oracle on the SAME cube and schedule, bounded to ~budget_s of CPU work.  Thread count:
-    the fastest of a short calibration over {8,16,32,64} <= usable CPUs (PyTorch-CPU per-frame
-    convolutions do not scale to hundreds of threads)."""
+@contextlib.contextmanager
+def conv_precision(p):
+    old = os.environ.get('SCIPNP_CONV_PRECISION')
+    os.environ['SCIPNP_CONV_PRECISION'] = p
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop('SCIPNP_CONV_PRECISION', None)
+        else:
+            os.environ['SCIPNP_CONV_PRECISION'] = old
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+class Trace:
+    """solver.ITERATE_HOOK target: keeps every reported iterate on the host"""
+
+    def __init__(self):
+        self.it = []
+
+    def __call__(self, k, mosaic):
+        self.it.append(mosaic.cpu().numpy())
+
+
+def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu=None):
+    """The CPU oracle on the SAME cube and schedule, bounded to ~budget_s of CPU work per run, two runs (the faster one is
+    `value`; both are listed).  Threads = the container's CPU quota (what this process can really run), the intra-op
+    pool pinned to it.  `gpu`: {precision: (mosaic, psnr list)} of the timed GPU runs for the full-size parity record."""
     from oracle import nets as ON
     from oracle import solver as OS
     onet = ON.OracleFFDNet()
     onet.load_state_dict(sd)
     onet.eval()
     usable = _usable_cpus()
-    frame = torch.rand(1, 3, H, W)
-    sig = torch.full((1, 1, 1, 1), SIGMA)
-    best = (1e9, 1)
+    cores = max(1, min(usable, 64))
+    torch.set_num_threads(cores)
     with torch.no_grad():
-        for n in [c for c in (8, 16, 32, 64) if c <= usable] or [usable]:
-            torch.set_num_threads(n)
-            onet(frame, sig)
-            t0 = time.perf_counter()
-            onet(frame, sig)
-            best = min(best, (time.perf_counter() - t0, n))
-        cores = best[1]
-        torch.set_num_threads(cores)
+        OS.two_stage_admm(y, Phi, 'ffdnet_color', [1], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)   # page in
         t0 = time.perf_counter()
         OS.two_stage_admm(y, Phi, 'ffdnet_color', [1], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
         t1 = time.perf_counter() - t0
@@ -92,51 +172,408 @@ def cpu_baseline(y, Phi, warm, orig, sd, budget_s=20.0, gpu_iters=None, gpu_mosa
         check = gpu_iters is not None and gpu_iters * t1 <= 2.5 * budget_s
         if check:
             iters = gpu_iters
-        t0 = time.perf_counter()
-        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
-        dt = time.perf_counter() - t0
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [iters], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
+            runs.append(time.perf_counter() - t0)
+            if runs[-1] > 1.5 * budget_s:
+                break
+    dt = min(runs)
     try:
         cpu_model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
     except Exception:
         cpu_model = 'unknown'
     out = dict(value=iters / dt, unit='ADMM iterations/s', cores=cores, kind='port', cpu_model=cpu_model,
+               runs_iters_per_s=[iters / r for r in runs],
                sample=f'{iters} two-stage ADMM+FFDNet iteration(s) of the same 512x512x8 cube (sigma 25/255, TV warm '
-                      f'start), PyTorch-CPU oracle, {cores} of {usable} usable CPU threads, {dt:.1f} s')
+                      f'start), PyTorch-CPU oracle, {cores} threads = the CPU quota of this container ({usable}), '
+                      f'best of {len(runs)} runs ({", ".join(f"{r:.1f} s" for r in runs)})')
     # one iteration on ONE thread (SURVEY 8d asks for both figures), if it fits the sample budget
-    per_iter = dt / iters
-    if per_iter * cores * 0.6 <= 15.0:
+    if (dt / iters) * cores * 0.6 <= 15.0:
         torch.set_num_threads(1)
         with torch.no_grad():
             t0 = time.perf_counter()
             OS.two_stage_admm(y, Phi, 'ffdnet_color', [1], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet)
         out['value_1_thread'] = 1.0 / (time.perf_counter() - t0)
         torch.set_num_threads(cores)
-    if check:
+    if check and gpu:
         ref = o['x_bayer']
-        out['parity'] = {'iterations': iters,
-                         'rel_l2_final_iterate': float(np.linalg.norm(gpu_mosaic - ref) / np.linalg.norm(ref)),
-                         'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_psnr) - np.array(o['psnr_all'])))),
-                         'gates': {'rel_l2': 1e-5, 'psnr_db': 1e-4}}
+        out['parity'] = {'iterations': iters, 'gates': {'rel_l2': 1e-5, 'psnr_db': 1e-4}}
+        for prec, (mosaic, psnr) in gpu.items():
+            out['parity'][prec] = {'rel_l2_final_iterate': rel_l2(mosaic, ref),
+                                   'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(psnr) - np.array(o['psnr_all']))))}
     return out
 
 
+# ------------------------------------------------------------------------------------------------ PMC traffic (child runs)
+def pmc_traffic(timeout_s=150):
+    """HBM bytes per launch of the body-layer convolutions and the projection, measured by rocprofv3 PMC passes run as
+    CHILD processes of this bench invocation on tools/pmc_probe.py (same kernels, same shapes, same cube): FETCH_SIZE and
+    WRITE_SIZE in separate passes with --kernel-trace only, FETCH_SIZE doubled for gfx950 (MI355X_MICROARCH.md, HBM).
+    Returns ({kernel tag: bytes}, source string) or (None, reason)."""
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on PATH'
+    import csv
+    import glob
+    tmp = tempfile.mkdtemp(prefix='scipnp_pmc_', dir='/tmp')
+    vals = {}
+    try:
+        for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, name)
+            r = subprocess.run([exe, '--kernel-trace', '--pmc', name, '--output-format', 'csv', '-d', d, '--',
+                                sys.executable, os.path.join(ROOT, 'tools', 'pmc_probe.py')],
+                               cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f'rocprofv3 --pmc {name} exited {r.returncode}: {r.stdout[-300:]}'
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row['Counter_Name'] == name:
+                        vals.setdefault(row['Kernel_Name'], {}).setdefault(name, []).append(float(row['Counter_Value']))
+    except Exception as e:                                  # noqa: BLE001 -- best effort, the bench line says what happened
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, dct in vals.items():
+        if 'FETCH_SIZE' in dct and 'WRITE_SIZE' in dct:
+            fetch = float(np.mean(dct['FETCH_SIZE'])) * 1024 * 2         # KiB; the counter sees half of a wide streaming read
+            wr = float(np.mean(dct['WRITE_SIZE'])) * 1024
+            out[k.replace('scipnp::', '').replace('void ', '')] = fetch + wr
+    return out, 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of this run, tools/pmc_probe.py)'
+
+
+def _pick(traffic, needle):
+    if not traffic:
+        return None
+    for k, v in traffic.items():
+        if needle in k:
+            return v
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ the timed runs
+def time_precision(prec, args, ctx):
+    """W warm-up steps, K timed steps of AdmmRun.step with the FFDNet convolutions in `prec`, bracketed by
+    barrier + synchronize; MAX over ranks.  Returns the record and the run (state after W + K iterations)."""
+    from adaptivepnp_sci_amd import shard
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    dist, rank, world, dev, cdev = ctx['dist'], ctx['rank'], ctx['world'], ctx['dev'], ctx['coll_dev']
+    run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'], model=ctx['net'],
+                  conv_precision=prec)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # device pre-heat (untimed set-up, like the TV warm start): after the light TV phase the part needs ~25 ms of
+    # matrix load to reach its steady clocks (tools/probes/step_times_probe.py); a production reconstruction lives in the
+    # steady state, a --steps 5 run would measure the ramp.  The denoiser pass on a zeroed input, solver state untouched.
+    (run.eng.in_c8s if run.eng.precision == 'f16x3' else run.eng.in_c8).zero_()
+    for _ in range(args.preheat):
+        run.eng.forward()
+    for _ in range(args.warmup):
+        run.step(SIGMA)
+    if dist is not None:
+        # untimed: the first gather sets up RCCL's point-to-point connections over xGMI
+        shard.gather_units({rank: run.result_mosaic()}, world, (H, W, B), cdev, dst=0)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # every rank's RCCL banner (NCCL_DEBUG=VERSION) leaves its C stdout buffer now
+    events, phi_events = [], []
+    run.profile_events, run.phi_events = events, phi_events
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step(SIGMA)
+    mosaic = run.result_mosaic()
+    n_gathered = 1
+    if dist is not None:                              # unit `rank` lives on this rank; ONE RCCL gather for the job
+        gathered = shard.gather_units({rank: mosaic}, world, (H, W, B), cdev, dst=0)
+        assert rank != 0 or len(gathered) == world
+        n_gathered = len(gathered) if rank == 0 else 0
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    run.profile_events = run.phi_events = None
+    body_launch_s = float(np.mean([a.elapsed_time(b) for a, b in events])) / 1e3 / (NB - 2)
+    phi_s = float(np.median([a.elapsed_time(b) for a, b in phi_events])) / 1e3
+    psnr = run.psnr_all()
+    rec = {'dtype': prec, 'value': world * args.steps / dt, 'unit': 'ADMM iterations/s', 'ms_per_step': 1e3 * dt / args.steps,
+           'frame_iterations_per_s': world * args.steps / dt * B, 'body_launch_s': body_launch_s, 'phi_s': phi_s,
+           'units_gathered': n_gathered,
+           'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None]}
+    return rec, run, mosaic, psnr
+
+
+def roofline_record(prec, body_launch_s, traffic, traffic_src, measured):
+    achieved = BODY_FLOP_PER_LAUNCH / body_launch_s
+    if prec == 'f16x3':
+        peak, exec_ratio = PEAK_F16_MFMA, SPLIT_EXEC_PER_ALGO
+        kname = ('conv3x3_c8s_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256; error-compensated '
+                 'split-fp16: 3 exact fp16 products per fp32 product on v_mfma_f32_32x32x16_f16, fp32 accumulate)')
+        peak_meas = measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs')
+        tr = _pick(traffic, 'conv3x3_c8s_kernel<3, 0')
+    else:
+        peak, exec_ratio = PEAK_FP32_MFMA, 1.0
+        kname = 'conv3x3_c8_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256, v_mfma_f32_32x32x2_f32)'
+        peak_meas = measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
+        tr = _pick(traffic, 'conv3x3_c8_kernel<3, 0')
+    src = traffic_src
+    if tr is None:                                   # no live PMC pass: the committed profile, named
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tpath):
+            tr = json.load(open(tpath)).get(prec, {}).get('hbm_bytes_per_launch')
+            src = f'committed profile profiles/pmc_traffic.json (live PMC pass unavailable: {traffic_src})'
+    return {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+            'traffic': tr, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+            'algorithmic_bytes_per_launch': BODY_BYTES_PER_LAUNCH, 'kernel': kname,
+            'flop_per_launch': BODY_FLOP_PER_LAUNCH, 'avg_launch_ms': body_launch_s * 1e3,
+            'denoiser_flop_per_iter': FFDNET_FLOP_PER_ITER,
+            # `achieved` counts ALGORITHMIC fp32-conv FLOPs; the split kernel's matrix pipes execute 3.11x that in fp16 products
+            'mfma_flop_executed_over_algorithmic': exec_ratio,
+            'matrix_pipe_frac_of_peak': achieved * exec_ratio / peak,
+            'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
+            # the ceiling MEASURED with a register-resident MFMA loop on random operands (no memory traffic)
+            'peak_measured': peak_meas,
+            'matrix_pipe_frac_of_measured_peak': (achieved / 1e12 * exec_ratio / peak_meas) if peak_meas else None}
+
+
+def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
+    from adaptivepnp_sci_amd import ops
+    phi_bytes = 16.0 * H * W * B + 8.0 * H * W        # SURVEY 8(d): theta, b, Phi read + x written (4 E) + y, Phi_sum (2 HW)
+    # the same projection kernel on a state large enough to leave the launch-latency regime (8 frames of 2048x2048, the
+    # same B = 8 register path: 570 MB algorithmic per launch), 20 launches between one event pair
+    Bl, Hl = 8, 2048
+    th = torch.rand(Bl, 4, Hl // 2, Hl // 2, device=dev)
+    bb, ph = torch.rand_like(th), (torch.rand_like(th) > 0.5).float()
+    yy, ps = torch.rand(4, Hl // 2, Hl // 2, device=dev) * Bl / 2, torch.full((4, Hl // 2, Hl // 2), Bl / 2.0, device=dev)
+    xo = torch.empty_like(th)
+    for _ in range(3):
+        ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
+    e1.record()
+    torch.cuda.synchronize()
+    lb = 16.0 * Hl * Hl * Bl + 8.0 * Hl * Hl
+    ls = e0.elapsed_time(e1) / 20 * 1e-3
+    phi_large = {'cube': [Hl, Hl, Bl], 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'achieved': lb / ls / 1e9,
+                 'unit': 'GB/s', 'frac': lb / ls / PEAK_HBM}
+    del th, bb, ph, yy, ps, xo
+    # and on the bench's own 512 x 512 x 8 state, 50 launches between one event pair (no per-launch event overhead)
+    xs = torch.empty_like(run.x)
+    for _ in range(3):
+        ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
+    e1.record()
+    torch.cuda.synchronize()
+    b2b = e0.elapsed_time(e1) / 50 * 1e-3
+    return {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
+            'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
+            'achieved': phi_bytes / phi_s / 1e9, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': phi_bytes / phi_s / PEAK_HBM,
+            'traffic': _pick(traffic, 'pm_project_kernel'), 'traffic_source': traffic_src,
+            'peak_measured': measured.get('hbm_read_GBs'), 'large_state': phi_large,
+            'back_to_back': {'launches': 50, 'launch_us': b2b * 1e6, 'achieved': phi_bytes / b2b / 1e9, 'frac': phi_bytes / b2b / PEAK_HBM},
+            'note': 'event pair around one ~10 us launch includes ~2-3 us of event/launch overhead; rocprofv3 kernel time is in profiles/'}
+
+
+# ------------------------------------------------------------------------------------------------ the other BASELINE configs
+def _ms_per_iter(run, sig, n, warm=2):
+    for _ in range(warm):
+        run.step(sig)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run.step(sig)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def fastdvd_flop_per_iter(Hh, Ww, Bf):
+    """algorithmic FLOPs of one FastDVDnet pass over Bf frames (packages/fastdvdnet/models.py:146-253): per frame one
+    stage-2 DenBlock and, with the stage-1 outputs shared between neighbouring windows, one stage-1 DenBlock per frame
+    (B + 2 - 2 duplicates of the circular window are de-duplicated by the engine: B stage-1 blocks for B frames)."""
+    px = Hh * Ww
+
+    def conv(ci, co, p, groups=1):
+        return 2.0 * 9 * ci * co / groups * p
+    blk = (conv(3 * 4, 3 * 30, px, 3) + conv(90, 32, px)                       # inc: grouped (3) + 90 -> 32
+           + conv(32, 64, px / 4) + 2 * conv(64, 64, px / 4)                   # downc0
+           + conv(64, 128, px / 16) + 2 * conv(128, 128, px / 16)              # downc1
+           + 2 * conv(128, 128, px / 16) + conv(128, 256, px / 16)             # upc2 (+ PixelShuffle)
+           + 2 * conv(64, 64, px / 4) + conv(64, 128, px / 4)                  # upc1 (+ PixelShuffle)
+           + conv(32, 32, px) + conv(32, 3, px))                               # outc
+    return 2 * Bf * blk
+
+
+def config_records(ffd_sd, budget_s=60.0):
+    """BASELINE configs other than the headline, one GPU: ms per iteration, the dominant kernel with its algorithmic
+    fraction, and parity against the CPU oracle on the same seeded inputs for <= 3 iterations (free-running from the
+    same warm start; gates 1e-5 rel-L2 per iterate).  Bounded: an oracle leg is shortened when it would not fit."""
+    from adaptivepnp_sci_amd import solver as S
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    from oracle import nets as ON
+    from oracle import solver as OS
+    t_start = time.perf_counter()
+    out = {}
+
+    def gpu_iterates(fn):
+        tr = Trace()
+        S.ITERATE_HOOK = tr
+        try:
+            fn()
+        finally:
+            S.ITERATE_HOOK = None
+        return tr.it
+
+    # ---- configs[0]: ADMM-TV warm start, 256x256x8 gray simulated cube, 50 iterations
+    y, Phi, orig = synth.make_problem(256, 256, 8, seed=0)
+    run = AdmmRun(y, Phi, 'tv', False, X_orig=orig)
+    ms = _ms_per_iter(run, 0, 50, 5)
+    E = 256 * 256 * 8
+    tv_bytes = (16.0 * E + 8 * 256 * 256) + 8.0 * E + 20.0 * E          # projection + fused Chambolle (v in, out) + dual update
+    its = gpu_iterates(lambda: S.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [3], False, [0], X_orig=orig,
+                                                                 logf=io.StringIO()))
+    o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [3], [0], X_orig=orig)
+    out['admm_tv_256'] = {
+        'workload': 'configs[0]: ADMM-TV (one-stage, Chambolle 5 inner iterations), 256x256x8, per-iteration PSNR on device',
+        'dtype': 'f32', 'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms,
+        'dominant_kernel': 'tv_plane_kernel (all 5 Chambolle iterations of a 128x128 plane in one workgroup)',
+        'bound': 'hbm (launch/VALU-latency limited at this size)', 'algorithmic_bytes_per_iteration': tv_bytes,
+        'achieved_GBs': tv_bytes / (ms * 1e-3) / 1e9, 'frac': tv_bytes / (ms * 1e-3) / PEAK_HBM,
+        'parity': {'iterations': 3, 'max_rel_l2_per_iterate': max(rel_l2(its[k], o['x_iterates'][k]) for k in range(3)), 'gate': 1e-5}}
+
+    # ---- configs[2]: two-stage ADMM + FastDVDnet, 512x512x8 (synthetic weights: model.pth is not in the reference snapshot)
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=1)
+    tv = AdmmRun(y, Phi, 'tv', False)
+    for _ in range(10):
+        tv.step(0)
+    warm = tv.result_mosaic().cpu().numpy()
+    fnet = torch.nn.DataParallel(synth.synth_fastdvdnet(1))
+    flop = fastdvd_flop_per_iter(512, 512, 8)
+    rec = {'workload': 'configs[2]: two-stage ADMM + FastDVDnet (5-frame window), 512x512x8, rho 0.55, sigma 8/255; synthetic '
+                       'weights (model.pth absent from the reference snapshot)',
+           'denoiser_flop_per_iteration': flop, 'dominant_kernel': 'conv3x3 c8/c8s kernels of the two DenBlock stages (16 blocks of 17 layers)'}
+    gpu_it = {}
+    for prec in PRECISIONS:
+        run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet, conv_precision=prec)
+        ms = _ms_per_iter(run, 8 / 255, 5, 2)
+        peak = PEAK_FP32_MFMA if prec == 'f32' else PEAK_F16_MFMA
+        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'achieved_TFLOPs': flop / (ms * 1e-3) / 1e12,
+                     'peak_TFLOPs': peak / 1e12, 'frac': flop / (ms * 1e-3) / peak}
+        with conv_precision(prec):
+            gpu_it[prec] = gpu_iterates(lambda: S.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [2], False, [8 / 255],
+                                                                             x0_bayer=warm, X_orig=orig, model_denoise=fnet,
+                                                                             logf=io.StringIO()))
+    t0 = time.perf_counter()
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [1], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=fnet)
+    t1 = time.perf_counter() - t0
+    n_or = 1
+    if t1 * 2 < 0.5 * budget_s:
+        o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [2], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=fnet)
+        n_or = 2
+    rec['parity'] = {'iterations': n_or, 'gate': 1e-5, 'oracle_s_per_iteration': t1}
+    for prec in PRECISIONS:
+        rec['parity'][prec] = {'max_rel_l2_per_iterate': max(rel_l2(gpu_it[prec][k], o['theta_iterates'][k]) for k in range(n_or))}
+    out['fastdvd_512'] = rec
+
+    # ---- configs[4], one 256x256x16 tile with the online finetune (per-tile model copy), FFDNet
+    y, Phi, orig = synth.make_problem(256, 256, 16, seed=3)
+    tv = AdmmRun(y, Phi, 'tv', False)
+    for _ in range(10):
+        tv.step(0)
+    warm = tv.result_mosaic().cpu().numpy()
+    kw = dict(lr_=2e-6, inital_iter=1, interval_iter=2, update_=True, update_per_iter=1)
+    tile_flop = FFDNET_FLOP_PER_ITER * (256 * 256 * 16) / (H * W * B)
+    rec = {'workload': 'configs[4]: one 256x256 patch of the 1024x1024x16 colour cube (16 frames), two-stage ADMM + FFDNet, '
+                       'online finetune (Adam on the measurement loss) firing at the gated iterations; 16 such tiles shard '
+                       'over the ranks (shard.reconstruct_tiled)',
+           'denoiser_flop_per_iteration': tile_flop,
+           'dominant_kernel': 'FFDNet body conv3x3 (forward); conv3x3 weight-gradient + backward-data kernels in a finetune event'}
+    gpu_it = {}
+    for prec in PRECISIONS:
+        net = FFDNet()
+        net.load_state_dict(ffd_sd)
+        run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net, conv_precision=prec)
+        ms = _ms_per_iter(run, SIGMA, 20, 3)
+        peak = PEAK_FP32_MFMA if prec == 'f32' else PEAK_F16_MFMA
+        # iteration WITH a finetune event (2 Adam steps, the reference driver's update_per_iter), steady state
+        net2 = FFDNet()
+        net2.load_state_dict(ffd_sd)
+        run2 = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net2, update_=True, lr_=2e-6,
+                       update_per_iter=2, inital_iter=0, interval_iter=1, conv_precision=prec)
+        run2.step(SIGMA)
+        run2.step(SIGMA)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run2.step(SIGMA)
+        torch.cuda.synchronize()
+        ev = (time.perf_counter() - t0) / 3 * 1e3
+        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'achieved_TFLOPs': tile_flop / (ms * 1e-3) / 1e12,
+                     'peak_TFLOPs': peak / 1e12, 'frac': tile_flop / (ms * 1e-3) / peak,
+                     'ms_per_iteration_with_finetune_event': ev}
+        net3 = FFDNet()
+        net3.load_state_dict(ffd_sd)
+        with conv_precision(prec):
+            gpu_it[prec] = gpu_iterates(lambda: S.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [3], False, [SIGMA],
+                                                                             x0_bayer=warm, X_orig=orig, model_denoise=net3,
+                                                                             logf=io.StringIO(), **kw))
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffd_sd)
+    onet.eval()
+    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [3], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                          lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=1)
+    rec['parity'] = {'iterations': 3, 'gate': 1e-5, 'finetune_event_at_iteration': 2}
+    for prec in PRECISIONS:
+        rec['parity'][prec] = {'max_rel_l2_per_iterate': max(rel_l2(gpu_it[prec][k], o['theta_iterates'][k]) for k in range(3))}
+    out['tile_256x256x16_finetune'] = rec
+    out['seconds'] = time.perf_counter() - t_start
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=25)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the records of the other BASELINE configurations')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes (roofline.traffic)')
+    ap.add_argument('--no-fast-path', action='store_true', help='time only the fp32 headline (profiling runs)')
     ap.add_argument('--preheat', type=int, default=40, help='untimed denoiser passes before the warm-up steps (device clocks)')
-    ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU-oracle work for cpu_baseline')
+    ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU-oracle work per cpu_baseline run')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))           # nothing above touched the GPU
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(env_world or 1)
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU', file=sys.stderr)
+        sys.exit(2)
 
     # PyTorch sizes its intra-op pool by the visible cores (256 on the MI355X boxes) while the container's CPU quota is 16:
     # any CPU-side tensor op above the grain size wakes the pool, whose idle spinning exhausts the quota and gets this
-    # (launching) thread throttled for tens of milliseconds -- keep the pool inside the quota
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cpus() // max(1, world))))   # ranks share the quota
+    # (launching) thread throttled for tens of milliseconds -- keep the pool inside the quota (ranks share it)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cpus() // max(1, world))))
     dist = None
     if world > 1 or os.environ.get('SCIPNP_BENCH_FORCE_DIST'):       # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
@@ -146,7 +583,13 @@ def main():
         os.environ.setdefault('WORLD_SIZE', str(world))
         local_rank %= max(1, torch.cuda.device_count())     # (a launcher may already have masked the devices per rank)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # SCIPNP_BENCH_BACKEND=gloo is a test hook: several ranks on ONE GPU (RCCL refuses two ranks per device), the
+        # collectives then run on host copies -- exercises the launcher and the rank plumbing on a 1-GPU box
+        backend = os.environ.get('SCIPNP_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -161,165 +604,90 @@ def main():
         tv.step(0)
     warm = tv.result_mosaic()
     y_d, Phi_d, orig_d = (torch.from_numpy(a).to(dev) for a in (y, Phi, orig))
-    run = AdmmRun(y_d, Phi_d, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig_d, model=net)
+    coll_dev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
+    ctx = dict(dist=dist, rank=rank, world=world, dev=dev, coll_dev=coll_dev, y_d=y_d, Phi_d=Phi_d, orig_d=orig_d, warm=warm, net=net)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # device pre-heat (untimed set-up, like the TV warm start above): after the light TV phase the part needs ~25 ms of
-    # matrix load to reach its steady clocks (tools/probes/step_times_probe.py: 2.83, 2.89, 2.66, 2.56, 2.46, 2.43, 2.38, ...
-    # 2.27 ms for the first twelve iterations); a production reconstruction lives in the steady state, a --steps 5 run would
-    # measure the ramp.  The denoiser pass on a zeroed input, ~100 ms, solver state untouched.
-    (run.eng.in_c8s if run.eng.precision == 'f16x3' else run.eng.in_c8).zero_()
-    for _ in range(args.preheat):
-        run.eng.forward()
-    for _ in range(args.warmup):
-        run.step(SIGMA)
-    from adaptivepnp_sci_amd import shard
-    if dist is not None:
-        # untimed: the first gather sets up RCCL's point-to-point connections over xGMI
-        shard.gather_units({rank: run.result_mosaic()}, world, (H, W, B), dev, dst=0)
-        import ctypes
-        ctypes.CDLL(None).fflush(None)          # every rank's RCCL banner (NCCL_DEBUG=VERSION) leaves its C stdout buffer now
-    events = []
-    run.profile_events = events
-    phi_events = []
-    run.phi_events = phi_events
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run.step(SIGMA)
-    mosaic = run.result_mosaic()
-    if dist is not None:                              # unit `rank` lives on this rank; ONE RCCL gather for the job
-        gathered = shard.gather_units({rank: mosaic}, world, (H, W, B), dev, dst=0)
-        assert rank != 0 or len(gathered) == world
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):                           # measured in separate rocprofv3 --pmc passes, see the file's note
-        traffic = json.load(open(tpath)).get(run.eng.precision, {}).get('hbm_bytes_per_launch')
-    measured = {}
-    mpath = os.path.join(ROOT, 'profiles', 'measured_peaks.json')
-    if os.path.exists(mpath):                          # tools/peaks_bench.py on an MI355X of the pool: register-resident MFMA loop
-        measured = json.load(open(mpath))              # on random operands, HBM read stream
-    # the same projection kernel on a state large enough to leave the launch-latency regime (8 frames of 2048x2048, the
-    # same B = 8 register path: 570 MB algorithmic per launch), 20 launches between one event pair
-    phi_large = None
-    if rank == 0:
-        from adaptivepnp_sci_amd import ops
-        Bl, Hl = 8, 2048
-        th = torch.rand(Bl, 4, Hl // 2, Hl // 2, device=dev)
-        bb, ph = torch.rand_like(th), (torch.rand_like(th) > 0.5).float()
-        yy, ps = torch.rand(4, Hl // 2, Hl // 2, device=dev) * Bl / 2, torch.full((4, Hl // 2, Hl // 2), Bl / 2.0, device=dev)
-        xo = torch.empty_like(th)
-        for _ in range(3):
-            ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
-        e1.record()
-        torch.cuda.synchronize()
-        lb = 16.0 * Hl * Hl * Bl + 8.0 * Hl * Hl
-        ls = e0.elapsed_time(e1) / 20 * 1e-3
-        phi_large = {'cube': [Hl, Hl, Bl], 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'achieved': lb / ls / 1e9,
-                     'unit': 'GB/s', 'frac': lb / ls / 8e12}
-        del th, bb, ph, yy, ps, xo
-        # and on the bench's own 512 x 512 x 8 state, 50 launches between one event pair (no per-launch event overhead)
-        xs = torch.empty_like(run.x)
-        for _ in range(3):
-            ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1.0, 1.0, out=xs)
-        e1.record()
-        torch.cuda.synchronize()
-        phi_b2b_s = e0.elapsed_time(e1) / 50 * 1e-3
-        del xs
-    body_ms = [a.elapsed_time(b) for a, b in events]
-    body_launch_s = float(np.mean(body_ms)) / 1e3 / (NB - 2)
-    psnr = run.psnr_all()
-    phi_s = float(np.median([a.elapsed_time(b) for a, b in phi_events])) / 1e3
-    phi_bytes = 16.0 * H * W * B + 8.0 * H * W        # theta, b, Phi read + x written (4 E) + y, Phi_sum (2 HW)
-    precision = run.eng.precision
-    if rank == 0:
-        iters_per_s = world * args.steps / dt
-        achieved = BODY_FLOP_PER_LAUNCH / body_launch_s
-        if precision == 'f16x3':
-            peak, kname, dtype = PEAK_F16_MFMA, ('conv3x3_c8s_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of '
-                                                 '256x256; error-compensated split-fp16: 3 exact fp16 products per fp32 '
-                                                 'product on v_mfma_f32_32x32x16_f16, fp32 accumulate)'), 'f16x3'
+    recs, gpu_out, last_run = {}, {}, None
+    for prec in (PRECISIONS[:1] if args.no_fast_path else PRECISIONS):
+        rec, run, mosaic, psnr = time_precision(prec, args, ctx)
+        recs[prec] = rec
+        gpu_out[prec] = (mosaic.cpu().numpy(), psnr)
+        if prec == 'f32':
+            last_run = run
         else:
-            peak, kname, dtype = PEAK_FP32_MFMA, ('conv3x3_c8_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of '
-                                                  '256x256, v_mfma_f32_32x32x2_f32)'), 'f32'
-        peak_meas = measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs' if precision == 'f16x3'
-                                 else 'mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
+            del run
+    if rank == 0:
+        measured = {}
+        mpath = os.path.join(ROOT, 'profiles', 'measured_peaks.json')
+        if os.path.exists(mpath):                          # tools/peaks_bench.py on an MI355X of the pool
+            measured = json.load(open(mpath))
+        traffic, traffic_src = (None, 'skipped (--no-pmc or N > 1)')
+        if world == 1 and not args.no_pmc:
+            traffic, traffic_src = pmc_traffic()
+        head = recs['f32']
         line = {
-            'metric': 'admm_iters_per_s', 'value': iters_per_s, 'unit': 'ADMM iterations/s',
-            'frames_per_s': iters_per_s * B,
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype,
+            'metric': 'admm_iters_per_s', 'value': head['value'], 'unit': 'ADMM iterations/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': f'synthetic (seeded moving-sinusoid cube, Bernoulli(0.5) mask, noise-free y); weights: {wdesc}',
             'config': {'workload': 'two-stage ADMM + FFDNet-color, one 512x512x8 Bayer cube per GPU, Malvar demosaic, '
                                    'sigma=25/255, TV warm start, per-iteration PSNR on device', 'cube': [H, W, B],
                        'parallelism': f'{world} independent cube(s), one per GPU, one RCCL gather at the end'},
-            'roofline': {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/pmc_traffic.json)',
-                         'algorithmic_bytes_per_launch': 2.0 * B * NC * (H // 2) * (W // 2) * 4, 'kernel': kname,
-                         'flop_per_launch': BODY_FLOP_PER_LAUNCH, 'avg_launch_ms': body_launch_s * 1e3,
-                         'denoiser_flop_per_iter': FFDNET_FLOP_PER_ITER,
-                         # honest bookkeeping for the split kernel: `achieved` counts ALGORITHMIC fp32-conv FLOPs; the
-                         # matrix pipes execute 3.11x that in fp16 products
-                         'mfma_flop_executed_over_algorithmic': SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0,
-                         'matrix_pipe_frac_of_peak': achieved * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) / peak,
-                         'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
-                         # the ceiling MEASURED with a register-resident MFMA loop on random operands (no memory traffic):
-                         # what the part sustains under its own clock management, vs the 2.5 PFLOP/s vendor figure
-                         'peak_measured': peak_meas,
-                         'matrix_pipe_frac_of_measured_peak': (
-                             achieved / 1e12 * (SPLIT_EXEC_PER_ALGO if precision == 'f16x3' else 1.0) / peak_meas) if peak_meas else None},
-            # the Phi / Phi^T Phi projection step (north_star: HBM fraction), one launch per iteration, HIP events
-            'phi_step': {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
-                         'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': phi_s * 1e6,
-                         'achieved': phi_bytes / phi_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': phi_bytes / phi_s / 8e12,
-                         'peak_measured': measured.get('hbm_read_GBs'), 'large_state': phi_large,
-                         'back_to_back': {'launches': 50, 'launch_us': phi_b2b_s * 1e6, 'achieved': phi_bytes / phi_b2b_s / 1e9,
-                                          'frac': phi_bytes / phi_b2b_s / 8e12},
-                         'note': 'event pair around one ~10 us launch includes ~2-3 us of event/launch overhead; rocprofv3 '
-                                 'kernel time is in profiles/'},
+            'ranks': world, 'units_gathered_on_rank0': head['units_gathered'],
+            'collective': ('none (single process)' if dist is None else
+                           'RCCL gather (torch.distributed backend nccl)' if dist.get_backend() == 'nccl' else
+                           f'{dist.get_backend()} gather on host copies (SCIPNP_BENCH_BACKEND test hook)'),
+            # frame-iterations/s = ADMM iterations/s x 8 frames per cube; `frames_per_s` (reconstructed frames/s
+            # of a whole solver call with the reference driver's 25-iteration schedule) is filled in below at N = 1
+            'frame_iterations_per_s': head['frame_iterations_per_s'],
+            'frames_per_s': None,
+            'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured),
+            'phi_step': phi_record(last_run, head['phi_s'], traffic, traffic_src, measured, dev),
             'preheat': f'{args.preheat} untimed denoiser passes before the warm-up steps (clock ramp after the TV phase)',
-            'psnr_db_first_last': [psnr[args.warmup] if len(psnr) > args.warmup else None, psnr[-1] if psnr else None],
+            'psnr_db_first_last': head['psnr_db_first_last'],
         }
+        if 'f16x3' in recs:
+            fp = recs['f16x3']
+            line['fast_path'] = {
+                'dtype': 'f16x3', 'note': 'library default (SCIPNP_CONV_PRECISION=f16x3): every fp32 operand carried as two fp16 '
+                                          'numbers (22 significant bits), 3 of the 4 partial products, fp32 accumulation',
+                'value': fp['value'], 'unit': 'ADMM iterations/s', 'ms_per_step': fp['ms_per_step'],
+                'frame_iterations_per_s': fp['frame_iterations_per_s'], 'speedup_over_f32': fp['value'] / head['value'],
+                'roofline': roofline_record('f16x3', fp['body_launch_s'], traffic, traffic_src, measured),
+                'psnr_db_first_last': fp['psnr_db_first_last'],
+                'parity_vs_f32_path': {'rel_l2_final_iterate': rel_l2(gpu_out['f16x3'][0], gpu_out['f32'][0]),
+                                       'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_out['f16x3'][1]) -
+                                                                                   np.array(gpu_out['f32'][1]))))}}
         if world == 1:
             # SURVEY 8(d)'s other reading of the metric: whole solver calls with the reference driver's schedule
             # (sigma [25,12,6]/255 x [15,6,4] iterations), inputs as NumPy arrays, outputs read back to the host
-            import io
             from adaptivepnp_sci_amd.solver import twoStageAdmm_denoise_bayer
             kw = dict(denoiser='ffdnet_color', iter_max=[15, 6, 4], sigma=[25 / 255, 12 / 255, 6 / 255], x0_bayer=warm,
                       X_orig=orig, model_denoise=net, logf=io.StringIO())
-            twoStageAdmm_denoise_bayer(y, Phi, **kw)
-            ts = []
-            for _ in range(3):
-                torch.cuda.synchronize(); tr0 = time.perf_counter()
-                twoStageAdmm_denoise_bayer(y, Phi, **kw)
-                ts.append(time.perf_counter() - tr0)
-            line['whole_reconstruction'] = {'schedule': 'two-stage ADMM + FFDNet-color, 25 iterations ([15,6,4] at sigma [25,12,6]/255), '
-                                                        'H2D of y/Phi and D2H of the RGB cube + mosaic included, no finetune',
-                                            'ms': 1e3 * min(ts), 'reconstructed_frames_per_s': B / min(ts)}
+            whole = {'schedule': 'two-stage ADMM + FFDNet-color, 25 iterations ([15,6,4] at sigma [25,12,6]/255), '
+                                 'H2D of y/Phi and D2H of the RGB cube + mosaic included, no finetune'}
+            for prec in recs:
+                with conv_precision(prec), contextlib.redirect_stdout(io.StringIO()):
+                    twoStageAdmm_denoise_bayer(y, Phi, **kw)
+                    ts = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        tr0 = time.perf_counter()
+                        twoStageAdmm_denoise_bayer(y, Phi, **kw)
+                        ts.append(time.perf_counter() - tr0)
+                whole[prec] = {'ms': 1e3 * min(ts), 'reconstructed_frames_per_s': B / min(ts)}
+            line['whole_reconstruction'] = whole
+            line['frames_per_s'] = whole['f32']['reconstructed_frames_per_s']
+            if 'fast_path' in line:
+                line['fast_path']['frames_per_s'] = whole['f16x3']['reconstructed_frames_per_s']
+        if world == 1 and not args.no_configs:
+            try:
+                line['configs'] = config_records(net.state_dict())
+            except Exception as e:                                   # noqa: BLE001 -- the headline must still be printed
+                line['configs'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and not args.no_cpu_baseline:
-            sd = net.state_dict()
-            line['cpu_baseline'] = cpu_baseline(y, Phi, warm.cpu().numpy(), orig, sd, args.cpu_budget,
-                                                gpu_iters=args.warmup + args.steps, gpu_mosaic=mosaic.cpu().numpy(),
-                                                gpu_psnr=psnr)
+            line['cpu_baseline'] = cpu_baseline(y, Phi, warm.cpu().numpy(), orig, net.state_dict(), args.cpu_budget,
+                                                gpu_iters=args.warmup + args.steps, gpu=gpu_out)
         else:
             line['cpu_baseline'] = None
         # RCCL (NCCL_DEBUG=VERSION on the boxes) writes its banner to the C-level stdout buffer: flush it first so that the
@@ -328,6 +696,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

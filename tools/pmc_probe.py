@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU box, run UNDER rocprofv3 --pmc by bench.py (child process): a few launches of the kernels whose HBM traffic the
+bench line reports, at the bench's shapes -- the FFDNet body-layer convolution (96 -> 96, 8 frames of 256 x 256) in both
+precisions with the real ffdnet_color weights of layer 1, and the plane-major projection on a 512 x 512 x 8 state."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from adaptivepnp_sci_amd import ops  # noqa: E402
+
+n, c, h, w = 8, 96, 256, 256
+g = torch.Generator().manual_seed(0)
+x = torch.rand(n, c, h, w, generator=g).cuda()
+wp = os.path.join(ROOT, 'tests', 'golden', 'ffdnet_color_weights.npz')
+if os.path.exists(wp):
+    z = np.load(wp)
+    wt, b = torch.from_numpy(z['model.2.weight']), torch.from_numpy(z['model.2.bias'])
+else:
+    wt, b = torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.randn(c, generator=g)
+x8 = ops.to_c8(x)
+xs = ops.c8_to_c8s(x8)
+pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
+pks = ops.pack_conv3x3_split(wt, b, Cin=c, Cout=c, device='cuda')
+o8, os_ = torch.empty_like(x8), torch.empty_like(xs)
+B, M, N = 8, 256, 256
+th = torch.rand(B, 4, M, N, device='cuda')
+bb, ph = torch.rand_like(th), (torch.rand_like(th) > 0.5).float()
+yy, ps = torch.rand(4, M, N, device='cuda') * B / 2, torch.full((4, M, N), B / 2.0, device='cuda')
+xo = torch.empty_like(th)
+for _ in range(4):
+    ops.conv3x3_c8(x8, pk, c, relu=True, out=o8)
+    ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_)
+    ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
+torch.cuda.synchronize()
