@@ -490,7 +490,7 @@ def config_records(ffd_sd, budget_s=60.0):
             gpu_it[prec] = gpu_iterates(lambda: S.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [2], False, [8 / 255],
                                                                              x0_bayer=warm, X_orig=orig, model_denoise=fnet,
                                                                              logf=io.StringIO()))
-    onet = torch.nn.DataParallel(ON.synth_fastdvdnet_weights(1))       # the same seeded tensors as synth.synth_fastdvdnet(1)
+    onet = ON.cpu_data_parallel(ON.synth_fastdvdnet_weights(1))       # the same seeded tensors as synth.synth_fastdvdnet(1)
     t0 = time.perf_counter()
     o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [1], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet)
     t1 = time.perf_counter() - t0

@@ -220,3 +220,14 @@ def synth_ddnet_weights(seed=0):
     sd['temp11.fusion.convblock.0.weight'], sd['temp11.fusion.convblock.2.weight'] = f0, f2
     net.load_state_dict(sd)
     return net
+
+
+def cpu_data_parallel(module):
+    """nn.DataParallel exactly as the reference driver wraps its networks (two_stage_ADMM_Online_FastDVD_Warm.py:240-241),
+    but pinned to the CPU: with exactly one visible GPU the constructor moves the wrapped module to cuda:0 and forward()
+    scatters the inputs there, which would turn the oracle into a PyTorch-GPU computation on the MI355X boxes.  The wrapper
+    keeps the `.module` attribute and the `module.`-prefixed state-dict keys the reference code relies on."""
+    dp = nn.DataParallel(module)
+    dp.device_ids = []            # forward(): `if not self.device_ids: return self.module(*inputs, **kwargs)`
+    dp.module.cpu()
+    return dp

@@ -384,9 +384,9 @@ def test_fastdvdnet_forward_vs_reference_golden(precision, monkeypatch):
     """Synthetic seeded weights (the reference's model.pth is not in the snapshot); circular-window edge frames
     0,1,6,7 included (B = 8); golden produced by the reference's fastdvdnet_denoiser_full_tensor_v2."""
     from adaptivepnp_sci_amd import fastdvdnet_denoiser_full_tensor_v2
-    from oracle.nets import synth_fastdvdnet_weights
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
     g = load_gold('fastdvd_forward')
-    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))          # the reference wraps it like this
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))          # the reference wraps it like this
     out = fastdvdnet_denoiser_full_tensor_v2(dev(g['v']), float(g['sigma']), None, None, net, True, 1e-6)
     # 32 fp32-MFMA conv layers + folded BatchNorm vs PyTorch-CPU: summation order / fold rounding only
     assert rel_l2(out.cpu().numpy(), g['out']) < 5e-6
@@ -651,10 +651,10 @@ def test_ddnet_forward_vs_reference_golden(precision, monkeypatch):
     test_ddnet on the same synthetic weights (non-trivial gate scalars)."""
     monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
     from adaptivepnp_sci_amd import test_ddnet as ddnet_plugin
-    from oracle.nets import synth_ddnet_weights
+    from oracle.nets import cpu_data_parallel, synth_ddnet_weights
     from oracle.sci_ops import one_to_three_channel
     g = load_gold('ddnet_forward')
-    net = torch.nn.DataParallel(synth_ddnet_weights(0))
+    net = cpu_data_parallel(synth_ddnet_weights(0))
     out = ddnet_plugin(dev(one_to_three_channel(torch.from_numpy(g['mosaic']))), None, None, net)
     err = rel_l2(out.cpu().numpy(), g['out'])
     assert err <= 2e-6, err
@@ -738,7 +738,7 @@ def test_denoiser_plugins_with_online_update_vs_oracle(ffdnet_state_dict):
     assert rel_l2((w_got - ffdnet_state_dict['model.2.weight']).numpy(), (w_ref - ffdnet_state_dict['model.2.weight']).numpy()) < 2e-2
     # FastDVDnet: same noise for both sides (the reference draws it from the global NumPy RNG)
     fnet = torch.nn.DataParallel(synth.synth_fastdvdnet(0))
-    onet = torch.nn.DataParallel(ON.synth_fastdvdnet_weights(0))
+    onet = ON.cpu_data_parallel(ON.synth_fastdvdnet_weights(0))
     np.random.seed(5)
     out, _ = fastdvdnet_denoiser_full_tensor_v2(dev(x), 8 / 255, dev(yall), dev(Phiall), fnet, True, 2e-6, True, 1)
     np.random.seed(5)

@@ -164,11 +164,11 @@ def test_full_size_properties(solver):
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_two_stage_fastdvdnet_iterates(solver, precision, monkeypatch):
     monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
-    from oracle.nets import synth_fastdvdnet_weights
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
     g = load_gold('fastdvdadmm_64x64x8')
     tr = Trace()
     solver.ITERATE_HOOK = tr
-    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
     res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [4], False, [8 / 255],
                                             x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, show_iqa=True,
                                             demosaic_method='malvar2004', logf=io.StringIO())
@@ -220,12 +220,12 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
     """update_=True, update_times=1, lr 2e-6, 2 Adam steps at k = 2 on 2*v + N(0,(5/255)^2) with the noise from the
     global NumPy RNG seeded like the reference's worker_init_fn(0) (np.random.seed(42), utilspy.py:22-25)."""
     from adaptivepnp_sci_amd import finetune
-    from oracle.nets import synth_fastdvdnet_weights
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
     g = load_gold('fastdvdadmm_64x64x8')
     gf = load_gold('fastdvd_finetune_64x64x8')
     tr = Trace()
     solver.ITERATE_HOOK = tr
-    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     losses = []
     orig_ft = finetune.fastdvdnet_online_finetune
@@ -258,7 +258,7 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
 def test_closed_form_demosaic_branch(solver, ffdnet_state_dict):
     """close_form_demosaic=True (reference :112-118, :175-182, :224-230): tau = 10, rho = 0.55, Malvar only at k = 0,
     clipped on the FFDNet branch and not on the FastDVDnet branch."""
-    from oracle.nets import synth_fastdvdnet_weights
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
     g = load_gold('closedform_64x64x8')
     tr = Trace()
     solver.ITERATE_HOOK = tr
@@ -270,7 +270,7 @@ def test_closed_form_demosaic_branch(solver, ffdnet_state_dict):
     assert rel_l2(res[0], g['rgb_ffdnet']) <= REL_TOL
     assert np.abs(np.array(res[4]) - g['psnr_ffdnet']).max() <= PSNR_TOL
     tr.it.clear()
-    net = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
     res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
                                             x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, logf=io.StringIO(),
                                             close_form_demosaic=True)
@@ -284,9 +284,9 @@ def test_deep_demosaicking_iterates(solver, ffdnet_state_dict, precision, monkey
     """model_demosaic=DDnet (reference :192-194 / :242-244) with both CNN denoisers, per-iterate
     parity against the reference run captured in the golden file (synthetic DDnet / FastDVDnet weights)."""
     monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
-    from oracle.nets import synth_ddnet_weights, synth_fastdvdnet_weights
+    from oracle.nets import cpu_data_parallel, synth_ddnet_weights, synth_fastdvdnet_weights
     g = load_gold('ddnetadmm_64x64x8')
-    dd = torch.nn.DataParallel(synth_ddnet_weights(0))
+    dd = cpu_data_parallel(synth_ddnet_weights(0))
     tr = Trace()
     solver.ITERATE_HOOK = tr
     res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'ffdnet_color', [2, 2], False, [25 / 255, 12 / 255],
@@ -299,7 +299,7 @@ def test_deep_demosaicking_iterates(solver, ffdnet_state_dict, precision, monkey
     assert res[6] is dd
     tr = Trace()
     solver.ITERATE_HOOK = tr
-    fd = torch.nn.DataParallel(synth_fastdvdnet_weights(0))
+    fd = cpu_data_parallel(synth_fastdvdnet_weights(0))
     res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [3], False, [8 / 255],
                                             x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=fd, model_demosaic=dd,
                                             show_iqa=True, logf=io.StringIO())

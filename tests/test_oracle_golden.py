@@ -143,7 +143,7 @@ def test_two_stage_ffdnet_warm_first_iterates_golden(ffdnet_state_dict):
 
 def test_fastdvdnet_forward_golden():
     g = load_gold('fastdvd_forward')
-    net = torch.nn.DataParallel(ON.synth_fastdvdnet_weights(0))
+    net = ON.cpu_data_parallel(ON.synth_fastdvdnet_weights(0))
     out = OD.fastdvdnet_pass(T(g['v']), float(g['sigma']), None, None, net, 1e-6)
     assert rel_l2(out, g['out']) == 0
 
