@@ -98,6 +98,9 @@ SIGNATURES = {
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
+    'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
 }
 

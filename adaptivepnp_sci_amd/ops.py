@@ -294,6 +294,27 @@ def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False,
     return out
 
 
+def pack_conv3x3_wino(packed_f32, Cin, Cout, out=None):
+    """fp32 direct packing (device buffer of pack_conv3x3 / pack_conv3x3_device) -> Winograd F(2x2,3x3) packing for
+    conv3x3_c8w (U = G g G^T in double, on the device)."""
+    if out is None:
+        out = torch.empty(_lib.load().scipnp_conv3x3_wino_packed_floats(Cin, Cout), dtype=F32, device=packed_f32.device)
+    _call('scipnp_pack_conv3x3_wino', _p(packed_f32, 'packed_f32'), _p(out, 'packed_wino'), Cin, Cout, _stream())
+    return out
+
+
+def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+    """stride-1 3x3 conv on c8 activations in fp32 Winograd F(2x2,3x3) arithmetic (csrc/conv_wino.hip)."""
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
+             (0x100 if head else 0))
+    _call('scipnp_conv3x3_c8w', _p(x, 'x'), _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'),
+          _p(mask_src, 'mask_src'), n, cg * 8, Cout, h, w, flags, _stream())
+    return out
+
+
 def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_scale=None, bn_shift=None):
     """OIHW fp32 weights (+ optional folded eval-mode BatchNorm) -> packed split-fp16 buffer (uint8 tensor)."""
     w = weight.detach().to('cpu', F32).contiguous()

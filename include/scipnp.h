@@ -303,6 +303,23 @@ int scipnp_pack_conv3x3_device(const float* w, const float* bias, float* packed,
 int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
                                       int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
                                       scipnp_stream_t s);
+/* ---------------------------------------------------------------- fp32 Winograd F(2x2,3x3) form of the same convolution
+ * (stride 1, zero padding 1; csrc/conv_wino.hip): Y = A^T[(G g G^T) (.) (B^T d B)]A with every product an exact fp32
+ * product accumulated in fp32 on v_mfma_f32_16x16x4_f32 -- 2.25x fewer multiply-adds than scipnp_conv3x3_c8, results
+ * equal to it up to fp32 re-association (<= 2e-6 relative L2 per layer in tests/test_gpu_ops.py).  The default fp32 path
+ * of the FFDNet / FastDVDnet / DDnet engines for their stride-1 layers (SCIPNP_F32_CONV=direct selects the direct kernel).
+ * packed_wino: scipnp_conv3x3_wino_packed_floats(Cin, Cout) floats, derived ON THE DEVICE from a buffer packed by
+ * scipnp_pack_conv3x3_weights / _device(_scaled) (so bias, BatchNorm folding and the transposed backward-data packing
+ * carry over); layout [Cin/8][CoutP/32][16 positions][co/16][ci/4][co%16][ci%4], then bias[CoutP].
+ * flags: bit0 ReLU, bit1 add `residual`, bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag (as conv3x3_c8_ex).
+ * -- replaces the same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8 (models/basicblock.py:61-98,
+ *    models/network_ffdnet.py:46-48, packages/fastdvdnet/models.py:16-89); the reference's fp32 cuDNN path makes the
+ *    same algorithmic choice for 3x3 convolutions. */
+size_t scipnp_conv3x3_wino_packed_floats(int Cin, int Cout);
+int scipnp_pack_conv3x3_wino(const float* packed_f32, float* packed_wino, int Cin, int Cout, scipnp_stream_t s);
+int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, const float* residual,
+                       const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+
 /* eval-mode BatchNorm after a bias-free conv, y = conv(x;W)*s + t: fold (s, t) and the parameter gradients
  * dW = s*G, dgamma = (<W,G> - mean*sum(dy))/sqrt(var+eps), dbeta = sum(dy), G = wgrad(x, dy), K = Cin*9
  * -- packages/fastdvdnet/models.py:16-89 with BN kept in eval() during finetune (test_fastdvdnet.py:376-379) */

@@ -804,3 +804,46 @@ def test_ffdnet_gray_forward_vs_reference_golden(precision, monkeypatch):
             out = net(dev(g[f'in_{tag}']), s / 255.)
             err = rel_l2(out.cpu().numpy(), g[f'out_{tag}_s{s}'])
             assert err <= 2e-6, (tag, s, err)
+
+
+@pytest.mark.parametrize('cin,cout,h,w,n', [(16, 96, 37, 45, 2), (96, 96, 64, 64, 2), (96, 16, 33, 31, 1), (32, 32, 16, 32, 3),
+                                            (128, 128, 20, 70, 1), (8, 40, 5, 3, 1)])
+def test_conv3x3_winograd_fp32_vs_fp64(ops, cin, cout, h, w, n):
+    """fp32 Winograd F(2x2,3x3) on the fp32 MFMA (csrc/conv_wino.hip) against an fp64 convolution and against the
+    direct fp32-MFMA kernel: ragged sizes (odd heights / widths cut 2x2 tiles at the border), every epilogue"""
+    g = torch.Generator().manual_seed(cin * 991 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    fwd = torch.randn(n, cout, h, w, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+    pw = ops.pack_conv3x3_wino(packed, cin, cout)
+    xc = ops.to_c8(x.cuda())
+    got = ops.from_c8(ops.conv3x3_c8w(xc, pw, cout)).cpu()
+    direct = ops.from_c8(ops.conv3x3_c8(xc, packed, cout)).cpu()
+    # F(2x2,3x3) in fp32: the transforms add a few roundings per product (|G g G^T| <= |g|, B^T d B sums 4 inputs);
+    # measured 2e-7 .. 6e-7 against fp64, the direct kernel 1.5e-7 .. 4.7e-7
+    assert rel_l2(got.numpy(), ref.numpy()) < 1.5e-6, rel_l2(got.numpy(), ref.numpy())
+    assert rel_l2(got.numpy(), direct.numpy()) < 1.5e-6
+    got = ops.from_c8(ops.conv3x3_c8w(xc, pw, cout, relu=True, residual=ops.to_c8(res.cuda()))).cpu()
+    assert rel_l2(got.numpy(), torch.relu(ref + res.double()).numpy()) < 1.5e-6
+    fw8 = ops.to_c8(fwd.cuda())
+    got = ops.from_c8(ops.conv3x3_c8w(xc, pw, cout, mask_src=fw8, residual=ops.to_c8(res.cuda()))).cpu()
+    want = torch.where(fwd > 0, ref + res.double(), torch.zeros_like(ref))
+    assert rel_l2(got.numpy(), want.numpy()) < 1.5e-6
+
+
+def test_conv3x3_winograd_identity_asymmetric(ops):
+    """centre-tap channel permutation through the Winograd kernel: catches row / column swaps of the 16x16x4 MFMA
+    operand and accumulator maps (exact: U = G g G^T of a centre tap is 0.25 / 0.5 / 1 patterns, sums are exact)"""
+    cin = cout = 32
+    wt = torch.zeros(cout, cin, 3, 3)
+    for c in range(cout):
+        wt[c, (c * 7 + 3) % cin, 1, 1] = 1.0
+    x = (torch.arange(1 * cin * 8 * 32, dtype=torch.float32).reshape(1, cin, 8, 32) % 251) * 0.25
+    packed = ops.pack_conv3x3(wt, None, Cin=cin, Cout=cout, device='cuda')
+    got = ops.from_c8(ops.conv3x3_c8w(ops.to_c8(x.cuda()), ops.pack_conv3x3_wino(packed, cin, cout), cout)).cpu()
+    perm = [(c * 7 + 3) % cin for c in range(cout)]
+    assert torch.equal(got, x[:, perm])
