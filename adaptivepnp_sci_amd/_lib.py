@@ -109,7 +109,7 @@ class AdmmTvArgs(C.Structure):
     _fields_ = [('M', C.c_int), ('N', C.c_int), ('B', C.c_int), ('two_stage', C.c_int),
                 ('theta', C.c_void_p), ('b', C.c_void_p), ('x', C.c_void_p), ('theta_raw', C.c_void_p),
                 ('Phi', C.c_void_p), ('y', C.c_void_p), ('Phisum', C.c_void_p),
-                ('c0', C.c_float), ('c1', C.c_float), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
+                ('c0', C.c_double), ('c1', C.c_double), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
                 ('tv_workspace', C.c_void_p), ('tv_workspace_bytes', C.c_size_t),
                 ('orig', C.c_void_p), ('sse_part', C.c_void_p)]
 

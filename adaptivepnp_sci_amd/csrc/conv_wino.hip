@@ -21,10 +21,11 @@
 // tile row w (output rows 2w, 2w+1; 16 tiles along x).  Output-channel blocks of 32 are separate workgroups placed next
 // to each other on ONE XCD (its L2 serves the re-read of the input tile).  K loop over input channel groups of 8; per
 // group, double-buffered in LDS:
-//   raw input halo tile (18 x 34 pixels x 8 channels) -> four channel-pair planes [q][18][34][2] (+2 floats between
-//     planes: the 32 lanes of a ds_read_b64 group then touch 64 distinct banks), global -> registers -> ds_write_b64;
-//   U slab (16 positions x 32 co x 8 ci = 16 KiB, laid out [p][co/16][ci/4][co%16][ci%4] by the packer so that the
-//     fragment reads are conflict-free) by LDS-DMA (buffer_load_dwordx4 ... lds), no staging registers.
+//   raw input halo tile ((rows + 2) x 34 pixels x 8 channels) -> four channel-pair planes [q][rows + 2][34][2], global ->
+//     registers -> ds_write_b64; a lane reads a patch row (4 pixels x 2 channels, 32 contiguous bytes) as two ds_read_b128;
+//   U slab (16 positions x 32 co x 8 ci = 16 KiB, laid out [p][lane][co half h][k-step j] by the packer: one conflict-free
+//     ds_read_b128 per lane and position feeds the four MFMAs of that position) by LDS-DMA (buffer_load_dwordx4 ... lds),
+//     no staging registers.
 #include "common.hpp"
 
 namespace scipnp {
@@ -32,16 +33,22 @@ namespace scipnp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WN_TW = 32, WN_TH = 16;                 // output pixels per workgroup (columns, rows)
-constexpr int WN_THREADS = 512;
-constexpr int WN_TWP = WN_TW + 2, WN_THP = WN_TH + 2; // input halo tile
-constexpr int WN_PLANE = WN_THP * WN_TWP * 2 + 2;     // floats per channel-pair plane (+2: bank spread)
-constexpr int WN_RAW = 4 * WN_PLANE;                  // 4904 floats = 19616 B (16-B multiple)
-constexpr int WN_SLAB = 16 * 32 * 8;                  // 4096 floats = 16 KiB
-constexpr int WN_STAGE = WN_RAW + WN_SLAB;
-constexpr size_t WN_LDS_BYTES = 2 * (size_t)WN_STAGE * sizeof(float);
-constexpr int WN_UNITS = WN_THP * WN_TWP * 2;         // 16-byte half pixels of the halo tile
-constexpr int WN_IN_ITERS = (WN_UNITS + WN_THREADS - 1) / WN_THREADS;
+constexpr int WN_SLAB = 16 * 32 * 8;                  // 4096 floats = 16 KiB: U of one (channel group, co block)
+
+// NW = waves per workgroup = tile rows of 2 output rows each: the workgroup covers 2*NW rows x 32 columns x 32 co
+template <int NW>
+struct WinoCfg {
+    static constexpr int TW = 32, TH = 2 * NW;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int TWP = TW + 2, THP = TH + 2;           // input halo tile
+    static constexpr int PLANE = (THP * TWP * 2 + 63) / 64 * 64; // floats per channel-pair plane; a multiple of 64 keeps the
+                                                               // lane groups of the 16-byte patch reads on distinct banks
+    static constexpr int RAW = 4 * PLANE;                      // floats (a multiple of 4: every buffer stays 16-B aligned)
+    static constexpr int UNITS = THP * TWP * 2;                // 16-byte half pixels of the halo tile
+    static constexpr int IN_ITERS = (UNITS + THREADS - 1) / THREADS;
+    static constexpr int U_ITERS = (WN_SLAB / 4) / THREADS;    // LDS-DMA pieces of 16 B per lane
+    static constexpr size_t LDS_BYTES = (2 * (size_t)RAW + 2 * (size_t)WN_SLAB) * sizeof(float);
+};
 
 struct WinoArgs {
     const float* in;
@@ -56,10 +63,17 @@ struct WinoArgs {
 };
 
 // TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
-template <int TAG>
-__global__ void __launch_bounds__(WN_THREADS, 2)
+//
+// Software pipeline, one barrier per channel group g:  the MFMAs of group g run on V_g (registers) and U_g (LDS) while
+// the same wave reads the raw patch of group g+1 from LDS and transforms it into V_{g+1} between the MFMAs; the raw tile
+// of group g+2 travels global -> registers -> LDS and U_{g+1} global -> LDS (LDS-DMA) under the same MFMAs.
+template <int TAG, int NW>
+__global__ void __launch_bounds__(64 * NW, 2)
 conv3x3_c8w_kernel(const WinoArgs a) {
+    using K = WinoCfg<NW>;
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    float* const raw_lds = smem_w;                     // [2][RAW]
+    float* const u_lds = smem_w + 2 * K::RAW;          // [2][SLAB]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int tn = lane & 15, q = lane >> 4;           // tile along x, channel pair
@@ -78,56 +92,58 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     const int bx = t % a.ntx;
     t /= a.ntx;
     const int by = t % a.nty, n = t / a.nty;
-    const int x0 = bx * WN_TW, y0 = by * WN_TH;
+    const int x0 = bx * K::TW, y0 = by * K::TH;
 
-    // ---- staging plan of the raw tile: unit e = tid + 512k -> pixel (r, c) of the halo tile, 16-byte half `hf`
-    int in_off[WN_IN_ITERS], lds_off[WN_IN_ITERS];
+    // ---- staging plan of the raw tile: unit e -> pixel (r, c) of the halo tile, 16-byte half `hf`.  Units past the
+    // end of the tile wrap around (a few lanes fetch and store a unit twice, same bytes): no lane is ever masked, so
+    // the staging code is straight-line; pixels outside the image get a byte offset past the buffer descriptor's
+    // range and read as 0.
+    unsigned in_off[K::IN_ITERS];
+    int lds_off[K::IN_ITERS];
 #pragma unroll
-    for (int k = 0; k < WN_IN_ITERS; ++k) {
-        const int e = tid + k * WN_THREADS;
-        in_off[k] = -1;
-        lds_off[k] = -1;
-        if (e < WN_UNITS) {
-            const int pix = e >> 1, hf = e & 1;
-            const int r = pix / WN_TWP, c = pix - r * WN_TWP;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            lds_off[k] = (2 * hf) * WN_PLANE + pix * 2;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[k] = (gy * W + gx) * 8 + 4 * hf;
-        }
+    for (int k = 0; k < K::IN_ITERS; ++k) {
+        const int e = (tid + k * K::THREADS) % K::UNITS;
+        const int pix = e >> 1, hf = e & 1;
+        const int r = pix / K::TWP, c = pix - r * K::TWP;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        lds_off[k] = (2 * hf) * K::PLANE + pix * 2;
+        in_off[k] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * 32 + 16 * hf) : 0xFFFFFF00u;
     }
     const float* in_g = a.in + (size_t)n * a.CGin * HW * 8;                  // advanced by HW*8 per group
     const float* w_g = a.wpk + (size_t)split * WN_SLAB;                      // advanced by NCB*4096 per group
     const size_t w_step = (size_t)a.NCB * WN_SLAB;
+    const unsigned plane_bytes = (unsigned)(HW * 32);
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    (void)wvu; (void)w_g;
+    (void)wvu; (void)w_g; (void)plane_bytes;
 
-    f32x4 st_in[WN_IN_ITERS];
-    auto issue_loads = [&](float* stage) {
-#pragma unroll
-        for (int k = 0; k < WN_IN_ITERS; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (in_off[k] >= 0) v = *(const f32x4*)(in_g + in_off[k]);
-            st_in[k] = v;
-        }
-        in_g += HW * 8;
+    // `last`: this is the last group that exists -- the pointer stays (the pipeline then re-fetches it, unused)
+    auto issue_raw = [&](f32x4 (&st)[K::IN_ITERS], bool last) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep them out of the host pass that only emits the launch stub
-        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, WN_SLAB * 4, 0x00020000);
-        char* ub = (char*)(stage + WN_RAW);
+        auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, plane_bytes, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)        // 1024 16-byte units / 512 threads
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_w, (__attribute__((address_space(3))) void*)(ub + 16 * (wvu * 64 + k * WN_THREADS)), 16,
-                (unsigned)(16 * (tid + k * WN_THREADS)), 0, 0, 0);
+        for (int k = 0; k < K::IN_ITERS; ++k)
+            st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_in, in_off[k], 0, 0));
 #endif
-        w_g += w_step;
+        if (!last) in_g += HW * 8;
     };
-    auto write_lds = [&](float* stage) {
+    auto issue_u = [&](float* dst, bool last) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, WN_SLAB * 4, 0x00020000);
+        char* ub = (char*)dst;
 #pragma unroll
-        for (int k = 0; k < WN_IN_ITERS; ++k)
-            if (lds_off[k] >= 0) {
-                *(f32x2*)(stage + lds_off[k]) = f32x2{st_in[k][0], st_in[k][1]};
-                *(f32x2*)(stage + lds_off[k] + WN_PLANE) = f32x2{st_in[k][2], st_in[k][3]};
-            }
+        for (int k = 0; k < K::U_ITERS; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r_w, (__attribute__((address_space(3))) void*)(ub + 16 * (wvu * 64 + k * K::THREADS)), 16,
+                (unsigned)(16 * (tid + k * K::THREADS)), 0, 0, 0);
+#endif
+        if (!last) w_g += w_step;
+    };
+    auto write_raw = [&](float* dst, const f32x4 (&st)[K::IN_ITERS]) {
+#pragma unroll
+        for (int k = 0; k < K::IN_ITERS; ++k) {
+            *(f32x2*)(dst + lds_off[k]) = f32x2{st[k][0], st[k][1]};
+            *(f32x2*)(dst + lds_off[k] + K::PLANE) = f32x2{st[k][2], st[k][3]};
+        }
     };
 
     f32x4 acc[16][2];
@@ -136,56 +152,106 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(smem_w);
-    write_lds(smem_w);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     // per-lane LDS offsets (floats)
-    const int b_off = q * WN_PLANE + ((2 * wv) * WN_TWP + 2 * tn) * 2;              // + (dy*TWP + dx)*2
-    const int a_off = WN_RAW + (((q >> 1) * 16 + tn) * 4) + 2 * (q & 1);            // + ((p*2 + h)*2)*64
+    const int b_off = q * K::PLANE + ((2 * wv) * K::TWP + 2 * tn) * 2;              // + (dy*TWP + dx)*2
+    const int a_off = lane * 4;                                                     // + p*256: {h0j0, h0j1, h1j0, h1j1}
 
-    for (int cig = 0; cig < a.CGin; ++cig) {
-        float* buf = smem_w + (cig & 1) * WN_STAGE;
-        float* nxt = smem_w + ((cig + 1) & 1) * WN_STAGE;
-        const bool more = (cig + 1 < a.CGin);
-        if (more) issue_loads(nxt);
-        // ---- input transform  V = B^T d B  of this lane's patch, two channels at once
-        f32x2 d[4][4];
+    const int CG = a.CGin;
+    // one patch row of this lane's tile: pixels 2tn .. 2tn+3 of halo row 2wv + dy, channels (2q, 2q+1)
+    auto load_patch_row = [&](const float* rawp, int dy, float (&row)[4][2]) {
+        const f32x4 lo = *(const f32x4*)(rawp + b_off + dy * K::TWP * 2), hi = *(const f32x4*)(rawp + b_off + dy * K::TWP * 2 + 4);
+        row[0][0] = lo[0]; row[0][1] = lo[1]; row[1][0] = lo[2]; row[1][1] = lo[3];
+        row[2][0] = hi[0]; row[2][1] = hi[1]; row[3][0] = hi[2]; row[3][1] = hi[3];
+    };
+    f32x4 st_in[K::IN_ITERS];
+    float Va[4][4][2], Vb[4][4][2];          // B^T d B of the current / next group: [xi][nu][channel of the pair]
+    {   // prologue: raw tiles of groups 0 and 1, U of group 0; then V_0
+        f32x4 st_b[K::IN_ITERS];
+        issue_raw(st_in, CG <= 1);
+        issue_u(u_lds, CG <= 1);
+        issue_raw(st_b, CG <= 2);
+        write_raw(raw_lds, st_in);
+        write_raw(raw_lds + K::RAW, st_b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float d[4][4][2];
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
+        for (int dy = 0; dy < 4; ++dy) load_patch_row(raw_lds, dy, d[dy]);
 #pragma unroll
-            for (int dx = 0; dx < 4; ++dx) d[dy][dx] = *(const f32x2*)(buf + b_off + (dy * WN_TWP + dx) * 2);
-        f32x2 V[4][4];
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x2 t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
-            d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+            for (int c = 0; c < 4; ++c) {
+                const float t0 = d[0][c][e] - d[2][c][e], t1 = d[1][c][e] + d[2][c][e], t2 = d[2][c][e] - d[1][c][e],
+                            t3 = d[1][c][e] - d[3][c][e];
+                d[0][c][e] = t0; d[1][c][e] = t1; d[2][c][e] = t2; d[3][c][e] = t3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Va[r][0][e] = d[r][0][e] - d[r][2][e];
+                Va[r][1][e] = d[r][1][e] + d[r][2][e];
+                Va[r][2][e] = d[r][2][e] - d[r][1][e];
+                Va[r][3][e] = d[r][1][e] - d[r][3][e];
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            V[r][0] = d[r][0] - d[r][2];
-            V[r][1] = d[r][1] + d[r][2];
-            V[r][2] = d[r][2] - d[r][1];
-            V[r][3] = d[r][1] - d[r][3];
-        }
-        // ---- 16 positions x 2 output-channel halves x 2 k-steps
+    }
+
+    // one channel group: MFMAs on (V, U_cig), transform of group cig+1 into Vn, staging of group cig+2 / U_{cig+1}
+    auto group_step = [&](int cig, const float (&V)[4][4][2], float (&Vn)[4][4][2]) {
+        const int cur = cig & 1;
+        const float* ucur = u_lds + cur * WN_SLAB;
+        const float* rnext = raw_lds + (cur ^ 1) * K::RAW;      // raw tile of group cig+1 (stale after the last group: unused)
+        issue_raw(st_in, cig + 3 >= CG);                        // raw tile of group cig+2 -> registers
+        issue_u(u_lds + (cur ^ 1) * WN_SLAB, cig + 2 >= CG);    // U of group cig+1 -> LDS
+        float d[4][4][2];
+        f32x4 af[3];                                            // U fragments of positions p, p+1, p+2 (rotating)
+        af[0] = *(const f32x4*)(ucur + a_off);
+        af[1] = *(const f32x4*)(ucur + a_off + 256);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            f32x2 af[2];
+            if (p < 14) af[(p + 2) % 3] = *(const f32x4*)(ucur + a_off + (p + 2) * 256);
+            // slices of the next group's input transform, spread under the MFMAs of this group
+            if (p < 4) {
+                load_patch_row(rnext, p, d[p]);
+            } else if (p < 8) {
+                const int c = p - 4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) af[h] = *(const f32x2*)(buf + a_off + (p * 2 + h) * 128);
+                for (int e = 0; e < 2; ++e) {
+                    const float t0 = d[0][c][e] - d[2][c][e], t1 = d[1][c][e] + d[2][c][e], t2 = d[2][c][e] - d[1][c][e],
+                                t3 = d[1][c][e] - d[3][c][e];
+                    d[0][c][e] = t0; d[1][c][e] = t1; d[2][c][e] = t2; d[3][c][e] = t3;
+                }
+            } else if (p < 12) {
+                const int r = p - 8;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    Vn[r][0][e] = d[r][0][e] - d[r][2][e];
+                    Vn[r][1][e] = d[r][1][e] + d[r][2][e];
+                    Vn[r][2][e] = d[r][2][e] - d[r][1][e];
+                    Vn[r][3][e] = d[r][1][e] - d[r][3][e];
+                }
+            } else if (p == 13) {
+                // raw tile of group cig+2: its LDS buffer held group cig, whose transform finished before the last barrier
+                write_raw(raw_lds + cur * K::RAW, st_in);
+            }
+            const f32x4 u = af[p % 3];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    acc[p][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[h][j], V[p >> 2][p & 3][j], acc[p][h], 0, 0, 0);
-            // the other stage was last read before the previous barrier: fill it once the loads have had time to land
-            if (p == 5 && more) write_lds(nxt);
+                    acc[p][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[h * 2 + j], V[p >> 2][p & 3][j], acc[p][h], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);                 // keep every slice under its own four MFMAs
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next group's U slab (LDS-DMA) has landed
         __syncthreads();
+    };
+    int cig = 0;
+    for (; cig + 1 < CG; cig += 2) {
+        group_step(cig, Va, Vb);
+        group_step(cig + 1, Vb, Va);
     }
+    if (cig < CG) group_step(cig, Va, Vb);
 
     // ---- output transform  Y = A^T M A, bias, epilogue; lane: tile (wv, tn), channels 32*split + 16*h + 4*q + r
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
@@ -231,12 +297,12 @@ __global__ void pack_wino_kernel(const float* __restrict__ pk, float* __restrict
     const size_t total = (size_t)CGin * NCB * WN_SLAB;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        // slab element index: [p 16][h 2][qh 2][c16 16][ci%4 4]
+        // slab element index: [p 16][lane 64 = q*16 + tn][h 2][j 2]  ->  U_p[co = 32 cb + 16 h + tn][ci = 2 q + j]
         const int e = (int)(i % WN_SLAB);
         const size_t sl = i / WN_SLAB;
         const int cb = (int)(sl % NCB), cig = (int)(sl / NCB);
-        const int c4 = e & 3, c16 = (e >> 2) & 15, qh = (e >> 6) & 1, h = (e >> 7) & 1, p = e >> 8;
-        const int co = cb * 32 + h * 16 + c16, ci = qh * 4 + c4;
+        const int j = e & 1, h = (e >> 1) & 1, tnl = (e >> 2) & 15, ql = (e >> 6) & 3, p = e >> 8;
+        const int co = cb * 32 + h * 16 + tnl, ci = 2 * ql + j;
         const int xi = p >> 2, nu = p & 3;
         const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         double u = 0;
@@ -289,21 +355,30 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     a.in = in; a.wpk = packed_wino; a.out = out; a.residual = residual; a.mask_src = mask_src;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w(Cout, 32) / 32;
     a.H = h; a.W = w;
-    a.ntx = (w + WN_TW - 1) / WN_TW; a.nty = (h + WN_TH - 1) / WN_TH;
+    const bool big = (flags & 0x200) != 0;                      // 16-row workgroups of 8 waves (default: 8 rows, 4 waves)
+    const int th = big ? WinoCfg<8>::TH : WinoCfg<4>::TH;
+    a.ntx = (w + 31) / 32; a.nty = (h + th - 1) / th;
     a.flags = flags;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
-    static bool attr_set[2] = {false, false};
     const int tag = (flags & 0x100) ? 1 : 0;
-    const void* fn = tag ? (const void*)conv3x3_c8w_kernel<1> : (const void*)conv3x3_c8w_kernel<0>;
-    if (!attr_set[tag]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w, %zu B LDS): %s", WN_LDS_BYTES,
-                                         hipGetErrorString(e));
-        attr_set[tag] = true;
+    const int vi = tag * 2 + (big ? 1 : 0);
+    const void* fns[4] = {(const void*)conv3x3_c8w_kernel<0, 4>, (const void*)conv3x3_c8w_kernel<0, 8>,
+                          (const void*)conv3x3_c8w_kernel<1, 4>, (const void*)conv3x3_c8w_kernel<1, 8>};
+    const size_t lds = big ? WinoCfg<8>::LDS_BYTES : WinoCfg<4>::LDS_BYTES;
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[vi]) {
+        hipError_t e = hipFuncSetAttribute(fns[vi], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w, %zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set[vi] = true;
     }
-    if (tag) hipLaunchKernelGGL((conv3x3_c8w_kernel<1>), dim3((unsigned)total), dim3(WN_THREADS), WN_LDS_BYTES, (hipStream_t)s, a);
-    else hipLaunchKernelGGL((conv3x3_c8w_kernel<0>), dim3((unsigned)total), dim3(WN_THREADS), WN_LDS_BYTES, (hipStream_t)s, a);
+    const dim3 grid((unsigned)total), block(big ? 512 : 256);
+    switch (vi) {
+        case 0: hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4>), grid, block, lds, (hipStream_t)s, a); break;
+        case 1: hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 8>), grid, block, lds, (hipStream_t)s, a); break;
+        case 2: hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 4>), grid, block, lds, (hipStream_t)s, a); break;
+        default: hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 8>), grid, block, lds, (hipStream_t)s, a); break;
+    }
     return launch_status("conv3x3_c8w_kernel");
 }
 

@@ -12,11 +12,12 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
     SCIPNP_REQUIRE(a, "null argument block");
     SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_in_c8s &&
                    a->net_out_c8 && a->packed_split && a->scratch0 && a->scratch1, "null pointer in argument block");
-    SCIPNP_REQUIRE(a->rho > 0.f && a->tau > 0.f, "rho and tau must be positive");
+    SCIPNP_REQUIRE(a->rho > 0.0 && a->tau > 0.0, "rho and tau must be positive");
     const int M = a->M, N = a->N, B = a->B;
-    const float inv_rho = 1.0f / a->rho, inv_tau = 1.0f / a->tau;
+    // one rounding from double, like the reference's Python scalars handed to PyTorch (1 / rou, alpha * rou, 1 / tau)
+    const float inv_rho = (float)(1.0 / a->rho), inv_tau = (float)(1.0 / a->tau), alpha_rho = (float)(a->alpha * a->rho);
     // x = p + Phi^T((y - Phi p)/(alpha rho + Phi Phi^T)),  p = theta - b/rho                      (:128-140)
-    int rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, inv_rho, a->alpha * a->rho, s);
+    int rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, inv_rho, alpha_rho, s);
     if (rc) return rc;
     // mosaic of x + b/rho, Malvar demosaic, x_rgb - w/tau, FFDNet input (pixel-unshuffle + sigma map, c8s)   (:168-198)
     rc = scipnp_pm_pre_denoise_ex(a->x, a->b, a->w, a->x_rgb, nullptr, nullptr, a->net_in_c8s, M, N, B, inv_rho, inv_tau,
@@ -38,11 +39,11 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
     int rc;
     float coef, sign;
     if (a->two_stage) {
-        SCIPNP_REQUIRE(a->c0 > 0.f, "rho must be positive");
-        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, 1.0f / a->c0, a->c1 * a->c0, s);
-        coef = 1.0f / a->c0; sign = +1.0f;                 // theta = TV(x + b/rho), b += x - theta
+        SCIPNP_REQUIRE(a->c0 > 0.0, "rho must be positive");
+        coef = (float)(1.0 / a->c0); sign = +1.0f;
+        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, coef, (float)(a->c1 * a->c0), s);                 // theta = TV(x + b/rho), b += x - theta
     } else {
-        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 1, a->c0, a->c1, s);
+        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 1, (float)a->c0, (float)a->c1, s);
         coef = -1.0f; sign = -1.0f;                         // theta = TV(x - b),     b -= x - theta
     }
     if (rc) return rc;

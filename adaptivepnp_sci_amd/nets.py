@@ -63,6 +63,16 @@ def default_precision():
     return p
 
 
+def f32_conv_form():
+    """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, csrc/conv_wino.hip -- 2.25x fewer products, every one an exact
+    fp32 product) or 'direct' (csrc/conv.hip) for the stride-1 layers of the fp32 FFDNet pass; SCIPNP_F32_CONV."""
+    import os
+    f = os.environ.get('SCIPNP_F32_CONV', 'winograd')
+    if f not in ('winograd', 'direct'):
+        raise ValueError("SCIPNP_F32_CONV must be 'winograd' or 'direct'")
+    return f
+
+
 class FFDNetEngine:
     """Packed weights + scratch for B frames of M x N (half-resolution) activations."""
 
@@ -70,6 +80,7 @@ class FFDNetEngine:
         self.device = device
         self.B, self.M, self.N = B, M, N
         self.precision = precision or default_precision()
+        self.f32_form = f32_conv_form() if self.precision == 'f32' else None
         self.refresh(model)
         nc = self.nc
         self.scratch = [torch.empty(B * nc * M * N, dtype=torch.float32, device=device) for _ in range(2)]
@@ -101,6 +112,17 @@ class FFDNetEngine:
                 self.packed_split.append(ops.pack_conv3x3_split_device(ws[i], bs[i], ops.packed_buffer(cin, cout, self.device, True),
                                                                        cin, cout))
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
+        self._pack_wino()
+
+    def _pack_wino(self):
+        """Winograd-domain weights U = G g G^T of every layer, derived on the device from the fp32 packing."""
+        self.packed_wino = None
+        if self.f32_form == 'winograd':
+            self.packed_wino = []
+            for i in range(self.nb):
+                cin = self.cin0 if i == 0 else self.nc
+                cout = self.cout_last if i == self.nb - 1 else self.nc
+                self.packed_wino.append(ops.pack_conv3x3_wino(self.packed[i], cin, cout))
 
     def adopt(self, packed_f32, packed_split=None):
         """Take over device-packed weights (the online finetune packs its updated master weights on the GPU,
@@ -109,6 +131,7 @@ class FFDNetEngine:
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
         if self.precision == 'f16x3':
             self.packed_split = list(packed_split)
+        self._pack_wino()
 
     def forward(self, in_c8=None, out_c8=None, events=None):
         """12 conv launches on the current stream (same sequence as the C entry scipnp_ffdnet_forward).
@@ -120,18 +143,22 @@ class FFDNetEngine:
             return self._forward_split(in_c8, out_c8, events)
         in_c8 = self.in_c8 if in_c8 is None else in_c8
         buf = [s.view(B, nc // 8, M, N, 8) for s in self.scratch]
-        ops.conv3x3_c8(in_c8, self.packed[0], nc, relu=True, out=buf[0], head=True)
+        if self.packed_wino is not None:
+            conv, pk = ops.conv3x3_c8w, self.packed_wino
+        else:
+            conv, pk = ops.conv3x3_c8, self.packed
+        conv(in_c8, pk[0], nc, relu=True, out=buf[0], head=True)
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         cur = 0
         for l in range(1, self.nb - 1):
-            ops.conv3x3_c8(buf[cur], self.packed[l], nc, relu=True, out=buf[cur ^ 1])
+            conv(buf[cur], pk[l], nc, relu=True, out=buf[cur ^ 1])
             cur ^= 1
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        ops.conv3x3_c8(buf[cur], self.packed[self.nb - 1], self.cout_last, relu=False, out=out_c8)
+        conv(buf[cur], pk[self.nb - 1], self.cout_last, relu=False, out=out_c8)
         return out_c8
 
     def _forward_split(self, in_c8, out_c8, events):

@@ -584,6 +584,12 @@ def main():
         print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU', file=sys.stderr)
         sys.exit(2)
 
+    # the rocprofv3 --pmc child passes (roofline.traffic) run BEFORE this process touches the GPU: children are only ever
+    # started from a parent that has not initialised HIP
+    traffic, traffic_src = (None, 'skipped (--no-pmc or N > 1)')
+    if world == 1 and rank == 0 and not args.no_pmc:
+        traffic, traffic_src = pmc_traffic()
+
     # PyTorch sizes its intra-op pool by the visible cores (256 on the MI355X boxes) while the container's CPU quota is 16:
     # any CPU-side tensor op above the grain size wakes the pool, whose idle spinning exhausts the quota and gets this
     # (launching) thread throttled for tens of milliseconds -- keep the pool inside the quota (ranks share it)
@@ -635,9 +641,6 @@ def main():
         mpath = os.path.join(ROOT, 'profiles', 'measured_peaks.json')
         if os.path.exists(mpath):                          # tools/peaks_bench.py on an MI355X of the pool
             measured = json.load(open(mpath))
-        traffic, traffic_src = (None, 'skipped (--no-pmc or N > 1)')
-        if world == 1 and not args.no_pmc:
-            traffic, traffic_src = pmc_traffic()
         head = recs['f32']
         line = {
             'metric': 'admm_iters_per_s', 'value': head['value'], 'unit': 'ADMM iterations/s',

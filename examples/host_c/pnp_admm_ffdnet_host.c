@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     memset(&tv, 0, sizeof tv);
     tv.M = M; tv.N = N; tv.B = B; tv.two_stage = 0;
     tv.theta = theta; tv.b = b; tv.x = x; tv.theta_raw = theta_raw; tv.Phi = Phi; tv.y = y; tv.Phisum = Phisum;
-    tv.c0 = 1.0f; tv.c1 = 0.01f; tv.tv_weight = 0.1f; tv.tv_iters = 5;
+    tv.c0 = 1.0; tv.c1 = 0.01; tv.tv_weight = 0.1f; tv.tv_iters = 5;
     tv.tv_workspace_bytes = scipnp_tv_workspace_bytes(M, N, 4 * B, 5);
     tv.tv_workspace = dmalloc(tv.tv_workspace_bytes);
     for (int k = 0; k < tv_iters; ++k) SCICHK(scipnp_admm_tv_iterate(&tv, NULL, st));
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     a.net_out_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4);
     a.packed_split = packed; a.nb = nb; a.nc = nc;
     a.scratch0 = dmalloc((size_t)B * nc * M * N * 4); a.scratch1 = dmalloc((size_t)B * nc * M * N * 4);
-    a.rho = 1.0f; a.alpha = 1.0f; a.tau = 100.0f; a.sigma = sigma;
+    a.rho = 1.0; a.alpha = 1.0; a.tau = 100.0; a.sigma = sigma;
     for (int k = 0; k < iters; ++k) {
         a.first_iter = (k == 0);
         SCICHK(scipnp_twostage_ffdnet_iterate(&a, NULL, st));

@@ -391,7 +391,11 @@ typedef struct {
     void *scratch0, *scratch1;          /* B*nc*M*N*4 bytes each */
     const float* orig;                  /* ground truth state [B][4][M][N] or NULL */
     double* sse_part;                   /* per-block partial sums for the PSNR, or NULL */
-    float rho, alpha, tau, sigma;       /* reference constants: rho = 1, alpha = 1, tau = 100 (:101-110) */
+    double rho, alpha, tau;             /* reference constants: rho = 1 (0.55 with FastDVDnet / closed form), alpha = 1,
+                                         * tau = 100 (:101-110).  double: the kernels take float(1/rho), float(alpha*rho),
+                                         * float(1/tau) rounded ONCE from double, as the reference's Python scalars are
+                                         * (1.0f/0.55f is one ulp away from float(1/0.55)) */
+    float sigma;
     int first_iter;                     /* 1 on the very first iteration (x and theta are one tensor there) */
 } scipnp_twostage_ffdnet_args;
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
@@ -407,7 +411,8 @@ typedef struct {
     int M, N, B, two_stage;
     float *theta, *b, *x, *theta_raw;   /* state [B][4][M][N]; theta_raw: scratch for the unclipped TV output */
     const float *Phi, *y, *Phisum;
-    float c0, c1, tv_weight;            /* tv_weight = 0.1 in the reference */
+    double c0, c1;                      /* double for the same reason as scipnp_twostage_ffdnet_args.rho */
+    float tv_weight;                    /* tv_weight = 0.1 in the reference */
     int tv_iters;                       /* n_iter_max = 5 in the reference */
     void* tv_workspace;                 /* scipnp_tv_workspace_bytes(M, N, 4*B, tv_iters) */
     size_t tv_workspace_bytes;

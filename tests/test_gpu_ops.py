@@ -833,6 +833,9 @@ def test_conv3x3_winograd_fp32_vs_fp64(ops, cin, cout, h, w, n):
     got = ops.from_c8(ops.conv3x3_c8w(xc, pw, cout, mask_src=fw8, residual=ops.to_c8(res.cuda()))).cpu()
     want = torch.where(fwd > 0, ref + res.double(), torch.zeros_like(ref))
     assert rel_l2(got.numpy(), want.numpy()) < 1.5e-6
+    # the 16-row / 8-wave workgroup form runs the same arithmetic per tile
+    got16 = ops.from_c8(ops.conv3x3_c8w(xc, pw, cout, mask_src=fw8, residual=ops.to_c8(res.cuda()), rows16=True)).cpu()
+    assert torch.equal(got16, got)
 
 
 def test_conv3x3_winograd_identity_asymmetric(ops):

@@ -14,14 +14,16 @@ b = torch.randn(c, generator=g)
 x8 = ops.to_c8(x)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pw = ops.pack_conv3x3_wino(pk, c, c)
-o8, o8w = torch.empty_like(x8), torch.empty_like(x8)
+o8, o8w, o8v = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
 variants = {'fp32 direct': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
-            'fp32 winograd': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8w)}
+            'fp32 winograd': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8w),
+            'fp32 wino 16row': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8v, rows16=True)}
 for f in variants.values():
     for _ in range(3):
         f()
 torch.cuda.synchronize()
-print('winograd vs direct rel-L2:', float((o8w - o8).norm() / o8.norm()))
+print('winograd vs direct rel-L2:', float((o8w - o8).norm() / o8.norm()), '16-row:', float((o8v - o8).norm() / o8.norm()),
+      'bitwise equal variants:', bool(torch.equal(o8w, o8v)))
 res = {k: [] for k in variants}
 for r in range(5):
     for k, f in variants.items():
