@@ -114,7 +114,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     const size_t w_step = (size_t)a.NCB * WN_SLAB;
     const unsigned plane_bytes = (unsigned)(HW * 32);
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    (void)wvu; (void)w_g; (void)plane_bytes;
+    (void)wvu; (void)w_g; (void)plane_bytes; (void)in_g;
 
     // `last`: this is the last group that exists -- the pointer stays (the pipeline then re-fetches it, unused)
     auto issue_raw = [&](f32x4 (&st)[K::IN_ITERS], bool last) {
@@ -380,6 +380,22 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
         default: hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 8>), grid, block, lds, (hipStream_t)s, a); break;
     }
     return launch_status("conv3x3_c8w_kernel");
+}
+
+int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,
+                              float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8 && packed_wino && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
+    float* buf[2] = {scratch0, scratch1};
+    int rc = scipnp_conv3x3_c8w(in_c8, packed_wino[0], buf[0], nullptr, nullptr, B, 16, nc, M, N, 1 | 0x100, s);
+    if (rc) return rc;
+    int cur = 0;
+    for (int l = 1; l < nb - 1; ++l) {
+        rc = scipnp_conv3x3_c8w(buf[cur], packed_wino[l], buf[cur ^ 1], nullptr, nullptr, B, nc, nc, M, N, 1, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return scipnp_conv3x3_c8w(buf[cur], packed_wino[nb - 1], out_c8, nullptr, nullptr, B, nc, 16, M, N, 0, s);
 }
 
 }  // extern "C"

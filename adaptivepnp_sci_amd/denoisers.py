@@ -10,7 +10,6 @@ changes into its pre/post kernels); they exist so that code written against the 
 plug-in API keeps working.
 """
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .nets import FFDNetEngine
@@ -30,45 +29,37 @@ def _engine_for(model, B, M, N, device):
     return eng
 
 
-def _unshuffle_to_c8(x, sigma):
-    """(n,3,H,W) -> c8 [n][2][H/2][W/2][8] with channel c*4+dy*2+dx, ch 12 = sigma, 13..15 = 0
-    (reference network_ffdnet.py:54-64; layout plumbing only, the arithmetic is in the HIP convs)."""
-    n, c, H, W = x.shape
-    x = F.pad(x, (0, W % 2, 0, H % 2), mode='replicate')
-    h, w = x.shape[-2] // 2, x.shape[-1] // 2
-    u = x.reshape(n, c, h, 2, w, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, c * 4, h, w)
-    extra = torch.zeros(n, 4, h, w, device=x.device, dtype=x.dtype)
-    extra[:, 0] = sigma
-    return ops.to_c8(torch.cat([u, extra], 1)), h, w
+def _net_input(eng, x, sigma):
+    """planar (n,C,H,W) frames -> the engine's own input buffers (c8 fp32, and c8s for the split-fp16 engine): replicate
+    pad, pixel-unshuffle and sigma map in one HIP kernel (scipnp_ffdnet_pack_input; reference network_ffdnet.py:54-64)"""
+    ops.ffdnet_pack_input(x, sigma, out_c8=eng.in_c8)
+    if eng.in_c8s is not None:
+        ops.c8_to_c8s(eng.in_c8, out=eng.in_c8s)
 
 
 def ffdnet_forward_nchw(model, x, sigma):
-    """FFDNet forward on n frames: x (n,3,H,W) (colour network) or (n,1,H,W) (ffdnet_gray) CUDA float32, same shape out."""
-    n, _, H, W = x.shape
-    in_c8, h, w = _unshuffle_to_c8(x.float().contiguous(), sigma)
-    eng = _engine_for(model, n, h, w, x.device)
-    out = ops.from_c8(eng.forward(in_c8), eng.out_ch)
-    return F.pixel_shuffle(out, 2)[..., :H, :W].contiguous()
+    """FFDNet forward on n frames: x (n,3,H,W) (colour network) or (n,1,H,W) (ffdnet_gray) CUDA float32, same shape out.
+    HIP kernels only: input assembly, the convolution stack, pixel-shuffle + crop (scipnp_ffdnet_unpack_output)."""
+    x = x.float().contiguous()
+    n, c, H, W = x.shape
+    eng = _engine_for(model, n, (H + 1) // 2, (W + 1) // 2, x.device)
+    _net_input(eng, x, sigma)
+    return ops.ffdnet_unpack_output(eng.forward(), c, H, W)
 
 
 def ffdnet_rgb_denoise_full_tensor(x, yall, Phiall, sigma, model, useGPU=True, lr_=0.000001, updata_=False,
                                    update_per_iter=4, device=0):
     """x (H,W,3,B) CUDA tensor -> denoised (H,W,3,B); with `updata_` first runs the online
     measurement-loss finetune and returns (out, model) like the reference."""
+    rgb = ops.cube_to_rgb(x.float().contiguous())
     if updata_:
         from .finetune import ffdnet_online_finetune
-        rgb = ops.cube_to_rgb(x.float().contiguous())
         B, _, H, W = rgb.shape
-        in_c8, h, w = _unshuffle_to_c8(rgb, sigma)
-        eng = _engine_for(model, B, h, w, x.device)
-        eng.in_c8.copy_(in_c8)
-        if eng.in_c8s is not None:
-            eng.in_c8s.copy_(ops.c8_to_c8s(in_c8))
+        eng = _engine_for(model, B, (H + 1) // 2, (W + 1) // 2, x.device)
+        _net_input(eng, rgb, sigma)
         ffdnet_online_finetune(model, eng, yall.permute(2, 0, 1).contiguous(), Phiall.permute(2, 3, 0, 1).contiguous(),
                                sigma, lr_, update_per_iter)
-        out = F.pixel_shuffle(ops.from_c8(eng.forward(eng.in_c8), 12), 2)[..., :H, :W].contiguous()
-        return ops.rgb_to_cube(out), model
-    rgb = ops.cube_to_rgb(x.float().contiguous())
+        return ops.rgb_to_cube(ops.ffdnet_unpack_output(eng.forward(), 3, H, W)), model
     return ops.rgb_to_cube(ffdnet_forward_nchw(model, rgb, sigma))
 
 
@@ -100,7 +91,7 @@ def test_ddnet(vnoisy, yall=None, Phiall=None, model=None, useGPU=True, args=Non
     if gray or (args is not None and getattr(args, 'dm_update', False)):
         raise NotImplementedError('grayscale / online-finetuned DDnet is outside the hot path (the solver never uses it)')
     H, W, _, B = vnoisy.shape
-    mosaic3 = vnoisy.float().sum(dim=2).contiguous()                       # (H,W,B): one non-zero term per pixel
+    mosaic3 = ops.cube_sum3(vnoisy.float().contiguous())                   # (H,W,B): one non-zero term per pixel
     planes = ops.mosaic_to_state(mosaic3)
     mosaic = torch.empty(B, H, W, dtype=torch.float32, device=vnoisy.device)
     ops.pm_ddnet_inputs(planes, None, 0.0, torch.empty_like(planes), mosaic)

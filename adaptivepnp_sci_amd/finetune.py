@@ -88,6 +88,12 @@ def _carve(flat, like):
     return out
 
 
+# Test/diagnostic hook: callable({state-dict key: gradient tensor (a device copy)}) invoked after the FIRST backward pass of
+# every online-finetune event, before the Adam step -- the quantity the reference holds in `.grad` after its first
+# total_loss.backward() (test_ffdnet_ipol.py:296, test_fastdvdnet.py:444).  None in production.
+GRAD_HOOK = None
+
+
 class _FFDNetTrainer:
     """Device master copies of the parameters, packed forward/backward weights, Adam state and the
     activation stash of one FFDNetEngine geometry."""
@@ -249,12 +255,17 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
     engine's packed weights refreshed and the module's parameters updated; the caller then runs the
     evaluation forward (reference :303-315)."""
     _lib.require_gpu()
+    if update_per_iter <= 0:                 # no Adam step: nothing changes (the trainer's fp32 forward packs are only
+        return model                         # filled by the last step's pack(final=True); never adopt them unfilled)
     tr = _FFDNetTrainer(model, eng)
     tr.pack()
     for it in range(update_per_iter):
         tr.forward_keep()
         loss = tr.loss_and_grad(y_pm, Phi_pm)
         tr.backward()
+        if it == 0 and GRAD_HOOK is not None:
+            GRAD_HOOK({**{f'model.{2 * l}.weight': tr.dw[l].clone() for l in range(tr.nb)},
+                       **{f'model.{2 * l}.bias': tr.db[l].clone() for l in range(tr.nb)}})
         tr.adam(lr_)
         tr.pack(final=(it == update_per_iter - 1))
         val = float(loss.item())
@@ -311,6 +322,7 @@ class _DenBlockTrainer:
                 self.gamma.append(None); self.beta.append(None); self.mean.append(None); self.var.append(None)
                 self.dgamma.append(None); self.dbeta.append(None)
         self.params = list(zip(names, pv))
+        self.grads = list(zip(names, gv))
         self._gW = gv[:nl]
         n = len(_LAYERS)
         self.scale = [None if g is None else torch.empty_like(g) for g in self.gamma]
@@ -573,22 +585,46 @@ class NoisePrefetch:
         import queue
         import threading
         self.q = queue.Queue(maxsize=2)
+        self._stop = threading.Event()
+        self._states = []          # global RNG state in front of draw i
+        self._taken = 0
         self.t = threading.Thread(target=self._run, args=(tuple(shape), int(count)), daemon=True)
         self.t.start()
 
     def _run(self, shape, count):
+        import queue
         for _ in range(count):
-            self.q.put(legacy_normal(0, 5 / 255, shape))
+            if self._stop.is_set():
+                return
+            self._states.append(np.random.get_state())
+            item = legacy_normal(0, 5 / 255, shape)
+            while not self._stop.is_set():
+                try:
+                    self.q.put(item, timeout=0.05)
+                    break
+                except queue.Full:
+                    pass
 
     def get(self):
         """next draw, or None once every planned draw has been handed out (the caller then draws synchronously)"""
         import queue
         while True:
             try:
-                return self.q.get(timeout=0.05)
+                item = self.q.get(timeout=0.05)
+                self._taken += 1
+                return item
             except queue.Empty:
                 if not self.t.is_alive() and self.q.empty():
                     return None
+
+    def close(self):
+        """stop the worker and hand unconsumed draws back: the global NumPy RNG is left in the state a caller who drew
+        synchronously (only the draws actually used) would have left it in.  While a prefetch is alive nothing else in
+        the process may use np.random -- legacy_normal's get_state / draw / set_state is not atomic."""
+        self._stop.set()
+        self.t.join()
+        if self._taken < len(self._states):
+            np.random.set_state(self._states[self._taken])
 
 
 def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None,
@@ -609,6 +645,7 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
     del noise_d
     tr = _FastDVDTrainer(model, eng)
     tr.pack()
+    first = True
     for n_steps, lr_i in zip(steps, lrs):
         tr.step = 0
         for blk in tr.blocks.values():                        # a new Adam per lr group (:385)
@@ -618,6 +655,9 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
             loss = tr.loss_and_grad(y_pm, Phi_pm)
             tr.backward_block('temp2', tr.dout, tr.ds1)
             tr.backward_block('temp1', tr.ds1, None)
+            if first and GRAD_HOOK is not None:
+                GRAD_HOOK({k: g.clone() for blk in tr.blocks.values() for k, g in blk.grads})
+            first = False
             tr.adam(lr_i)
             tr.pack()
             val = float(loss.item())

@@ -448,10 +448,39 @@ def c8_add_to_c8s(x, residual_c8s, out=None):
     return out
 
 
-def c8_to_c8s(x):
+def c8_to_c8s(x, out=None):
     n, cg, h, w, _ = x.shape
-    out = torch.empty(n, cg, 2, h, w, 8, device=x.device, dtype=torch.float16)
+    if out is None:
+        out = torch.empty(n, cg, 2, h, w, 8, device=x.device, dtype=torch.float16)
     _call('scipnp_c8_to_c8s', _p(x, 'x'), _p(out, 'out', torch.float16), n, cg * 8, h, w, _stream())
+    return out
+
+
+def ffdnet_pack_input(x, sigma, out_c8=None):
+    """planar (n,C,H,W) frames -> FFDNet network input in fp32 c8: replicate pad to even size, pixel-unshuffle, sigma map
+    channel (models/network_ffdnet.py:54-64) -- csrc/plugin.hip."""
+    n, c, H, W = x.shape
+    h, w, cg = (H + 1) // 2, (W + 1) // 2, (4 * c + 1 + 7) // 8
+    if out_c8 is None:
+        out_c8 = torch.empty(n, cg, h, w, 8, device=x.device, dtype=F32)
+    _call('scipnp_ffdnet_pack_input', _p(x, 'x'), float(sigma), _p(out_c8, 'out_c8'), n, c, H, W, _stream())
+    return out_c8
+
+
+def ffdnet_unpack_output(out_c8, C_, H, W, out=None):
+    """network output c8 [n][ceil(4C/8)][h][w][8] -> pixel-shuffled, cropped planar (n,C,H,W) (network_ffdnet.py:66-69)"""
+    n = out_c8.shape[0]
+    if out is None:
+        out = torch.empty(n, C_, H, W, device=out_c8.device, dtype=F32)
+    _call('scipnp_ffdnet_unpack_output', _p(out_c8, 'out_c8'), _p(out, 'out'), n, C_, H, W, _stream())
+    return out
+
+
+def cube_sum3(cube):
+    """(H,W,3,B) -> (H,W,B), sum over the colour axis"""
+    H, W, _, B = cube.shape
+    out = torch.empty(H, W, B, device=cube.device, dtype=F32)
+    _call('scipnp_cube_sum3', _p(cube, 'cube'), _p(out, 'out'), H, W, B, _stream())
     return out
 
 

@@ -7,19 +7,22 @@ Same positional/keyword arguments, same return tuples, same log text.  Everythin
 input conversion and the final read-back stays on the GPU in the plane-major layout
 (include/scipnp.h): per iteration the host only enqueues kernels on the current HIP stream -- no
 device->host copy for TV (the reference goes through NumPy every iteration, :153-160) and none
-for the per-iteration PSNR (:274-279): squared-error partials are reduced on device and read
-back once after the last iteration, when the log lines are emitted.
+for the per-iteration PSNR (:274-279): squared-error partials are reduced on device; `psnr_all` is read
+back once after the last iteration, the logged iterations' values stream out asynchronously.
 
 `AdmmRun` is the stepper both entry points (and bench.py) drive: one `step()` = one ADMM iteration.
 
 Documented deviations from the reference:
   * `demosaic_method` other than 'malvar2004' raises ValueError (the reference silently feeds
     zeros to the denoiser, :187-191);
-  * `logf=None` is accepted (no-op writer); arrays may be NumPy or CUDA tensors;
-  * log lines are printed after the loop instead of during it (identical text).
+  * `logf=None` is accepted (no-op writer); arrays may be NumPy or CUDA tensors.
+Log lines are written while the iterations run, like the reference's (:282-309): the PSNR of a logged iteration is
+reduced on the device, copied to page-locked host memory without blocking the stream, and its line is emitted as
+soon as that copy has landed (in iteration order; nothing waits for it inside the loop).
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -59,6 +62,32 @@ def _as_lists(sigma, iter_max):
     return sigma, iter_max
 
 
+# Split-fp16 overflow flag (scipnp_split_overflow) is ONE device word: solves that overlap in time (two host threads /
+# HIP streams, harness.run_two_stage) must not clear each other's report.  The flag stays set until the last of the
+# overlapping solves has looked at it; a solve that ends while it is set raises -- possibly for a neighbour's overflow
+# (conservative), never the other way round.
+_ovf_lock = threading.Lock()
+_ovf_active = 0
+
+
+def _overflow_begin():
+    global _ovf_active
+    with _ovf_lock:
+        _ovf_active += 1
+
+
+def _overflow_end():
+    """-> True if the flag was set; resets it when no other solve is in flight"""
+    global _ovf_active
+    with _ovf_lock:
+        _ovf_active = max(0, _ovf_active - 1)
+        return ops.split_overflow(reset=(_ovf_active == 0))
+
+
+_OVERFLOW_MSG = ('denoiser activations left fp16 range in the split-fp16 convolution path; rerun with '
+                 'SCIPNP_CONV_PRECISION=f32 (inputs are expected in [0,1] units like the reference)')
+
+
 class AdmmRun:
     """Device-resident state of one reconstruction and its per-iteration kernel sequence.
 
@@ -70,7 +99,7 @@ class AdmmRun:
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
                  update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None,
-                 conv_precision=None):
+                 conv_precision=None, Phi_sum=None):
         if str(denoiser).lower() not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         denoiser = denoiser.lower()                # the reference compares denoiser.lower() (:146, :164, :214)
@@ -90,6 +119,14 @@ class AdmmRun:
         self.Phi = ops.mosaic_to_state(Phi)
         self.y = ops.y_to_meas(y)
         self.Phisum, x0 = ops.pm_setup(self.Phi, self.y, want_x0=x0_bayer is None)
+        if Phi_sum is not None:
+            # admm_denoise / gap_denoise(y, Phi, Phi_sum, ...): the caller's normaliser (H,W) is USED as given, after the
+            # reference's zeros -> 1 (:74-75 / :361-362); pm_setup's own sum of Phi over the frames is dropped
+            ps = np.array(Phi_sum.detach().cpu().numpy() if torch.is_tensor(Phi_sum) else Phi_sum, dtype=np.float32)
+            if ps.shape != tuple(y.shape):
+                raise ValueError(f'Phi_sum must have the shape of y {tuple(y.shape)}, got {ps.shape}')
+            ps[ps == 0] = 1
+            self.Phisum = ops.y_to_meas(_dev(ps, self.device))
         if x0_bayer is not None:
             x0 = ops.mosaic_to_state(_dev(x0_bayer, self.device))
         self.theta = x0                  # x and theta are ONE tensor in the reference until the first clip
@@ -255,6 +292,12 @@ class AdmmRun:
         ops.pm_ddnet_inputs(self.x, b_in, inv_rho, self.dd_planes, self.dd_mosaic)
         self.dd.forward(self.dd_planes, self.dd_mosaic, self.x_rgb)
 
+    def check_overflow(self):
+        """for callers that drive `step()` themselves (bench.py): raise if a split-fp16 conversion left fp16 range
+        since the flag was last cleared (the solver entry points do this at the end of their schedule)"""
+        if self.denoiser != 'tv' and self.eng.precision == 'f16x3' and ops.split_overflow():
+            raise _lib.ScipnpError(_OVERFLOW_MSG)
+
     # ------------------------------------------------------------------ reporting
     def _new_sse(self, nblocks):
         if self._sse_fixed is not None:           # hipGraph replay: one fixed buffer, rows are collected on the device
@@ -330,52 +373,96 @@ def _run_tv_graphed(run, total):
         run.sse_rows.extend(table[i] for i in range(n))
 
 
-def _run_schedule(run, sigma, iter_max):
+class _LogStream:
+    """The reference's per-iteration log text (dvp...:282-309 / :513-535), written while the loop runs.  A logged
+    iteration's squared error is summed on the device and copied to page-locked memory on the solver's stream; `poll`
+    emits, in iteration order, every line whose copy has landed -- the loop never waits for one."""
+
+    def __init__(self, run, denoiser, noise_estimate, logf, two_stage):
+        self.run, self.name, self.noise_estimate, self.logf = run, denoiser.upper(), noise_estimate, logf
+        self.two_stage = two_stage
+        self.have_orig = run.iqa
+        self.no_orig = run.orig is None
+        self.pending = []
+        self.n = float(run.H) * run.W * run.B
+
+    def after_step(self, k, nsig):
+        """k = index of the iteration that has just been enqueued (0-based)"""
+        if self.have_orig and (k + 1) % 2 == 0:
+            host = torch.empty(1, dtype=torch.float64).pin_memory()
+            host.copy_(self.run.sse_rows[k].sum().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((k, nsig, host, ev))
+        self.poll()
+        if self.two_stage and self.no_orig and ((k + 2) % 2 == 0):     # only when X_orig is None (reference :307-309)
+            self.logf.write('  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255 \n'.format(self.name, k + 2, nsig * 255))
+
+    def poll(self, block=False):
+        while self.pending and (block or self.pending[0][3].query()):
+            k, nsig, host, ev = self.pending.pop(0)
+            ev.synchronize()
+            psnr = float(10 * np.log10(1.0 / (float(host[0]) / self.n)))
+            self._emit(k, nsig, psnr)
+
+    def _emit(self, k, nsig, psnr):
+        if not self.noise_estimate and nsig is not None:
+            if nsig < 1:
+                line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255, PSNR {3:2.2f} dB.'.format(self.name, k + 1, nsig * 255, psnr)
+                print(line)
+                self.logf.write(line + ' \n')
+            else:
+                line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}, PSNR {3:2.2f} dB.'.format(self.name, k + 1, nsig, psnr)
+                print(line)
+                self.logf.write(line + '\n')
+        else:
+            line = '  ADMM-{0} iteration {1: 3d}, PSNR {2:2.2f} dB.'.format(self.name, k + 1, psnr)
+            print(line)
+            self.logf.write(line + '\n')
+
+
+def _run_schedule(run, sigma, iter_max, log=None):
+    """the iterations of one solver call; `log`: _LogStream (lines stream out during the loop) or None"""
     total = sum(iter_max)
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
             and os.environ.get('SCIPNP_HIPGRAPH', '0') == '1'):
-        return _run_tv_graphed(run, total)
+        _run_tv_graphed(run, total)
+        if log is not None:                              # graph replay: the values exist only after the replays
+            k = 0
+            for nsig, iters in zip(sigma, iter_max):
+                for _ in range(iters):
+                    log.after_step(k, nsig)
+                    k += 1
+            log.poll(block=True)
+        return
+    split = run.denoiser != 'tv' and run.eng.precision == 'f16x3'
+    own_noise = None
     if run.noise_source is None:
         n_events = _count_finetune_events(run.update_, run.two_stage, run.denoiser, total, run.inital_iter, run.interval_iter,
                                           run.update_times, run.k, run.update_i)
         if n_events:
+            # drawn ahead on a worker thread (the 65 ms NumPy draw overlaps the iterations before the gate); created only
+            # now that the run exists, closed below whatever happens (unconsumed draws are given back to the global RNG)
             from .finetune import NoisePrefetch
-            run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
-    for idx, nsig in enumerate(sigma):
-        for _ in range(iter_max[idx]):
-            run.step(nsig, last=(run.k == total - 1))
-    if run.denoiser != 'tv' and run.eng.precision == 'f16x3' and ops.split_overflow():
-        raise _lib.ScipnpError('denoiser activations left fp16 range in the split-fp16 convolution path; rerun with '
-                               'SCIPNP_CONV_PRECISION=f32 (inputs are expected in [0,1] units like the reference)')
-
-
-def _log_lines(denoiser, schedule, psnr_all, noise_estimate, logf, have_orig, two_stage, no_orig=None):
-    """Reference log text (dvp...:282-309 / :513-535), emitted after the loop."""
-    name = denoiser.upper()
-    if no_orig is None:
-        no_orig = not have_orig
-    k = 0
-    for nsig, iters in schedule:
-        for _ in range(iters):
-            if have_orig and (k + 1) % 2 == 0:
-                if not noise_estimate and nsig is not None:
-                    if nsig < 1:
-                        line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255, PSNR {3:2.2f} dB.'.format(
-                            name, k + 1, nsig * 255, psnr_all[k])
-                        print(line)
-                        logf.write(line + ' \n')
-                    else:
-                        line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}, PSNR {3:2.2f} dB.'.format(
-                            name, k + 1, nsig, psnr_all[k])
-                        print(line)
-                        logf.write(line + '\n')
-                else:
-                    line = '  ADMM-{0} iteration {1: 3d}, PSNR {2:2.2f} dB.'.format(name, k + 1, psnr_all[k])
-                    print(line)
-                    logf.write(line + '\n')
-            k += 1
-            if two_stage and no_orig and ((k + 1) % 2 == 0):       # only when X_orig is None (reference :307-309)
-                logf.write('  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255 \n'.format(name, k + 1, nsig * 255))
+            own_noise = run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
+    if split:
+        _overflow_begin()
+    try:
+        for idx, nsig in enumerate(sigma):
+            for _ in range(iter_max[idx]):
+                k = run.k
+                run.step(nsig, last=(run.k == total - 1))
+                if log is not None:
+                    log.after_step(k, nsig)
+        if log is not None:
+            log.poll(block=True)
+    finally:
+        if own_noise is not None:
+            own_noise.close()
+            run.noise_source = None
+        overflow = _overflow_end() if split else False
+    if overflow:
+        raise _lib.ScipnpError(_OVERFLOW_MSG)
 
 
 def _check_demosaic(denoiser, demosaic_method, model_demosaic=None):
@@ -395,26 +482,27 @@ def twoStageAdmm_denoise_bayer(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                inital_iter=1, interval_iter=5, logf=None, useGPU=True, update_=False,
                                update_per_iter=1, close_form_demosaic=False,
                                large=False, update_times=-1, args=None):
+    """dvp_linear_inv_2_stage_ADMM_tensor_online.py:40-324, same arguments and return tuple"""
+    return _two_stage(y_bayer, Phi_bayer, denoiser, iter_max, noise_estimate, sigma, x0_bayer, X_orig, model_denoise,
+                      model_demosaic, show_iqa, demosaic_method, lr_, inital_iter, interval_iter, logf, update_,
+                      update_per_iter, close_form_demosaic, update_times, None)
+
+
+def _two_stage(y_bayer, Phi_bayer, denoiser, iter_max, noise_estimate, sigma, x0_bayer, X_orig, model_denoise,
+               model_demosaic, show_iqa, demosaic_method, lr_, inital_iter, interval_iter, logf, update_, update_per_iter,
+               close_form_demosaic, update_times, _Phi_sum):
     if str(denoiser).lower() not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
     denoiser = denoiser.lower()
     _check_demosaic(denoiser, demosaic_method, model_demosaic)
     logf = logf or _NullLog()
     sigma, iter_max = _as_lists(sigma, iter_max)
-    # the FastDVDnet finetune's NumPy noise draw (65 ms at 512x512x8) starts before anything else, on a worker thread
-    noise_source = None
-    n_events = _count_finetune_events(update_, True, denoiser, sum(iter_max), inital_iter, interval_iter, update_times)
-    if n_events:
-        from .finetune import NoisePrefetch
-        noise_source = NoisePrefetch((np.shape(Phi_bayer)[2], 3) + tuple(np.shape(Phi_bayer)[:2]), n_events)
     run = AdmmRun(y_bayer, Phi_bayer, denoiser, True, x0_bayer, X_orig, model_denoise, show_iqa, lr_=lr_,
                   inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
                   update_per_iter=update_per_iter, update_times=update_times, logf=logf,
-                  close_form_demosaic=close_form_demosaic, model_demosaic=model_demosaic)
-    run.noise_source = noise_source
-    _run_schedule(run, sigma, iter_max)
+                  close_form_demosaic=close_form_demosaic, model_demosaic=model_demosaic, Phi_sum=_Phi_sum)
+    _run_schedule(run, sigma, iter_max, _LogStream(run, denoiser, noise_estimate, logf, True))
     psnr_all = run.psnr_all()
-    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, True, run.orig is None)
     x_bayer_np = ops.to_host(run.result_mosaic())
     psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
@@ -429,6 +517,13 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
                                     lr_=0.000001,
                                     inital_iter=1, interval_iter=5, logf=None, useGPU=True, device=0,
                                     update_=False, update_per_iter=1):
+    """dvp_linear_inv_2_stage_ADMM_tensor_online.py:326-552, same arguments and return tuple"""
+    return _one_stage(y_bayer, Phi_bayer, _lambda, gamma, denoiser, iter_max, noise_estimate, sigma, x0_bayer, X_orig, model,
+                      show_iqa, demosaic_method, lr_, inital_iter, interval_iter, logf, update_, update_per_iter, None)
+
+
+def _one_stage(y_bayer, Phi_bayer, _lambda, gamma, denoiser, iter_max, noise_estimate, sigma, x0_bayer, X_orig, model,
+               show_iqa, demosaic_method, lr_, inital_iter, interval_iter, logf, update_, update_per_iter, _Phi_sum):
     if str(denoiser).lower() not in DENOISERS:
         raise ValueError('Unsupported denoiser {}!'.format(denoiser))
     denoiser = denoiser.lower()
@@ -437,10 +532,9 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     sigma, iter_max = _as_lists(sigma, iter_max)
     run = AdmmRun(y_bayer, Phi_bayer, denoiser, False, x0_bayer, X_orig, model, show_iqa, _lambda=_lambda, gamma=gamma,
                   lr_=lr_, inital_iter=inital_iter, interval_iter=interval_iter, update_=update_,
-                  update_per_iter=update_per_iter, logf=logf)
-    _run_schedule(run, sigma, iter_max)
+                  update_per_iter=update_per_iter, logf=logf, Phi_sum=_Phi_sum)
+    _run_schedule(run, sigma, iter_max, _LogStream(run, denoiser, noise_estimate, logf, False))
     psnr_all = run.psnr_all()
-    _log_lines(denoiser, list(zip(sigma, iter_max)), psnr_all, noise_estimate, logf, run.iqa, False)
     x_bayer_np = ops.to_host(run.result_mosaic())
     psnr_, ssim_ = run.final_report(x_bayer_np)
     if denoiser == 'tv':
@@ -448,17 +542,31 @@ def admm_denoise_bayer_demosaic_pre(y_bayer, Phi_bayer, _lambda=1, gamma=0.01,
     return ops.to_host(ops.rgb_to_cube(run.out_rgb)), x_bayer_np, psnr_, ssim_, psnr_all, model
 
 
+def _bind(fn, y, Phi, denoiser, kw):
+    """the public entry point's own defaults for everything the alias caller left out"""
+    import inspect
+    ba = inspect.signature(fn).bind(y, Phi, denoiser=denoiser, **kw)
+    ba.apply_defaults()
+    return ba.arguments
+
+
 def admm_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
-    """PnP-SCI-style alias named by the task brief: (y, Phi, Phi_sum, denoiser, ...) -> two-stage ADMM.
-    Phi_sum is recomputed on device exactly as the reference does (:72-75); the argument is accepted
-    for signature compatibility and checked for shape only."""
-    if Phi_sum is not None and tuple(np.shape(Phi_sum)) != tuple(np.shape(y)):
-        raise ValueError('Phi_sum must have the shape of y')
-    return twoStageAdmm_denoise_bayer(y, Phi, denoiser=denoiser, **kw)
+    """PnP-SCI-style alias named by the task brief: (y, Phi, Phi_sum, denoiser, ...) -> two-stage ADMM; keyword arguments
+    as `twoStageAdmm_denoise_bayer`.  Phi_sum (H,W), if given, IS the normaliser of the Euclidean projection (after the
+    reference's zeros -> 1, :74-75): pass the sum of Phi over the frames to reproduce `twoStageAdmm_denoise_bayer` bit for
+    bit, or e.g. the sum of Phi**2 for non-binary masks.  None: computed on the device as the reference does (:72-75)."""
+    a = _bind(twoStageAdmm_denoise_bayer, y, Phi, denoiser, kw)
+    return _two_stage(a['y_bayer'], a['Phi_bayer'], a['denoiser'], a['iter_max'], a['noise_estimate'], a['sigma'],
+                      a['x0_bayer'], a['X_orig'], a['model_denoise'], a['model_demosaic'], a['show_iqa'],
+                      a['demosaic_method'], a['lr_'], a['inital_iter'], a['interval_iter'], a['logf'], a['update_'],
+                      a['update_per_iter'], a['close_form_demosaic'], a['update_times'], Phi_sum)
 
 
 def gap_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
-    """Alias for the one-stage ("GAP form") solver, see `admm_denoise`."""
-    if Phi_sum is not None and tuple(np.shape(Phi_sum)) != tuple(np.shape(y)):
-        raise ValueError('Phi_sum must have the shape of y')
-    return admm_denoise_bayer_demosaic_pre(y, Phi, denoiser=denoiser, **kw)
+    """Alias for the one-stage ("GAP form") solver `admm_denoise_bayer_demosaic_pre`; Phi_sum as in `admm_denoise`
+    (reference :359-362)."""
+    a = _bind(admm_denoise_bayer_demosaic_pre, y, Phi, denoiser, kw)
+    return _one_stage(a['y_bayer'], a['Phi_bayer'], a['_lambda'], a['gamma'], a['denoiser'], a['iter_max'],
+                      a['noise_estimate'], a['sigma'], a['x0_bayer'], a['X_orig'], a['model'], a['show_iqa'],
+                      a['demosaic_method'], a['lr_'], a['inital_iter'], a['interval_iter'], a['logf'], a['update_'],
+                      a['update_per_iter'], Phi_sum)

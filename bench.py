@@ -17,7 +17,9 @@ mosaics are gathered to rank 0 with ONE RCCL gather at the end of the timed regi
 
 The SAME invocation times both convolution precisions on the same cube:
   headline (`value`, `dtype: "f32"`) : the FFDNet convolutions in fp32 arithmetic on the fp32 MFMA
-                 (the reference's precision);
+                 (the reference's precision) as Winograd F(2x2,3x3): every product an exact fp32 product, 2.25x fewer
+                 of them than the direct form, so the ALGORITHMIC rate `roofline.achieved` can exceed the MFMA peak;
+  `f32_direct_form` : the same pass with direct-form convolutions (executed = algorithmic FLOPs);
   `fast_path`  : the library default, error-compensated split-fp16 operands on the fp16 MFMA (22 significant
                  bits per operand, fp32 accumulation; meets the 1e-5 / 1e-4 dB gates but is narrower than fp32,
                  so it is reported beside the headline, not as it).
@@ -273,8 +275,19 @@ def time_precision(prec, args, ctx):
     from adaptivepnp_sci_amd import shard
     from adaptivepnp_sci_amd.solver import AdmmRun
     dist, rank, world, dev, cdev = ctx['dist'], ctx['rank'], ctx['world'], ctx['dev'], ctx['coll_dev']
-    run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'], model=ctx['net'],
-                  conv_precision=prec)
+    direct = prec == 'f32_direct'
+    old_form = os.environ.get('SCIPNP_F32_CONV')
+    if direct:                                   # the fp32 pass in direct form (csrc/conv.hip) instead of Winograd
+        os.environ['SCIPNP_F32_CONV'] = 'direct'
+    try:
+        run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'],
+                      model=ctx['net'], conv_precision='f32' if direct else prec)
+    finally:
+        if direct:
+            if old_form is None:
+                os.environ.pop('SCIPNP_F32_CONV', None)
+            else:
+                os.environ['SCIPNP_F32_CONV'] = old_form
 
     def barrier():
         if dist is not None:
@@ -313,6 +326,7 @@ def time_precision(prec, args, ctx):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     run.profile_events = run.phi_events = None
+    run.check_overflow()                              # split-fp16 range guard (the solver entry points do this themselves)
     body_launch_s = float(np.mean([a.elapsed_time(b) for a, b in events])) / 1e3 / (NB - 2)
     phi_s = float(np.median([a.elapsed_time(b) for a, b in phi_events])) / 1e3
     psnr = run.psnr_all()
@@ -323,7 +337,7 @@ def time_precision(prec, args, ctx):
     return rec, run, mosaic, psnr
 
 
-def roofline_record(prec, body_launch_s, traffic, traffic_src, measured):
+def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_form='winograd'):
     achieved = BODY_FLOP_PER_LAUNCH / body_launch_s
     if prec == 'f16x3':
         peak, exec_ratio = PEAK_F16_MFMA, SPLIT_EXEC_PER_ALGO
@@ -331,6 +345,15 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured):
                  'split-fp16: 3 exact fp16 products per fp32 product on v_mfma_f32_32x32x16_f16, fp32 accumulate)')
         peak_meas = measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs')
         tr = _pick(traffic, 'conv3x3_c8s_kernel<3, 0')
+    elif f32_form == 'winograd':
+        # F(2x2,3x3): 16 products per 2x2 output tile and channel pair instead of 36 -- the matrix pipes execute 1/2.25 of
+        # the ALGORITHMIC (direct-form) multiply-adds, every one an exact fp32 product on v_mfma_f32_16x16x4_f32; `achieved`
+        # counts algorithmic FLOPs as the contract asks, so `frac` can exceed 1 -- the pipes' own duty is matrix_pipe_frac_of_peak
+        peak, exec_ratio = PEAK_FP32_MFMA, 1.0 / 2.25
+        kname = ('conv3x3_c8w_kernel<TAG=0,NW=4> (FFDNet body layer 96->96, 8 frames of 256x256; fp32 Winograd F(2x2,3x3), '
+                 'v_mfma_f32_16x16x4_f32, input/output transforms fused into the kernel)')
+        peak_meas = measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
+        tr = _pick(traffic, 'conv3x3_c8w_kernel<0, 4')
     else:
         peak, exec_ratio = PEAK_FP32_MFMA, 1.0
         kname = 'conv3x3_c8_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256, v_mfma_f32_32x32x2_f32)'
@@ -340,7 +363,8 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured):
     if tr is None:                                   # no live PMC pass: the committed profile, named
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):
-            tr = json.load(open(tpath)).get(prec, {}).get('hbm_bytes_per_launch')
+            key = 'f32_direct' if (prec == 'f32' and f32_form == 'direct') else prec
+            tr = json.load(open(tpath)).get(key, {}).get('hbm_bytes_per_launch')
             src = f'committed profile profiles/pmc_traffic.json (live PMC pass unavailable: {traffic_src})'
     return {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / peak,
             'traffic': tr, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
@@ -628,7 +652,12 @@ def main():
     ctx = dict(dist=dist, rank=rank, world=world, dev=dev, coll_dev=coll_dev, y_d=y_d, Phi_d=Phi_d, orig_d=orig_d, warm=warm, net=net)
 
     recs, gpu_out, last_run = {}, {}, None
-    for prec in (PRECISIONS[:1] if args.no_fast_path else PRECISIONS):
+    from adaptivepnp_sci_amd.nets import f32_conv_form
+    f32_form = f32_conv_form()
+    passes = list(PRECISIONS[:1] if args.no_fast_path else PRECISIONS)
+    if f32_form == 'winograd' and not args.no_fast_path:
+        passes.append('f32_direct')
+    for prec in passes:
         rec, run, mosaic, psnr = time_precision(prec, args, ctx)
         recs[prec] = rec
         gpu_out[prec] = (mosaic.cpu().numpy(), psnr)
@@ -658,7 +687,7 @@ def main():
             # of a whole solver call with the reference driver's 25-iteration schedule) is filled in below at N = 1
             'frame_iterations_per_s': head['frame_iterations_per_s'],
             'frames_per_s': None,
-            'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured),
+            'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured, f32_form),
             'phi_step': phi_record(last_run, head['phi_s'], traffic, traffic_src, measured, dev),
             'preheat': f'{args.preheat} untimed denoiser passes before the warm-up steps (clock ramp after the TV phase)',
             'psnr_db_first_last': head['psnr_db_first_last'],
@@ -675,6 +704,16 @@ def main():
                 'parity_vs_f32_path': {'rel_l2_final_iterate': rel_l2(gpu_out['f16x3'][0], gpu_out['f32'][0]),
                                        'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_out['f16x3'][1]) -
                                                                                    np.array(gpu_out['f32'][1]))))}}
+        if 'f32_direct' in recs:
+            fd = recs['f32_direct']
+            line['f32_direct_form'] = {
+                'dtype': 'f32', 'note': 'the same fp32 pass with the convolutions in direct form on v_mfma_f32_32x32x2_f32 '
+                                        '(SCIPNP_F32_CONV=direct): executed = algorithmic FLOPs, the plain MFMA roofline',
+                'value': fd['value'], 'unit': 'ADMM iterations/s', 'ms_per_step': fd['ms_per_step'],
+                'roofline': roofline_record('f32', fd['body_launch_s'], traffic, traffic_src, measured, 'direct'),
+                'parity_vs_headline': {'rel_l2_final_iterate': rel_l2(gpu_out['f32_direct'][0], gpu_out['f32'][0]),
+                                       'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_out['f32_direct'][1]) -
+                                                                                   np.array(gpu_out['f32'][1]))))}}
         if world == 1:
             # SURVEY 8(d)'s other reading of the metric: whole solver calls with the reference driver's schedule
             # (sigma [25,12,6]/255 x [15,6,4] iterations), inputs as NumPy arrays, outputs read back to the host
@@ -683,7 +722,7 @@ def main():
                       X_orig=orig, model_denoise=net, logf=io.StringIO())
             whole = {'schedule': 'two-stage ADMM + FFDNet-color, 25 iterations ([15,6,4] at sigma [25,12,6]/255), '
                                  'H2D of y/Phi and D2H of the RGB cube + mosaic included, no finetune'}
-            for prec in recs:
+            for prec in [p_ for p_ in recs if p_ in PRECISIONS]:
                 with conv_precision(prec), contextlib.redirect_stdout(io.StringIO()):
                     twoStageAdmm_denoise_bayer(y, Phi, **kw)
                     ts = []

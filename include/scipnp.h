@@ -320,6 +320,11 @@ int scipnp_pack_conv3x3_wino(const float* packed_f32, float* packed_wino, int Ci
 int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, const float* residual,
                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* The whole FFDNet-colour pass (test_ffdnet_ipol.py:340-359 -> network_ffdnet.py:65-66) as ONE call on the Winograd
+ * kernel: same arguments as scipnp_ffdnet_forward with every layer packed by scipnp_pack_conv3x3_wino. */
+int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,
+                              float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+
 /* eval-mode BatchNorm after a bias-free conv, y = conv(x;W)*s + t: fold (s, t) and the parameter gradients
  * dW = s*G, dgamma = (<W,G> - mean*sum(dy))/sqrt(var+eps), dbeta = sum(dy), G = wgrad(x, dy), K = Cin*9
  * -- packages/fastdvdnet/models.py:16-89 with BN kept in eval() during finetune (test_fastdvdnet.py:376-379) */
@@ -420,6 +425,24 @@ typedef struct {
     double* sse_part;
 } scipnp_admm_tv_args;
 int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Layout steps of the stand-alone denoiser plug-ins (the solver fuses them into its pre/post kernels) -- csrc/plugin.hip
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* FFDNet.forward's input assembly, models/network_ffdnet.py:54-64: x planar [n][C][H][W] (C = 3 colour / 1 gray) ->
+ * replicate-padded to even size, pixel-unshuffled (channel c*4 + dy*2 + dx), sigma as channel 4C, zero-padded to
+ * CG = ceil((4C+1)/8) groups: out_c8 [n][CG][h][w][8] fp32, h = ceil(H/2), w = ceil(W/2) (scipnp_c8_to_c8s makes the
+ * split-fp16 form of it). */
+int scipnp_ffdnet_pack_input(const float* x, float sigma, float* out_c8, int n, int C, int H, int W, scipnp_stream_t s);
+
+/* FFDNet.forward's output assembly, models/network_ffdnet.py:66-69: net_out c8 [n][ceil(4C/8)][h][w][8] ->
+ * pixel-shuffled and cropped y planar [n][C][H][W]. */
+int scipnp_ffdnet_unpack_output(const float* out_c8, float* y, int n, int C, int H, int W, scipnp_stream_t s);
+
+/* (H,W,3,B) cube -> (H,W,B) sum over the colour axis (packages/DDnet/DDnet_test.py: the demosaicker's input is the
+ * mosaic, i.e. the channel sum of a CFA-sampled cube). */
+int scipnp_cube_sum3(const float* cube, float* out, int H, int W, int B, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * DDnet deep demosaicking -- glue around scipnp_conv3x3_c8 / _c8s.

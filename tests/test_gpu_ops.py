@@ -746,9 +746,10 @@ def test_denoiser_plugins_with_online_update_vs_oracle(ffdnet_state_dict):
     assert rel_l2(out.cpu().numpy(), ref.detach().numpy()) <= 1e-5
 
 
-def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict):
-    """scipnp_ffdnet_forward (fp32) and scipnp_ffdnet_forward_c8s (split-fp16): the whole 12-layer pass as ONE C-ABI
-    call each, bit-identical to the layer-by-layer launches the solver issues"""
+def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict, monkeypatch):
+    """scipnp_ffdnet_forward (fp32 direct), scipnp_ffdnet_forward_c8w (fp32 Winograd) and scipnp_ffdnet_forward_c8s
+    (split-fp16): the whole 12-layer pass as ONE C-ABI call each, bit-identical to the layer-by-layer launches the solver
+    issues"""
     from adaptivepnp_sci_amd.nets import FFDNet, FFDNetEngine
     net = FFDNet()
     net.load_state_dict(ffdnet_state_dict)
@@ -756,8 +757,10 @@ def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict
     x = torch.rand(3, 16, 20, 36, generator=g)
     x[:, 12] = 25 / 255
     x[:, 13:] = 0
-    for prec in ('f32', 'f16x3'):
-        eng = FFDNetEngine(net, 3, 20, 36, torch.device('cuda'), precision=prec)
+    for prec in ('f32', 'f32-direct', 'f16x3'):
+        monkeypatch.setenv('SCIPNP_F32_CONV', 'direct' if prec == 'f32-direct' else 'winograd')
+        eng = FFDNetEngine(net, 3, 20, 36, torch.device('cuda'), precision=prec.split('-')[0])
+        assert (eng.packed_wino is not None) == (prec == 'f32')
         eng.in_c8.copy_(__import__('adaptivepnp_sci_amd').ops.to_c8(x.cuda()))
         if prec == 'f16x3':
             from adaptivepnp_sci_amd import ops as O

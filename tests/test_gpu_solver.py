@@ -191,6 +191,8 @@ def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict, pre
     losses = []
     orig_ft = finetune.ffdnet_online_finetune
     finetune.ffdnet_online_finetune = lambda *a, **k: orig_ft(*a, trace=losses, **k)
+    grads = []
+    monkeypatch.setattr(finetune, 'GRAD_HOOK', lambda d: grads.append({k: v.cpu().numpy() for k, v in d.items()}))
     try:
         res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
                                                 x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net, show_iqa=True,
@@ -203,6 +205,16 @@ def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict, pre
     assert rel_l2(res[0], g['rgb']) <= REL_TOL
     # losses of the two Adam steps (the golden's third entry is the reference's post-update print)
     assert len(losses) == 2 and np.allclose(losses, g['losses'][:2], rtol=1e-5)
+    # the gradients themselves against the reference's .grad after its first backward() (tools/make_golden.py g_ffdtune):
+    # every bias and four weight tensors in full, every tensor by its norm
+    assert len(grads) == 1 and len(grads[0]) == 24
+    for k0, got in grads[0].items():
+        key = k0.replace('.', '_')
+        if 'grad_' + key in g.files:
+            assert rel_l2(got, g['grad_' + key]) <= 1e-4, (k0, rel_l2(got, g['grad_' + key]))
+        nref = float(g['gradnorm_' + key])
+        assert abs(float(np.linalg.norm(got.astype(np.float64))) - nref) <= 1e-4 * nref, k0
+    assert sum(('grad_' + k0.replace('.', '_')) in g.files for k0 in grads[0]) == 16
     # the module was updated in place: parameter deltas vs the reference's.  Adam's first steps are ~ -lr*sign(g),
     # so deltas agree except where a gradient is ~0 (sign undetermined at round-off level)
     sd = net.state_dict()
@@ -230,6 +242,8 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
     losses = []
     orig_ft = finetune.fastdvdnet_online_finetune
     finetune.fastdvdnet_online_finetune = lambda *a, **k: orig_ft(*a, trace=losses, **k)
+    grads = []
+    monkeypatch.setattr(finetune, 'GRAD_HOOK', lambda d: grads.append({k: v.cpu().numpy() for k, v in d.items()}))
     np.random.seed(42)
     st = np.random.get_state()
     assert np.array_equal(np.random.normal(0, 5 / 255, (8, 3, 64, 64)), gf['noise'])     # same stream as the reference run
@@ -245,6 +259,18 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
         assert rel_l2(tr.it[k], gf['theta'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], gf['theta'][k]))
     assert rel_l2(res[0], gf['rgb']) <= REL_TOL
     assert len(losses) == 2 and np.allclose(losses, gf['losses'][:2], rtol=1e-5), (losses, gf['losses'])
+    # gradients of the first backward pass against the reference's .grad (tools/make_golden.py g_fastdvd): BatchNorm
+    # affine gradients and one tensor per layer type in full, every tensor by its norm
+    assert len(grads) == 1
+    n_full = 0
+    for k0, got in grads[0].items():
+        key = k0.replace('.', '_')
+        nref = float(gf['gradnorm_' + key])
+        assert abs(float(np.linalg.norm(got.astype(np.float64))) - nref) <= 2e-4 * nref + 1e-12, (k0, nref)
+        if 'grad_' + key in gf.files:
+            n_full += 1
+            assert rel_l2(got, gf['grad_' + key]) <= 1e-4, (k0, rel_l2(got, gf['grad_' + key]))
+    assert n_full >= 2 * (8 + 26), n_full
     sd = net.state_dict()
     for k0 in sd0:
         if sd0[k0].dim() == 4:
@@ -417,3 +443,92 @@ def test_admm_tv_single_call_iteration_equals_the_launch_by_launch_path(solver, 
         plain.step(0)
     assert torch.equal(fused.theta, plain.theta) and torch.equal(fused.b, plain.b) and torch.equal(fused.x, plain.x)
     assert np.abs(np.array(fused.psnr_all()) - np.array(plain.psnr_all())).max() < 1e-9
+
+
+def test_named_aliases_use_phi_sum(solver):
+    """north_star's admm_denoise / gap_denoise(y, Phi, Phi_sum, denoiser, ...): with Phi_sum = sum of Phi over the frames
+    (zeros left in: the alias applies the reference's zeros -> 1, dvp...:74-75 / :361-362) they ARE the two real entry
+    points, bit for bit; with another normaliser the result changes, i.e. the argument is used, and equals the
+    projection evaluated with that normaliser."""
+    from adaptivepnp_sci_amd import ops, synth
+    y, Phi, orig = synth.make_problem(32, 48, 6, seed=11)
+    Phi[3:6, 7:9, :] = 0                                   # pixels no frame sees: Phi_sum = 0 there
+    y = (Phi * orig).sum(2).astype(np.float32)
+    ps = Phi.sum(2)
+    assert (ps == 0).any()
+    for alias, real in ((solver.admm_denoise, solver.twoStageAdmm_denoise_bayer),
+                        (solver.gap_denoise, solver.admm_denoise_bayer_demosaic_pre)):
+        kw = dict(iter_max=[4], sigma=[0], X_orig=orig, logf=io.StringIO())
+        want = real(y, Phi, denoiser='tv', **kw)
+        got = alias(y, Phi, ps, 'tv', **kw)
+        assert np.array_equal(got[0], want[0]) and got[3] == want[3]
+        got_none = alias(y, Phi, None, 'tv', **kw)
+        assert np.array_equal(got_none[0], want[0])
+        other = alias(y, Phi, (Phi ** 2).sum(2) + 0.5, 'tv', **kw)
+        assert not np.array_equal(other[0], want[0])
+        with pytest.raises(ValueError):
+            alias(y, Phi, ps[:-2], 'tv', **kw)
+    # one projection with a caller-supplied normaliser against the operator called directly
+    run = solver.AdmmRun(y, Phi, 'tv', True, Phi_sum=ps + 0.25)
+    want_ps = ops.y_to_meas(torch.from_numpy(ps + 0.25).cuda())
+    assert torch.equal(run.Phisum, want_ps)
+
+
+def test_log_lines_stream_out_during_the_loop(solver):
+    """the reference writes its log line inside the iteration loop (dvp...:282-304); here a logged iteration's PSNR comes
+    back asynchronously and its line is written as soon as it has landed -- long before the last iteration"""
+    g = load_gold('tvadmm_64x64x8')
+    events = []
+
+    class Log:
+        def write(self, s):
+            events.append(('log', s))
+
+    def hook(k, mosaic):
+        torch.cuda.synchronize()                    # makes the arrival order deterministic for the test
+        events.append(('iter', k))
+
+    solver.ITERATE_HOOK = hook
+    solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'tv', [12], False, [0], X_orig=g['orig'], logf=Log())
+    kinds = [e[0] for e in events]
+    first_log = kinds.index('log')
+    assert events[first_log][1].startswith('  ADMM-TV iteration   2,')
+    assert ('iter', 4) in events[first_log:], 'the first log line must be out while the loop is still running'
+    logs = [e[1] for e in events if e[0] == 'log']
+    assert [int(s.split('iteration')[1].split(',')[0]) for s in logs] == [2, 4, 6, 8, 10, 12]     # in order, all of them
+
+
+def test_ffdnet_finetune_with_zero_steps_changes_nothing(solver, ffdnet_state_dict):
+    """update_per_iter = 0: no Adam step, the engine keeps its packed weights (never adopts unfilled buffers)"""
+    from adaptivepnp_sci_amd.finetune import ffdnet_online_finetune
+    from adaptivepnp_sci_amd.nets import FFDNetEngine
+    net = make_ffdnet(ffdnet_state_dict)
+    for prec in ('f16x3', 'f32'):
+        eng = FFDNetEngine(net, 2, 16, 24, torch.device('cuda'), precision=prec)
+        eng.in_c8.uniform_(0, 1)
+        if eng.in_c8s is not None:
+            from adaptivepnp_sci_amd import ops
+            ops.c8_to_c8s(eng.in_c8, out=eng.in_c8s)
+        before = eng.forward().clone()
+        ffdnet_online_finetune(net, eng, torch.zeros(4, 16, 24, device='cuda'), torch.ones(2, 4, 16, 24, device='cuda'),
+                               25 / 255, 2e-6, 0)
+        assert torch.equal(eng.forward(), before)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), ffdnet_state_dict[k])
+
+
+def test_admm_tv_iterate_scalars_round_once_from_double(solver):
+    """scipnp_admm_tv_iterate with rho = 0.55 (the FastDVDnet / closed-form constant): the C entry rounds 1/rho and
+    alpha*rho ONCE from double, like the Python scalars of the reference -- float(1/0.55) != 1.0f/0.55f"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib, ops, synth
+    assert np.float32(1 / 0.55) != np.float32(1) / np.float32(0.55)
+    y, Phi, orig = synth.make_problem(32, 32, 4, seed=5)
+    run = solver.AdmmRun(y, Phi, 'tv', True)
+    run.b.uniform_(-0.2, 0.2)
+    a = run._tv_args
+    a.c0, a.c1 = 0.55, 0.3
+    want = torch.empty_like(run.x)
+    ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1 / 0.55, 0.3 * 0.55, out=want)
+    _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(a), None, _lib.stream_ptr()), 'scipnp_admm_tv_iterate')
+    assert torch.equal(run.x, want)

@@ -54,3 +54,27 @@ def test_draw_does_not_hold_the_gil():
             ok = True
             break
     assert ok, (t_busy, t_rng, t_both)
+
+
+def test_prefetch_close_hands_unused_draws_back():
+    """NoisePrefetch.close(): the global generator ends up where a synchronous caller who drew only the draws actually
+    used would have left it (a failed solve must not leave the stream advanced)"""
+    from adaptivepnp_sci_amd.finetune import NoisePrefetch
+    shape = (2, 3, 8, 8)
+    np.random.seed(7)
+    first = legacy_normal(0, 5 / 255, shape)
+    want_next = np.random.normal(size=5)
+    np.random.seed(7)
+    p = NoisePrefetch(shape, 3)
+    got = p.get()
+    time.sleep(0.2)                                   # let the worker draw ahead
+    p.close()
+    assert np.array_equal(got, first)
+    assert np.array_equal(np.random.normal(size=5), want_next)
+    # nothing consumed at all: the state is untouched
+    np.random.seed(9)
+    st = np.random.get_state()
+    p = NoisePrefetch(shape, 2)
+    time.sleep(0.2)
+    p.close()
+    assert np.array_equal(np.random.get_state()[1], st[1]) and np.random.get_state()[2] == st[2]

@@ -83,6 +83,34 @@ class Capture:
         R.compare_psnr = self.orig
 
 
+class GradCapture:
+    """Snapshot of every parameter's .grad at the FIRST optimizer.step() inside the block (the reference calls
+    total_loss.backward(); optimizer.step() -- test_ffdnet_ipol.py:296-297, test_fastdvdnet.py:444-445), in the
+    optimizer's parameter order = model.parameters() order (requires_grad ones)."""
+
+    def __init__(self):
+        self.grads = None
+
+    def __enter__(self):
+        self.orig = torch.optim.Adam.step
+        cap = self
+
+        def step(opt, *a, **k):
+            if cap.grads is None:
+                cap.grads = [p.grad.detach().clone() for g in opt.param_groups for p in g['params']]
+            return cap.orig(opt, *a, **k)
+        torch.optim.Adam.step = step
+        return self
+
+    def __exit__(self, *a):
+        torch.optim.Adam.step = self.orig
+
+    def named(self, model):
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        assert len(names) == len(self.grads)
+        return dict(zip(names, self.grads))
+
+
 def load_ref_ffdnet():
     net = RefFFDNet(in_nc=3, out_nc=3, nc=96, nb=12, act_mode='R')
     sd = torch.load(os.path.join(ref_shim.REF, 'model_zoo', 'ffdnet_color.pth'), map_location='cpu')
@@ -341,29 +369,40 @@ def g_ffdtune():
     warm = _tv_warm(y, Phi, 20)
     logf = io.StringIO()
     seed_all()
-    with Capture() as cap:
+    with Capture() as cap, GradCapture() as gc:
         res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [4], False, [25 / 255],
                                            x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=net,
                                            show_iqa=True, demosaic_method='malvar2004', lr_=2e-6,
                                            inital_iter=1, interval_iter=2, logf=logf, update_=True,
                                            update_per_iter=2)
     ref_it = np.stack(cap.iterates)
+    ref_grads = gc.named(net)
     new_sd = {k: v.detach().clone() for k, v in res[5].state_dict().items()}
     trace = []
     onet = oracle_ffdnet(sd)
     for p in onet.parameters():
         p.requires_grad = True
-    o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [4], [25 / 255], x0_bayer=warm, X_orig=orig,
-                          model_denoise=onet, lr=2e-6, inital_iter=1, interval_iter=2, update=True,
-                          update_per_iter=2, finetune_trace=trace)
+    with GradCapture() as ogc:
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [4], [25 / 255], x0_bayer=warm, X_orig=orig,
+                              model_denoise=onet, lr=2e-6, inital_iter=1, interval_iter=2, update=True,
+                              update_per_iter=2, finetune_trace=trace)
     check('finetune iterates', np.stack(o['theta_iterates']), ref_it)
+    for k, v in ogc.named(onet).items():
+        check(f'first-step gradient {k}', v, ref_grads[k])
+    # the reference's .grad after the first backward(): every bias, the weights of the head, two body layers and the tail
+    # in full, and the L2 norm of every tensor (the full set is 3.4 MB)
+    grads = {}
+    for k, v in ref_grads.items():
+        grads['gradnorm_' + k.replace('.', '_')] = float(torch.linalg.vector_norm(v.double()))
+        if k.endswith('bias') or k in ('model.0.weight', 'model.2.weight', 'model.12.weight', 'model.22.weight'):
+            grads['grad_' + k.replace('.', '_')] = v.numpy()
     osd = o['model'].state_dict()
     for k in new_sd:
         check(f'finetuned {k}', osd[k], new_sd[k])
     delta = {k.replace('.', '_') + '_delta': (new_sd[k] - sd[k]).numpy() for k in new_sd}
     print('   oracle finetune losses:', trace)
     save('ffdnet_finetune_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta=ref_it, rgb=res[0],
-         losses=np.array(trace), **delta)
+         losses=np.array(trace), **delta, **grads)
 
 
 def _ref_fastdvd(seed):
@@ -402,21 +441,35 @@ def g_fastdvd():
     rnet, onet, sd = _ref_fastdvd(0)
     seed_all()
     st = np.random.get_state()
-    with Capture() as cap:
+    with Capture() as cap, GradCapture() as gc:
         res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [4], False, [8 / 255],
                                            x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rnet,
                                            show_iqa=True, demosaic_method='malvar2004', lr_=2e-6, inital_iter=1,
                                            interval_iter=2, logf=logf, update_=True, update_per_iter=2,
                                            update_times=1)
     ref_it = np.stack(cap.iterates)
+    ref_grads = gc.named(rnet)
     np.random.set_state(st)
     noise = np.random.normal(0, 5 / 255, (8, 3, 64, 64))   # the draw the reference made (first use of the RNG)
     np.random.set_state(st)
     trace = []
-    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
-                          lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=2, update_times=1,
-                          finetune_trace=trace)
+    with GradCapture() as ogc:
+        o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                              lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=2, update_times=1,
+                              finetune_trace=trace)
     check('FastDVDnet finetune iterates', np.stack(o['theta_iterates']), ref_it)
+    for k, v in ogc.named(onet).items():
+        check(f'first-step gradient {k}', v, ref_grads[k])
+    # the reference's .grad after the first backward(): norms of all 2.48 M parameters' tensors, and in full one tensor of
+    # every layer type of both DenBlocks (grouped input conv, stride-2 conv, BatchNorm affine, PixelShuffle conv, output conv)
+    full = ('inc.convblock.0.weight', 'inc.convblock.3.weight', 'downc0.convblock.0.weight', 'downc0.convblock.3.convblock.0.weight',
+            'downc1.convblock.0.weight', 'upc1.convblock.1.weight', 'outc.convblock.0.weight', 'outc.convblock.3.weight')
+    grads = {}
+    for k, v in ref_grads.items():
+        key = k.replace('module.', '', 1)
+        grads['gradnorm_' + key.replace('.', '_')] = float(torch.linalg.vector_norm(v.double()))
+        if v.dim() == 1 or any(key.endswith(f) for f in full):
+            grads['grad_' + key.replace('.', '_')] = v.numpy()
     rsd, osd = res[5].state_dict(), o['model'].state_dict()
     worst = max(rel(osd[k], rsd[k]) for k in rsd)
     print(f'   finetuned weights worst rel-L2 {worst:.3e}; losses {trace}')
@@ -424,7 +477,7 @@ def g_fastdvd():
     dn = {k.replace('.', '_') + '_dnorm': float(torch.norm(rsd[k].float() - sd[k.replace('module.', '', 1)].float()))
           for k in rsd if k.endswith('weight') and rsd[k].dim() == 4}
     save('fastdvd_finetune_64x64x8', theta=ref_it, rgb=res[0], noise=noise.astype(np.float64),
-         losses=np.array(trace), **dn)
+         losses=np.array(trace), **dn, **grads)
 
 
 def g_closedform():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box, run UNDER rocprofv3 --pmc by bench.py (child process): a few launches of the kernels whose HBM traffic the
-bench line reports, at the bench's shapes -- the FFDNet body-layer convolution (96 -> 96, 8 frames of 256 x 256) in both
-precisions with the real ffdnet_color weights of layer 1, and the plane-major projection on a 512 x 512 x 8 state."""
+bench line reports, at the bench's shapes -- the FFDNet body-layer convolution (96 -> 96, 8 frames of 256 x 256) in all three
+forms (fp32 direct, fp32 Winograd, split-fp16) with the real ffdnet_color weights of layer 1, and the plane-major projection on a 512 x 512 x 8 state."""
 import os
 import sys
 
@@ -25,6 +25,7 @@ x8 = ops.to_c8(x)
 xs = ops.c8_to_c8s(x8)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pks = ops.pack_conv3x3_split(wt, b, Cin=c, Cout=c, device='cuda')
+pkw = ops.pack_conv3x3_wino(pk, c, c)
 o8, os_ = torch.empty_like(x8), torch.empty_like(xs)
 B, M, N = 8, 256, 256
 th = torch.rand(B, 4, M, N, device='cuda')
@@ -33,6 +34,7 @@ yy, ps = torch.rand(4, M, N, device='cuda') * B / 2, torch.full((4, M, N), B / 2
 xo = torch.empty_like(th)
 for _ in range(4):
     ops.conv3x3_c8(x8, pk, c, relu=True, out=o8)
+    ops.conv3x3_c8w(x8, pkw, c, relu=True, out=o8)
     ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_)
     ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
 torch.cuda.synchronize()
