@@ -260,16 +260,20 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
     assert rel_l2(res[0], gf['rgb']) <= REL_TOL
     assert len(losses) == 2 and np.allclose(losses, gf['losses'][:2], rtol=1e-5), (losses, gf['losses'])
     # gradients of the first backward pass against the reference's .grad (tools/make_golden.py g_fastdvd): BatchNorm
-    # affine gradients and one tensor per layer type in full, every tensor by its norm
+    # affine gradients and one tensor per layer type in full, every tensor by its norm.  Tolerance: in fp32 this gradient
+    # is only determined to ~1e-4 -- the reference network evaluated in float32 and in float64 on the same input differs
+    # by 0.4 - 1.5e-4 on most layers (ReLU masks flip where an activation is within round-off of zero;
+    # tools/probes/fastdvd_grad_conditioning.py) -- so two fp32 implementations cannot be asked to agree to 1e-4 here
+    # (the FFDNet gradients above do: <= 1e-4)
     assert len(grads) == 1
     n_full = 0
     for k0, got in grads[0].items():
         key = k0.replace('.', '_')
         nref = float(gf['gradnorm_' + key])
-        assert abs(float(np.linalg.norm(got.astype(np.float64))) - nref) <= 2e-4 * nref + 1e-12, (k0, nref)
+        assert abs(float(np.linalg.norm(got.astype(np.float64))) - nref) <= 5e-4 * nref + 1e-12, (k0, nref)
         if 'grad_' + key in gf.files:
             n_full += 1
-            assert rel_l2(got, gf['grad_' + key]) <= 1e-4, (k0, rel_l2(got, gf['grad_' + key]))
+            assert rel_l2(got, gf['grad_' + key]) <= 1e-3, (k0, rel_l2(got, gf['grad_' + key]))
     assert n_full >= 2 * (8 + 26), n_full
     sd = net.state_dict()
     for k0 in sd0:
