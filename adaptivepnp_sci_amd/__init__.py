@@ -7,7 +7,7 @@ driven through drop-in equivalents of the reference's solver entry points.
 Importing the package does not touch the GPU; the first solver/op call loads libscipnp.so and
 raises if the library or the device is missing (there is no CPU fallback).
 """
-from .solver import (admm_denoise, admm_denoise_bayer_demosaic_pre, gap_denoise,  # noqa: F401
+from .solver import (admm_denoise, admm_denoise_bayer_demosaic_pre, admm_denoise_gray, gap_denoise,  # noqa: F401
                      twoStageAdmm_denoise_bayer)
 from .denoisers import fastdvdnet_denoiser_full_tensor_v2, ffdnet_rgb_denoise_full_tensor, test_ddnet  # noqa: F401
 from .ddnet import DDnet  # noqa: F401

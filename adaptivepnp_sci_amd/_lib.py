@@ -101,6 +101,10 @@ SIGNATURES = {
     'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_gray_net_input': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _vp]),
+    'scipnp_gray_net_output': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_cube_to_frames': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_frames_to_cube': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_pack_input': (_int, [_vp, _flt, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_ffdnet_unpack_output': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_cube_sum3': (_int, [_vp, _vp, _int, _int, _int, _vp]),

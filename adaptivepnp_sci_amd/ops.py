@@ -484,6 +484,34 @@ def cube_sum3(cube):
     return out
 
 
+def gray_net_input(x, b, sigma, in_c8):
+    B, _, M, N = x.shape
+    _call('scipnp_gray_net_input', _p(x, 'x'), _p(b, 'b'), float(np.float32(sigma)), _p(in_c8, 'in_c8'), M, N, B, _stream())
+    return in_c8
+
+
+def gray_net_output(out_c8, theta_raw):
+    B, _, M, N = theta_raw.shape
+    _call('scipnp_gray_net_output', _p(out_c8, 'out_c8'), _p(theta_raw, 'theta_raw'), M, N, B, _stream())
+    return theta_raw
+
+
+def cube_to_frames(cube):
+    """(H,W,B) -> [B][H][W]"""
+    H, W, B = cube.shape
+    out = torch.empty(B, H, W, device=cube.device, dtype=F32)
+    _call('scipnp_cube_to_frames', _p(cube, 'cube'), _p(out, 'frames'), H, W, B, _stream())
+    return out
+
+
+def frames_to_cube(frames):
+    """[B][H][W] -> (H,W,B)"""
+    B, H, W = frames.shape
+    out = torch.empty(H, W, B, device=frames.device, dtype=F32)
+    _call('scipnp_frames_to_cube', _p(frames, 'frames'), _p(out, 'cube'), H, W, B, _stream())
+    return out
+
+
 def split_overflow(reset=True):
     """True if the split-fp16 kernels saw a value outside fp16's range since the last reset (synchronises)."""
     flag = C.c_int(0)

@@ -325,6 +325,124 @@ class AdmmRun:
         return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
 
 
+GRAY_DENOISERS = ('tv_gray', 'ffdnet_gray')
+
+
+class GrayAdmmRun:
+    """Grayscale (non-Bayer) PnP-ADMM, SURVEY 8(f) rank 4 -- PARITY UNPINNED: the reference has no grayscale solver.  This is
+    its one-stage loop (dvp...:385-407, :500-509) with the Bayer split and the demosaic removed, i.e. the ADMM of the
+    PnP-SCI family the reference derives from:
+        v = theta + b;  x = v + lambda * Phi ((y - sum_t v Phi) / (Phi_sum + gamma));  theta = clip(D(x - b), 0, 1);
+        b = b - (x - theta);   reports x
+    with D = Chambolle TV on the full frames (weight 0.1, 5 iterations, 'tv_gray') or the model zoo's FFDNet-gray per frame
+    ('ffdnet_gray', model_zoo/ffdnet_gray.pth, pinned against the reference network class in tests/golden/ffdnet_gray_*).
+    The projection / dual update / PSNR partials are the plane-major kernels (per pixel: any consistent layout).  With
+    FFDNet-gray the state lives pixel-unshuffled [B][4][M][N] -- exactly FFDNet's own 2x2 unshuffle -- so the network input
+    is the state plus the sigma map; with TV the state is the frames themselves, [B][H][W]."""
+
+    two_stage = False
+    update_ = False
+    update_i = 0
+    update_times = -1
+    inital_iter = 1
+    interval_iter = 5
+    noise_source = None
+    phi_events = None
+
+    def __init__(self, y, Phi, denoiser, x0=None, X_orig=None, model=None, show_iqa=True, _lambda=1, gamma=0.01,
+                 Phi_sum=None, conv_precision=None):
+        denoiser = str(denoiser).lower()
+        if denoiser == 'ffdnet':
+            denoiser = 'ffdnet_gray'
+        if denoiser not in GRAY_DENOISERS:
+            raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+        _lib.load()
+        _lib.require_gpu()
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.denoiser, self.model = denoiser, model
+        Phi_d, y_d = _dev(Phi, self.device), _dev(y, self.device)
+        if Phi_d.dim() != 3 or y_d.shape != Phi_d.shape[:2] or Phi_d.shape[0] % 2 or Phi_d.shape[1] % 2:
+            raise ValueError(f'expected y (H,W) and Phi (H,W,B) with even H,W; got {tuple(y_d.shape)} {tuple(Phi_d.shape)}')
+        self.H, self.W, self.B = Phi_d.shape
+        self.M, self.N = self.H // 2, self.W // 2
+        B, M, N, H, W = self.B, self.M, self.N, self.H, self.W
+        self.unshuffled = denoiser == 'ffdnet_gray'
+        self.Phi = self._state(Phi_d)
+        self.y = ops.y_to_meas(y_d) if self.unshuffled else y_d.reshape(4, M, N)
+        self.Phisum, x0_s = ops.pm_setup(self.Phi, self.y, want_x0=x0 is None)
+        if Phi_sum is not None:
+            ps = np.array(Phi_sum.detach().cpu().numpy() if torch.is_tensor(Phi_sum) else Phi_sum, dtype=np.float32)
+            if ps.shape != (H, W):
+                raise ValueError(f'Phi_sum must have the shape of y {(H, W)}, got {ps.shape}')
+            ps[ps == 0] = 1
+            ps = _dev(ps, self.device)
+            self.Phisum = ops.y_to_meas(ps) if self.unshuffled else ps.reshape(4, M, N)
+        if x0 is not None:
+            x0_s = self._state(_dev(x0, self.device))
+        self.theta = x0_s
+        self.x = torch.empty_like(x0_s)
+        self.b = torch.zeros_like(x0_s)
+        self.theta_raw = torch.empty_like(x0_s)
+        self.orig = None
+        if X_orig is not None:
+            self.orig = self._state(_dev(X_orig, self.device))
+        self.iqa = bool(show_iqa and X_orig is not None)
+        self._lambda, self.gamma = _lambda, gamma
+        self.sse_rows = []
+        self.k = 0
+        if self.unshuffled:
+            if model is None:
+                raise ValueError("denoiser 'ffdnet_gray' needs model= (an FFDNet(in_nc=1, out_nc=1, nc=64, nb=15) with the "
+                                 'ffdnet_gray weights loaded)')
+            self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
+            if self.eng.in_ch != 5:
+                raise ValueError('ffdnet_gray needs the grayscale network (5 -> nc -> 4 channels)')
+        else:
+            if (H * W) % 16:
+                raise ValueError('tv_gray needs H*W to be a multiple of 16')
+            self.plan = ops.TvPlan(H, W, B, 5, self.device)
+
+    def _state(self, cube):
+        """(H,W,B) device cube -> the run's state layout, as a [B][4][M][N] view for the per-pixel kernels"""
+        if self.unshuffled:
+            return ops.mosaic_to_state(cube)
+        return ops.cube_to_frames(cube).view(self.B, 4, self.M, self.N)
+
+    def _cube(self, state):
+        return ops.state_to_mosaic(state) if self.unshuffled else ops.frames_to_cube(state.view(self.B, self.H, self.W))
+
+    def step(self, nsig, last=False):
+        B, M, N, H, W = self.B, self.M, self.N, self.H, self.W
+        ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x)
+        if self.unshuffled:
+            ops.gray_net_input(self.x, self.b, nsig, self.eng.in_c8)
+            if self.eng.in_c8s is not None:
+                ops.c8_to_c8s(self.eng.in_c8, out=self.eng.in_c8s)
+            ops.gray_net_output(self.eng.forward(), self.theta_raw)
+        else:
+            ops.tv_chambolle(self.x.view(B, H, W), self.b.view(B, H, W), -1.0, self.theta_raw.view(B, H, W), self.plan, 0.1)
+        part = None
+        if self.iqa:
+            part = torch.empty(ops.sse_nblocks(self.x.numel()), dtype=torch.float64, device=self.device)
+            self.sse_rows.append(part)
+        ops.pm_dual_update(self.theta_raw, self.x, self.theta, self.b, -1.0, self.orig if self.iqa else None, part, which=1)
+        if ITERATE_HOOK is not None:
+            ITERATE_HOOK(self.k, self._cube(self.x))
+        self.k += 1
+
+    psnr_all = AdmmRun.psnr_all
+
+    def result_cube(self):
+        return self._cube(self.x)
+
+    def final_report(self):
+        if self.orig is None:
+            return [], []
+        if self.unshuffled:
+            return frame_metrics(self.orig, self.x)
+        return frame_metrics(ops.mosaic_to_state(self._cube(self.orig)), ops.mosaic_to_state(self._cube(self.x)))
+
+
 def _count_finetune_events(update_, two_stage, denoiser, total, inital_iter, interval_iter, update_times, k0=0, done=0):
     """number of FastDVDnet finetune events a schedule of `total` iterations will fire (the gate of _cnn_step, evaluated
     ahead of time)"""
@@ -435,7 +553,7 @@ def _run_schedule(run, sigma, iter_max, log=None):
                     k += 1
             log.poll(block=True)
         return
-    split = run.denoiser != 'tv' and run.eng.precision == 'f16x3'
+    split = getattr(run, 'eng', None) is not None and run.eng.precision == 'f16x3'
     own_noise = None
     if run.noise_source is None:
         n_events = _count_finetune_events(run.update_, run.two_stage, run.denoiser, total, run.inital_iter, run.interval_iter,
@@ -542,6 +660,25 @@ def _one_stage(y_bayer, Phi_bayer, _lambda, gamma, denoiser, iter_max, noise_est
     return ops.to_host(ops.rgb_to_cube(run.out_rgb)), x_bayer_np, psnr_, ssim_, psnr_all, model
 
 
+def admm_denoise_gray(y, Phi, Phi_sum=None, _lambda=1, gamma=0.01, denoiser='tv_gray', iter_max=50, noise_estimate=True,
+                      sigma=None, x0=None, X_orig=None, model=None, show_iqa=True, logf=None):
+    """Grayscale (non-Bayer) PnP-ADMM on a (H,W,B) cube, see `GrayAdmmRun` (parity unpinned: the reference has no such
+    solver).  denoiser: 'tv_gray' or 'ffdnet_gray' (alias 'ffdnet'; model = FFDNet(in_nc=1, out_nc=1,
+    nc=64, nb=15) with model_zoo/ffdnet_gray.pth).  Arguments and log text follow `admm_denoise_bayer_demosaic_pre`;
+    returns (x (H,W,B), psnr per frame, ssim per frame, psnr_all)."""
+    logf = logf or _NullLog()
+    sigma, iter_max = _as_lists(sigma, iter_max)
+    run = GrayAdmmRun(y, Phi, denoiser, x0, X_orig, model, show_iqa, _lambda, gamma, Phi_sum)
+    _run_schedule(run, sigma, iter_max, _LogStream(run, run.denoiser, noise_estimate, logf, False))
+    psnr_all = run.psnr_all()
+    psnr_, ssim_ = run.final_report()
+    return ops.to_host(run.result_cube()), psnr_, ssim_, psnr_all
+
+
+def _is_gray(denoiser):
+    return str(denoiser).lower() in GRAY_DENOISERS + ('ffdnet',)
+
+
 def _bind(fn, y, Phi, denoiser, kw):
     """the public entry point's own defaults for everything the alias caller left out"""
     import inspect
@@ -554,7 +691,10 @@ def admm_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
     """PnP-SCI-style alias named by the task brief: (y, Phi, Phi_sum, denoiser, ...) -> two-stage ADMM; keyword arguments
     as `twoStageAdmm_denoise_bayer`.  Phi_sum (H,W), if given, IS the normaliser of the Euclidean projection (after the
     reference's zeros -> 1, :74-75): pass the sum of Phi over the frames to reproduce `twoStageAdmm_denoise_bayer` bit for
-    bit, or e.g. the sum of Phi**2 for non-binary masks.  None: computed on the device as the reference does (:72-75)."""
+    bit, or e.g. the sum of Phi**2 for non-binary masks.  None: computed on the device as the reference does (:72-75).
+    denoiser 'tv_gray' / 'ffdnet_gray': the grayscale (non-Bayer) mode, `admm_denoise_gray` (its keyword arguments)."""
+    if _is_gray(denoiser):
+        return admm_denoise_gray(y, Phi, Phi_sum, denoiser=denoiser, **kw)
     a = _bind(twoStageAdmm_denoise_bayer, y, Phi, denoiser, kw)
     return _two_stage(a['y_bayer'], a['Phi_bayer'], a['denoiser'], a['iter_max'], a['noise_estimate'], a['sigma'],
                       a['x0_bayer'], a['X_orig'], a['model_denoise'], a['model_demosaic'], a['show_iqa'],
@@ -564,7 +704,9 @@ def admm_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
 
 def gap_denoise(y, Phi, Phi_sum=None, denoiser='tv', **kw):
     """Alias for the one-stage ("GAP form") solver `admm_denoise_bayer_demosaic_pre`; Phi_sum as in `admm_denoise`
-    (reference :359-362)."""
+    (reference :359-362); the gray denoisers go to `admm_denoise_gray`."""
+    if _is_gray(denoiser):
+        return admm_denoise_gray(y, Phi, Phi_sum, denoiser=denoiser, **kw)
     a = _bind(admm_denoise_bayer_demosaic_pre, y, Phi, denoiser, kw)
     return _one_stage(a['y_bayer'], a['Phi_bayer'], a['_lambda'], a['gamma'], a['denoiser'], a['iter_max'],
                       a['noise_estimate'], a['sigma'], a['x0_bayer'], a['X_orig'], a['model'], a['show_iqa'],

@@ -445,6 +445,21 @@ int scipnp_ffdnet_unpack_output(const float* out_c8, float* y, int n, int C, int
 int scipnp_cube_sum3(const float* cube, float* out, int H, int W, int B, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Grayscale (non-Bayer) PnP-ADMM mode -- csrc/gray.hip.  The reference has no grayscale solver: this is
+ * its one-stage loop (dvp...:385-407, :500-509) with the Bayer split and the demosaic removed; projection, dual update
+ * and PSNR partials are scipnp_pm_project / scipnp_pm_dual_update on any consistent per-pixel layout.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* FFDNet-gray input from the pixel-unshuffled state [B][4][M][N]: in_c8 [B][1][M][N][8] = {x - b (4 values), sigma, 0,0,0}
+ * (the 2x2 pixel-unshuffle of network_ffdnet.py:60-62 is exactly that state layout) */
+int scipnp_gray_net_input(const float* x, const float* b, float sigma, float* in_c8, int M, int N, int B, scipnp_stream_t s);
+/* FFDNet-gray output c8 [B][1][M][N][8] (4 real channels = the pixel-shuffle phases) -> state [B][4][M][N] */
+int scipnp_gray_net_output(const float* out_c8, float* theta_raw, int M, int N, int B, scipnp_stream_t s);
+/* (H,W,B) cube, frame index fastest (the reference's array layout) <-> [B][H][W] frames (TV prior on full frames) */
+int scipnp_cube_to_frames(const float* cube, float* frames, int H, int W, int B, scipnp_stream_t s);
+int scipnp_frames_to_cube(const float* frames, float* cube, int H, int W, int B, scipnp_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * DDnet deep demosaicking -- glue around scipnp_conv3x3_c8 / _c8s.
  * reference: models/network_demosaicking.py:381-463 (DDnet.forward), :186-244, :310-379 (DenBlocks),
  *            packages/DDnet/DDnet_test.py:166-216 (circular 5-frame window), dvp...:192-194, :242-244 (call sites)

@@ -4,6 +4,10 @@ PyTorch-CPU, returning every iterate so that the HIP path can be compared step b
 two_stage_admm  <- dvp_linear_inv_2_stage_ADMM_tensor_online.py:40-324  (twoStageAdmm_denoise_bayer)
 one_stage_admm  <- dvp_linear_inv_2_stage_ADMM_tensor_online.py:326-552 (admm_denoise_bayer_demosaic_pre)
 
+one_stage_admm_gray -- PARITY UNPINNED: the reference has no grayscale (non-Bayer) solver; this is
+                  the one-stage loop above with the Bayer split and the demosaic removed, restated here only so that the
+                  HIP gray mode has a CPU statement of the same arithmetic to be compared with.
+
 Semantics that are easy to lose and are kept on purpose (all verified bit-for-bit against the
 imported reference by tools/make_golden.py):
   * at entry x, theta and the start point are ONE tensor (:87-89 / :375-377).  On the CNN branches
@@ -178,3 +182,44 @@ def one_stage_admm(y_bayer, Phi_bayer, _lambda=1, gamma=0.01, denoiser='tv', ite
     x_bayer = ops.bayer_merge(x).numpy()
     return dict(x_iterates=iterates, psnr_all=psnr_all, x_bayer=x_bayer,
                 rgb=None if rgb_out is None else rgb_out.numpy(), model=model)
+
+
+def one_stage_admm_gray(y, Phi, _lambda=1, gamma=0.01, denoiser='tv_gray', iter_max=50, sigma=None, x0=None, X_orig=None,
+                        model=None, Phi_sum=None):
+    """PARITY UNPINNED (no reference function exists): grayscale PnP-ADMM on a (H,W,B) cube -- the reference's one-stage
+    loop (dvp...:385-407, :500-509) without the Bayer split / demosaic:
+        x = (theta+b) + lambda * At((y - A(theta+b)) / (Phi_sum + gamma));  theta = clip(D(x - b), 0, 1);  b = b - (x - theta)
+    D = skimage-0.18 Chambolle TV on the frames (weight 0.1, 5 iterations, multichannel) or FFDNet-gray per frame.
+    Returns dict(x_iterates, psnr_all, x)."""
+    y = torch.as_tensor(y)
+    Phi = torch.as_tensor(Phi)
+    sigma, iter_max = _as_list(sigma, iter_max)
+    if Phi_sum is None:
+        Phi_sum = torch.sum(Phi, dim=2)
+    else:
+        Phi_sum = torch.as_tensor(Phi_sum).clone()
+    Phi_sum[Phi_sum == 0] = 1
+    x = theta = ops.transpose_At(y, Phi) if x0 is None else torch.as_tensor(x0).clone()
+    b = torch.zeros_like(x)
+    iterates, psnr_all = [], []
+    for stage, nsig in enumerate(sigma):
+        for _ in range(iter_max[stage]):
+            yb = ops.forward_A(theta + b, Phi)
+            x = theta + b + _lambda * ops.transpose_At((y - yb) / (Phi_sum + gamma), Phi)
+            if denoiser == 'tv_gray':
+                theta = torch.from_numpy(tv_chambolle_multichannel((x - b).numpy(), 0.1, n_iter_max=5))
+            elif denoiser == 'ffdnet_gray':
+                v = x - b
+                theta = torch.empty_like(v)
+                with torch.no_grad():
+                    for t in range(v.shape[2]):
+                        frame = v[:, :, t][None, None]
+                        theta[:, :, t] = model(frame, torch.full((1, 1, 1, 1), nsig).type_as(frame))[0, 0]
+            else:
+                raise ValueError('Unsupported denoiser {}!'.format(denoiser))
+            theta = torch.clip(theta, 0, 1)
+            b = b - (x - theta)
+            iterates.append(x.numpy().copy())
+            if X_orig is not None:
+                psnr_all.append(psnr_np(X_orig, iterates[-1]))
+    return dict(x_iterates=iterates, psnr_all=psnr_all, x=x.numpy())

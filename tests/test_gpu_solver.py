@@ -536,3 +536,67 @@ def test_admm_tv_iterate_scalars_round_once_from_double(solver):
     ops.pm_project(run.theta, run.b, run.Phi, run.y, run.Phisum, 0, 1 / 0.55, 0.3 * 0.55, out=want)
     _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(a), None, _lib.stream_ptr()), 'scipnp_admm_tv_iterate')
     assert torch.equal(run.x, want)
+
+
+# ---------------------------------------------------------------------------------------------- grayscale mode (8f rank 4)
+def _gray_net():
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from oracle.nets import OracleFFDNet
+    gw = load_gold('ffdnet_gray_weights')
+    sd = {k: torch.from_numpy(gw[k]) for k in gw.files}
+    net, onet = FFDNet(in_nc=1, out_nc=1, nc=64, nb=15), OracleFFDNet(in_nc=1, out_nc=1, nc=64, nb=15)
+    net.load_state_dict(sd)
+    onet.load_state_dict(sd)
+    return net, onet.eval()
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 8), (48, 80, 5)])
+def test_gray_admm_tv_is_the_oracle_bit_for_bit(solver, shape):
+    """grayscale (non-Bayer) ADMM-TV -- PARITY UNPINNED against the reference (it has no such solver), pinned against the
+    oracle's restatement of the one-stage loop without the Bayer split: projection, skimage-order Chambolle on the FULL
+    frames and the dual update are bit-identical, so every iterate is"""
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    H, W, B = shape
+    y, Phi, orig = synth.make_problem(H, W, B, seed=21)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    logf = io.StringIO()
+    x, psnr_, ssim_, psnr_all = solver.admm_denoise_gray(y, Phi, None, 1, 0.01, 'tv_gray', [6], False, [0], X_orig=orig, logf=logf)
+    o = OS.one_stage_admm_gray(y, Phi, 1, 0.01, 'tv_gray', [6], [0], X_orig=orig)
+    for k in range(6):
+        assert np.array_equal(tr.it[k], o['x_iterates'][k]), (k, rel_l2(tr.it[k], o['x_iterates'][k]))
+    assert np.array_equal(x, o['x']) and np.abs(np.array(psnr_all) - np.array(o['psnr_all'])).max() <= 1e-9
+    assert len(psnr_) == B and len(ssim_) == B
+    from oracle import metrics as OMt
+    assert np.abs(np.array(psnr_) - np.array(OMt.psnr_frames(orig, o['x']))).max() <= PSNR_TOL
+    assert np.abs(np.array(ssim_) - np.array(OMt.ssim_frames(orig, o['x']))).max() <= 1e-6
+    assert logf.getvalue().count('ADMM-TV_GRAY iteration') == 3
+    # through the north_star alias, with the normaliser handed in
+    via = solver.gap_denoise(y, Phi, Phi.sum(2), 'tv_gray', iter_max=[6], sigma=[0], X_orig=orig, logf=io.StringIO())
+    assert np.array_equal(via[0], x)
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_gray_admm_ffdnet_gray_iterates(solver, precision, monkeypatch):
+    """grayscale ADMM with the model zoo's FFDNet-gray (weights pinned against the reference network class, golden
+    ffdnet_gray_*): per-iterate rel-L2 <= 1e-5, PSNR <= 1e-4 dB against the oracle; the solver itself is parity-unpinned"""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    net, onet = _gray_net()
+    y, Phi, orig = synth.make_problem(64, 96, 6, seed=22)
+    warm = solver.admm_denoise_gray(y, Phi, None, denoiser='tv_gray', iter_max=[10], sigma=[0], logf=io.StringIO())[0]
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    x, psnr_, ssim_, psnr_all = solver.admm_denoise(y, Phi, None, 'ffdnet_gray', iter_max=[3, 2], sigma=[30 / 255, 15 / 255],
+                                                    x0=warm, X_orig=orig, model=net, logf=io.StringIO())
+    o = OS.one_stage_admm_gray(y, Phi, 1, 0.01, 'ffdnet_gray', [3, 2], [30 / 255, 15 / 255], x0=warm, X_orig=orig, model=onet)
+    for k in range(5):
+        assert rel_l2(tr.it[k], o['x_iterates'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], o['x_iterates'][k]))
+    assert np.abs(np.array(psnr_all) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+    assert psnr_all[-1] > psnr_all[0] - 3                      # sanity: the loop runs on image-like data
+    with pytest.raises(ValueError):
+        solver.admm_denoise_gray(y, Phi, None, denoiser='ffdnet_gray', iter_max=[1], sigma=[0.1])      # no model
+    with pytest.raises(ValueError):
+        solver.admm_denoise_gray(y, Phi, None, denoiser='bm3d', iter_max=[1], sigma=[0.1])

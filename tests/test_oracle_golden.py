@@ -203,3 +203,16 @@ def test_ffdnet_gray_forward_golden():
         for tag, n in (('2x64x96', 2), ('1x37x50', 1)):
             out = net(T(g[f'in_{tag}']), torch.full((n, 1, 1, 1), 40 / 255.))
             assert rel_l2(out, g[f'out_{tag}_s40']) == 0
+
+
+def test_gray_oracle_projection_is_the_pinned_bayer_projection():
+    """oracle.one_stage_admm_gray (PARITY UNPINNED: the reference has no grayscale solver) shares everything but the
+    Bayer split with the pinned one-stage oracle: its first iterate (projection of the start point, before any prior)
+    must equal the Bayer solver's, pixel for pixel, and a second run is deterministic"""
+    from adaptivepnp_sci_amd import synth
+    y, Phi, orig = synth.make_problem(32, 48, 6, seed=3)
+    g = OS.one_stage_admm_gray(y, Phi, 1, 0.01, 'tv_gray', [2], [0], X_orig=orig)
+    bay = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [1], [0], X_orig=orig)
+    assert np.array_equal(g['x_iterates'][0], bay['x_iterates'][0])
+    g2 = OS.one_stage_admm_gray(y, Phi, 1, 0.01, 'tv_gray', [2], [0], X_orig=orig, Phi_sum=Phi.sum(2))
+    assert np.array_equal(g2['x'], g['x']) and len(g['psnr_all']) == 2
