@@ -87,26 +87,45 @@ __device__ __forceinline__ float torch_contig_sum(int nB, F term) {
     return f;
 }
 
-// The same two orders with the frame count known only at run time (any nB < 64), `term(i)` a memory load; T is float or
-// float4 (four independent sums).  The lane sums follow ATen's row_sum for ANY number of 8-float vectors: four
-// accumulators over the full groups of four vectors, the remaining vectors appended to accumulator 0, then
-// ((c0+c1)+c2)+c3 -- for up to four vectors that is the sequential sum of (2) above.  At nB >= 64 the strided order
-// enters the next level of ATen's cascade (level step 16 groups of four), which is not restated here.
-constexpr int TORCH_SUM_RT_MAX = 63;
+// The same two orders with the frame count known only at run time, `term(i)` a memory load; T is float or float4 (four
+// independent sums).  Both follow ATen's cascade_sum (SumKernel.cpp, torch 2.10: row_sum = multi_row_sum over groups of
+// four with level step 16):
+//   strided: element i feeds accumulator i % 4; after every 16 groups of four the accumulators are flushed into the next
+//            level (and that one after 16 flushes, ...); leftovers of the last partial run stay in level 0; the levels are
+//            added to level 0 in order, the tail elements (past the last full group of four) to accumulator 0, result
+//            ((a0+a1)+a2)+a3.  Below 64 addends no flush ever happens and this is the plain four-accumulator sum of (1).
+//   contiguous: the same over 8-float VECTORS per lane (the flush needs 64 vectors = 512 addends: not restated, hence
+//            TORCH_SUM_RT_MAX), then the lane sums are added to the tail sum in lane order, as in (2).
+constexpr int TORCH_SUM_RT_MAX = 511;
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4_add(float a, float b) { return a + b; }
 
 template <typename T, typename F>
 __device__ __forceinline__ T torch_strided_sum_rt(int nB, T zero, F term) {
-    T a0 = zero, a1 = zero, a2 = zero, a3 = zero;
-    const int n4 = nB & ~3;
-    for (int i = 0; i < n4; i += 4) {
+    T a0 = zero, a1 = zero, a2 = zero, a3 = zero;           // level 0
+    T u0 = zero, u1 = zero, u2 = zero, u3 = zero;           // level 1 (level 2 would need 256 groups = 1024 addends)
+    const int ngrp = nB >> 2;
+    int g = 0;
+    for (; g + 16 <= ngrp; g += 16) {
+        for (int j = 0; j < 16; ++j) {
+            const int i = 4 * (g + j);
+            a0 = f4_add(a0, term(i));
+            a1 = f4_add(a1, term(i + 1));
+            a2 = f4_add(a2, term(i + 2));
+            a3 = f4_add(a3, term(i + 3));
+        }
+        u0 = f4_add(u0, a0); u1 = f4_add(u1, a1); u2 = f4_add(u2, a2); u3 = f4_add(u3, a3);
+        a0 = zero; a1 = zero; a2 = zero; a3 = zero;
+    }
+    for (; g < ngrp; ++g) {
+        const int i = 4 * g;
         a0 = f4_add(a0, term(i));
         a1 = f4_add(a1, term(i + 1));
         a2 = f4_add(a2, term(i + 2));
         a3 = f4_add(a3, term(i + 3));
     }
-    for (int i = n4; i < nB; ++i) a0 = f4_add(a0, term(i));
+    if (ngrp >= 16) { a0 = f4_add(a0, u0); a1 = f4_add(a1, u1); a2 = f4_add(a2, u2); a3 = f4_add(a3, u3); }
+    for (int i = 4 * ngrp; i < nB; ++i) a0 = f4_add(a0, term(i));
     return f4_add(f4_add(f4_add(a0, a1), a2), a3);
 }
 

@@ -47,11 +47,13 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
         coef = -1.0f; sign = -1.0f;                         // theta = TV(x - b),     b -= x - theta
     }
     if (rc) return rc;
-    // planes up to 128 x 128: TV and the dual update are one launch (theta_raw stays untouched)
+    // planes up to 256 columns take the banded TV kernel (many workgroups per plane) followed by the dual update; narrower
+    // problems that leave the chip idle either way keep the one-launch whole-plane form with the dual update in its epilogue
     int nstd = 0;
     scipnp_sse_partials(a->x, a->x, (size_t)4 * M * N * B, nullptr, &nstd, s);          // size query: pm_dual_update's grid
     const bool want_sse = a->sse_part && a->orig;
-    if (tv_plane_dual_fits(M, N, 4 * B, nstd, want_sse)) {
+    const bool banded = N <= 256 && a->tv_iters <= 5 && (long long)4 * B * ((M + 31) / 32) >= 128;
+    if (!banded && tv_plane_dual_fits(M, N, 4 * B, nstd, want_sse)) {
         if (nblocks) *nblocks = nstd;
         return tv_plane_dual(a->x, a->b, coef, a->theta, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->orig,
                              want_sse ? a->sse_part : nullptr, a->two_stage ? 0 : 1, sign, nstd, (hipStream_t)s);

@@ -346,6 +346,180 @@ tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
     }
 }
 
+// ---- banded variant (round 2): ONE launch for all iterations with MANY workgroups per channel.  A workgroup owns a band
+// of RB rows of one channel (all columns, N <= 256) and computes it together with a halo of TVB_HALO rows on either side:
+// five Chambolle iterations have a dependency cone of 4 rows up (p at r-1) and 4 rows down (out at r+1), so the band's own
+// rows come out exactly as the whole-plane computation gives them -- same float32 operations per pixel, bit-identical
+// `out` -- while rows of the halo go stale one per iteration from the artificial boundary inwards and are never used.
+// The stop test needs the channel's global energy of every iteration: kernel A runs all iterations unconditionally, leaves
+// the band's own-row partial sums of every iteration in global memory and stores the `out` of the LAST iteration
+// (speculating that the channel does not stop early: with eps = 2e-4 and 5 iterations it almost never does); kernel B
+// evaluates skimage's stop test per channel from the partials of all its bands and, for a channel that did stop at
+// iteration i* < n-1, recomputes its bands up to i* and overwrites theta.  Geometry: thread = (column, strip of R rows);
+// row neighbours inside a strip are register neighbours, column neighbours lane neighbours, strip / wave seams go through LDS.
+constexpr int TVB_HALO = 4;
+
+template <int COLS, int R, int STRIPS>
+__device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, float coef, float* th, int M, int N,
+                                            int n_iter, int a_lo, int a_hi, int ext_lo, float tau_over_w, double* part_out) {
+    constexpr int WPS = COLS / 64;                       // waves per strip
+    __shared__ float s_p0e[STRIPS + 1][COLS];            // [s+1]: p0 on the last row of strip s
+    __shared__ float s_oe[STRIPS + 1][COLS];             // [s]:   out on the first row of strip s
+    __shared__ float s_p1e[STRIPS][WPS][R];              // p1 of a wave's last column (read by the next wave's first)
+    __shared__ float s_oce[STRIPS][WPS][R];              // out of a wave's first column (read by the previous wave's last)
+    __shared__ double s_red[2][COLS * STRIPS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = tid & (COLS - 1), strip = tid / COLS, wcol = col >> 6;
+    const int r0 = ext_lo + strip * R;
+
+    float v[R], p0[R], p1[R], out[R];
+    bool ok[R], own[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = r0 + k;
+        ok[k] = col < N && r < M;
+        own[k] = ok[k] && r >= a_lo && r < a_hi;
+        v[k] = ok[k] ? tv_input(xc, bc, coef, (size_t)r * N + col) : 0.f;
+        p0[k] = 0.f;
+        p1[k] = 0.f;
+        out[k] = v[k];
+    }
+    if (strip == 0) { s_p0e[0][col] = 0.f; s_oe[STRIPS][col] = 0.f; }      // artificial band edges: defined (unused) values
+
+    for (int it = 0; it < n_iter; ++it) {
+        double a1 = 0.0, a2 = 0.0;
+        if (it > 0) {           // the seams of p were published before the barrier that closed iteration it-1
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                float left = __shfl_up(p1[k], 1, 64);
+                if (lane == 0) left = s_p1e[strip][wcol > 0 ? wcol - 1 : 0][k];
+                float up = s_p0e[strip][col];
+                if (k > 0) up = p0[k > 0 ? k - 1 : 0];
+                float d = -(p0[k] + p1[k]);
+                if (r0 + k > 0) d = d + up;
+                if (col > 0) d = d + left;
+                out[k] = v[k] + d;
+                if (own[k]) a1 += (double)(d * d);
+            }
+        }
+        if (it == n_iter - 1) break;          // only `out` of the last iteration is used (its energy decides nothing)
+        s_oe[strip][col] = out[0];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) s_oce[strip][wcol][k] = out[k];
+        }
+        __syncthreads();                      // (also orders thread 0's read of s_red below before the next writes)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            float right = __shfl_down(out[k], 1, 64);
+            if (lane == 63) right = s_oce[strip][wcol + 1 < WPS ? wcol + 1 : wcol][k];
+            float down = s_oe[strip + 1][col];
+            if (k + 1 < R) down = out[k + 1 < R ? k + 1 : k];
+            const float g0 = (r0 + k < M - 1) ? (down - out[k]) : 0.f;
+            const float g1 = (col < N - 1) ? (right - out[k]) : 0.f;
+            float nrm = sqrtf(g0 * g0 + g1 * g1);
+            if (own[k]) a2 += (double)nrm;
+            nrm = nrm * tau_over_w;
+            nrm = nrm + 1.f;
+            p0[k] = (p0[k] - 0.25f * g0) / nrm;
+            p1[k] = (p1[k] - 0.25f * g1) / nrm;
+            if (k == R - 1) s_p0e[strip + 1][col] = p0[k];
+            if (lane == 63) s_p1e[strip][wcol][k] = p1[k];
+        }
+        if (part_out) {         // kernel A: the band's own-row partial energy sums of this iteration
+            for (int off = 32; off > 0; off >>= 1) {
+                a1 += __shfl_down(a1, off, 64);
+                a2 += __shfl_down(a2, off, 64);
+            }
+            if (lane == 0) { s_red[0][wave] = a1; s_red[1][wave] = a2; }
+        }
+        __syncthreads();                      // publishes the seams of p (and the wave partials)
+        if (part_out && tid == 0) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < COLS * STRIPS / 64; ++i) { s1 += s_red[0][i]; s2 += s_red[1][i]; }
+            part_out[2 * it] = s1;
+            part_out[2 * it + 1] = s2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (own[k]) th[(size_t)(r0 + k) * N + col] = out[k];
+}
+
+// kernel A (STAGE 0): all iterations + partials; kernel B (STAGE 1): stop test per channel, recomputation if it stopped early.
+// NOTE on the energy of the LAST iteration: skimage evaluates the stop test after the p-update of every iteration including
+// the last, but nothing depends on that value (the loop ends either way), so its norm sum is not needed.
+template <int COLS, int R, int STRIPS, int STAGE>
+__global__ void __launch_bounds__(COLS* STRIPS)
+tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta, int M, int N,
+               int n_iter, int RB, int nbands, double weight, float tau_over_w, double eps, double* __restrict__ part,
+               int32_t* __restrict__ stop_iter) {
+    const int c = blockIdx.x / nbands, band = blockIdx.x - c * nbands;
+    const size_t chan = (size_t)c * M * N;
+    const int a_lo = band * RB, a_hi = min(M, a_lo + RB);
+    const int ext_lo = max(0, a_lo - TVB_HALO);
+    const float* xc = x + chan;
+    const float* bc = b ? b + chan : nullptr;
+    if (STAGE == 0) {
+        tv_band_run<COLS, R, STRIPS>(xc, bc, coef, theta + chan, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
+                                     part + ((size_t)c * nbands + band) * 2 * n_iter);
+        return;
+    }
+    // ---- stop test of the channel (every workgroup of the channel evaluates it identically)
+    __shared__ int s_stop_at;
+    if (threadIdx.x == 0) {
+        const double* pc = part + (size_t)c * nbands * 2 * n_iter;
+        double E0 = 0.0, Eprev = 0.0;
+        int stop_at = n_iter - 1;
+        for (int it = 0; it < n_iter - 1; ++it) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < nbands; ++k) { s1 += pc[(size_t)k * 2 * n_iter + 2 * it]; s2 += pc[(size_t)k * 2 * n_iter + 2 * it + 1]; }
+            // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
+            double E = (double)(float)s1;
+            E += weight * (double)(float)s2;
+            E /= (double)((size_t)M * N);
+            if (it == 0) { E0 = E; Eprev = E; }
+            else if (fabs(Eprev - E) < eps * E0) { stop_at = it; break; }
+            else Eprev = E;
+        }
+        s_stop_at = stop_at;
+        if (stop_iter && band == 0) stop_iter[c] = stop_at;
+    }
+    __syncthreads();
+    const int stop_at = s_stop_at;
+    if (stop_at == n_iter - 1) return;                   // theta already holds the `out` of the last iteration
+    tv_band_run<COLS, R, STRIPS>(xc, bc, coef, theta + chan, M, N, stop_at + 1, a_lo, a_hi, ext_lo, tau_over_w, nullptr);
+}
+
+// band height for N <= 256: 16-row bands when 32-row bands would leave the chip short of workgroups
+static bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && n_iter - 1 <= TVB_HALO; }
+
+static int tv_band_launch(const float* x, const float* b, float coef, float* theta, int M, int N, int C, double weight_d,
+                          float tau_over_w, double eps_d, int n_iter, double* part, int32_t* stop_iter, hipStream_t st) {
+    const bool small = (long long)C * ((M + 31) / 32) < 256;        // fewer than one workgroup per CU with 32-row bands
+    const int RB = small ? 16 : 32;
+    const int nbands = (M + RB - 1) / RB;
+    const dim3 grid((unsigned)(C * nbands));
+#define SCIPNP_TVB(COLS, R, STRIPS)                                                                                     \
+    do {                                                                                                                \
+        static_assert(STRIPS * R >= 16 + 2 * TVB_HALO, "band + halo rows");                                            \
+        hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+                           n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
+        hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+                           n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
+    } while (0)
+    if (N <= 64) {
+        if (small) SCIPNP_TVB(64, 3, 8); else SCIPNP_TVB(64, 5, 8);
+    } else if (N <= 128) {
+        if (small) SCIPNP_TVB(128, 6, 4); else SCIPNP_TVB(128, 10, 4);
+    } else {
+        if (small) SCIPNP_TVB(256, 6, 4); else SCIPNP_TVB(256, 10, 4);
+    }
+#undef SCIPNP_TVB
+    return launch_status("tv_band_kernel");
+}
+
 // the shortest decimal that round-trips a float32: weight and eps are Python floats (doubles) in the reference and
 // promote its float32 sums to double; they reach this ABI as float32 (0.1f -> 0.1, 2e-4f -> 2e-4)
 static double as_double(float f) {
@@ -437,7 +611,14 @@ int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* th
     const double weight_d = as_double(weight);
     const float tau_over_w = (float)(0.25 / weight_d);
     const bool fits_plane = M <= TVP_MAX && N <= TVP_MAX;
-    SCIPNP_REQUIRE(kernel >= 0 && kernel <= 2 && (kernel != 2 || fits_plane), "kernel=%d not available for %d x %d planes", kernel, M, N);
+    const bool fits_band = tv_band_fits(M, N, n_iter_max);
+    SCIPNP_REQUIRE(kernel >= 0 && kernel <= 3 && (kernel != 2 || fits_plane) && (kernel != 3 || fits_band),
+                   "kernel=%d not available for %d x %d planes, %d iterations", kernel, M, N, n_iter_max);
+    if (kernel == 3 || (kernel == 0 && fits_band)) {
+        // banded one-launch form (+ the stop-test / recompute launch); its partials live in the tiled kernel's slot
+        // of the workspace (n_iter x C x ceil(M/16) x 2 doubles: at least as many as C x nbands x 2 x n_iter)
+        return tv_band_launch(x, b, coef, theta, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, ws.partial, stop_iter, st);
+    }
     if (fits_plane && kernel != 1) {
         // rows per thread: ceil(M / strips), strips = 1024 / columns
         return tv_plane_launch(x, b, coef, theta, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, stop_iter, nullptr, st);

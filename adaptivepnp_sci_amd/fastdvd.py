@@ -148,10 +148,27 @@ def alloc_denblock_buffers(B, H, W, device, alias=True):
     return b
 
 
-def denblock_forward(pk, frames, sigma, out, b):
+def wino_packs(packed):
+    """Winograd-domain weights (csrc/conv_wino.hip) of the stride-1 layers without PixelShuffle store of one DenBlock,
+    None for the others; derived on the device from the fp32 direct packing"""
+    return [None if (s2 or shuf) else ops.pack_conv3x3_wino(packed[i], cin, cout)
+            for i, (_k, _bn, cin, cout, _relu, s2, shuf) in enumerate(_LAYERS)]
+
+
+def denblock_forward(pk, frames, sigma, out, b, pkw=None):
     """out[n] = DenBlock(frames[n-1], frames[n], frames[n+1]) for all n (circular); pk = 16 packed layers,
-    b = buffers from alloc_denblock_buffers.  reference packages/fastdvdnet/models.py:179-198."""
-    c = ops.conv3x3_c8
+    b = buffers from alloc_denblock_buffers; pkw = wino_packs(pk) to run the stride-1 layers as fp32 Winograd.
+    reference packages/fastdvdnet/models.py:179-198."""
+    if pkw is not None:
+        direct, full = ops.conv3x3_c8, pk
+
+        def c(x, w, cout, **kw):                       # w: the direct packing; its layer index selects the form
+            i = next(j for j, p_ in enumerate(full) if p_ is w)
+            if pkw[i] is None:
+                return direct(x, w, cout, **kw)
+            return ops.conv3x3_c8w(x, pkw[i], cout, **kw)
+    else:
+        c = ops.conv3x3_c8
     ops.fastdvd_pack_triplets(frames, sigma, b['t_in'])
     c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
     c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
@@ -232,10 +249,22 @@ class FastDVDEngine:
 
     def refresh(self, model):
         sd = _strip(model.state_dict())
-        self.packed = {p: pack_denblock(sd, p, self.device, split=self.precision == 'f16x3') for p in ('temp1', 'temp2')}
+        self.set_packed({p: pack_denblock(sd, p, self.device, split=self.precision == 'f16x3') for p in ('temp1', 'temp2')})
+
+    def set_packed(self, packed):
+        """install packed weights {'temp1': [...16], 'temp2': [...]} (refresh, or the finetune's device-packed updated
+        weights); the fp32 engine derives the Winograd packs of its stride-1 layers from them"""
+        from .nets import f32_conv_form
+        self.packed = packed
+        self.packed_wino = None
+        if self.precision == 'f32' and f32_conv_form() == 'winograd':
+            self.packed_wino = {p: wino_packs(pk) for p, pk in packed.items()}
 
     def forward(self, frames, sigma):
         """frames planar (B,3,H,W) -> denoised planar (B,3,H,W) (owned by the engine, overwritten per call)."""
-        fwd = denblock_forward_split if self.precision == 'f16x3' else denblock_forward
-        fwd(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
-        return fwd(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)
+        if self.precision == 'f16x3':
+            denblock_forward_split(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
+            return denblock_forward_split(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)
+        w = self.packed_wino or {'temp1': None, 'temp2': None}
+        denblock_forward(self.packed['temp1'], frames, sigma, self.s1, self.bufs, w['temp1'])
+        return denblock_forward(self.packed['temp2'], self.s1, sigma, self.out, self.bufs, w['temp2'])

@@ -666,5 +666,5 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
                 trace.append(val)
     tr.write_back()
     # the engine continues on the device-packed updated weights (no host repack)
-    eng.packed = {p: (b.fwd_s if tr.split else b.fwd) for p, b in tr.blocks.items()}
+    eng.set_packed({p: (b.fwd_s if tr.split else b.fwd) for p, b in tr.blocks.items()})
     return model

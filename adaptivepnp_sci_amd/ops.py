@@ -153,7 +153,8 @@ class TvPlan:
 
 def tv_chambolle(x, b, coef, theta, plan, weight=0.1, eps=2e-4, kernel=0):
     """theta = TV(x + coef*b) channel by channel; x, b, theta: (C, M, N) views of plane-major state.
-    kernel: 0 = the library's choice, 1 = tiled (a launch per iteration), 2 = whole plane (one launch, planes <= 128x128)."""
+    kernel: 0 = the library's choice, 1 = tiled (a launch per iteration), 2 = whole plane (one launch, planes <= 128x128),
+    3 = banded (one launch of many workgroups per plane + the stop-test launch; <= 256 columns, <= 5 iterations)."""
     _call('scipnp_tv_chambolle_ex', _p(x, 'x'), _p(b, 'b'), float(np.float32(coef)), _p(theta, 'theta'),
           plan.M, plan.N, plan.C, float(np.float32(weight)), float(np.float32(eps)), plan.n_iter_max,
           C.c_void_p(plan.ptr), plan.nbytes, _p(plan.stop_iter, 'stop_iter', torch.int32), int(kernel), _stream())

@@ -487,7 +487,7 @@ def config_records(ffd_sd, budget_s=60.0):
     out['admm_tv_256'] = {
         'workload': 'configs[0]: ADMM-TV (one-stage, Chambolle 5 inner iterations), 256x256x8, per-iteration PSNR on device',
         'dtype': 'f32', 'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms,
-        'dominant_kernel': 'tv_plane_kernel (all 5 Chambolle iterations of a 128x128 plane in one workgroup)',
+        'dominant_kernel': 'tv_band_kernel (all 5 Chambolle iterations of a 128x128 plane in one launch of 8 workgroups per plane: 16-row bands with a 4-row halo)',
         'bound': 'hbm (launch/VALU-latency limited at this size)', 'algorithmic_bytes_per_iteration': tv_bytes,
         'achieved_GBs': tv_bytes / (ms * 1e-3) / 1e9, 'frac': tv_bytes / (ms * 1e-3) / PEAK_HBM,
         'parity': {'iterations': 3, 'max_rel_l2_per_iterate': max(rel_l2(its[k], o['x_iterates'][k]) for k in range(3)), 'gate': 1e-5}}

@@ -62,8 +62,9 @@ int scipnp_bayer_merge(const float* planes, float* mosaic, int M, int N, int B, 
  *   p = theta - inv_rho*b ;  x = p + Phi*((y - sum_t p*Phi)/(alpha_rho + Phisum))
  * x may alias theta (the reference's first iteration does).  One quad (2x2 pixels x B frames) is one
  * 128-byte line for B = 8; the frame reduction is a wavefront shuffle for B = 1,2,4,8,16 and a per-quad loop for
- * any other B.  1 <= B <= 63 everywhere (A, At, phisum, both projections, the plane-major engine): the sums over
- * frames reproduce PyTorch's CPU summation orders, which are restated up to 63 addends (csrc/common.hpp). */
+ * any other B.  1 <= B <= 511 everywhere (A, At, phisum, both projections, the plane-major engine): the sums over
+ * frames reproduce PyTorch's CPU summation orders (ATen cascade_sum with its flush after 16 groups of four), restated up
+ * to 511 addends (csrc/common.hpp). */
 int scipnp_proj_twostage(const float* theta, const float* b, const float* Phi, const float* y,
                          const float* Phisum, float* x, int M, int N, int B,
                          float inv_rho, float alpha_rho, scipnp_stream_t s);
@@ -90,7 +91,7 @@ int scipnp_pm_setup(const float* Phi, const float* y, float* Phisum, float* x0,
                     int M, int N, int B, scipnp_stream_t s);
 /* projection on plane-major state; mode 0 = two-stage (c0 = inv_rho, c1 = alpha_rho),
  * mode 1 = one-stage (c0 = lambda, c1 = gamma).  x may alias theta.        -- dvp...:128-140 / :389-391
- * Up to 32 frames every tensor is read exactly once (frames held in registers); 33..63 frames take two passes. */
+ * Up to 32 frames every tensor is read exactly once (frames held in registers); 33..511 frames take two passes. */
 int scipnp_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
                       const float* Phisum, float* x, int M, int N, int B, int mode,
                       float c0, float c1, scipnp_stream_t s);
@@ -106,9 +107,12 @@ int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta
                         int M, int N, int C, float weight, float eps, int n_iter_max,
                         void* workspace, size_t workspace_bytes, int32_t* stop_iter,
                         scipnp_stream_t s);
-/* the same with the kernel named: 0 = as scipnp_tv_chambolle chooses (planes up to 128 x 128: all iterations in ONE
- * launch, a workgroup per channel holding its plane in registers; larger planes: one launch of 16 x 256 tiles per
- * iteration), 1 = the tiled kernel, 2 = the whole-plane kernel (SCIPNP_EINVAL if the plane does not fit). */
+/* the same with the kernel named: 0 = as scipnp_tv_chambolle chooses (planes up to 256 columns and <= 5 iterations: the
+ * banded form, 3; otherwise 2 where it fits, else 1); 1 = tiled, one launch of 16 x 256 tiles per iteration; 2 = whole
+ * plane, all iterations in ONE launch, a workgroup per channel holding its plane in registers (planes up to 128 x 128);
+ * 3 = banded, all iterations in one launch of many workgroups per channel (bands of 16 / 32 rows computed with a 4-row
+ * halo) plus one launch for the stop test and the recomputation of channels that stopped early.  SCIPNP_EINVAL if the
+ * named kernel does not fit the shape.  All four give bit-identical `theta` and stop iterations. */
 int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* theta,
                            int M, int N, int C, float weight, float eps, int n_iter_max,
                            void* workspace, size_t workspace_bytes, int32_t* stop_iter,
@@ -408,8 +412,10 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
 /* ADMM-TV iteration of either solver (dvp...:121-160, :265-271 two-stage; :385-407, :500-509 one-stage):
  * two_stage != 0: c0 = rho, c1 = alpha (theta = TV(x + b/rho), b += x - theta);
  * two_stage == 0: c0 = lambda, c1 = gamma (theta = TV(x - b), b -= x - theta).
- * Planes up to 128 x 128 (cubes up to 256 x 256): two launches, the projection and one kernel for all TV iterations plus
- * the dual update (theta_raw is then left untouched); larger planes: projection, a launch per TV iteration, dual update.
+ * Planes up to 256 columns with enough channels to fill the chip: four launches -- projection, the banded TV kernel (all
+ * iterations, many workgroups per plane), its stop-test launch, dual update; small problems (fewer than 128 bands of 32 rows,
+ * planes up to 128 x 128): two launches, the projection and one whole-plane kernel for all TV iterations plus the dual update
+ * (theta_raw is then left untouched); wider planes: projection, a launch per TV iteration, dual update.
  * sse_part must hold the partials of scipnp_pm_dual_update's grid (size query: scipnp_sse_partials); all of them are
  * written (the fused kernel zero-fills the entries it does not use), *nblocks receives their number. */
 typedef struct {

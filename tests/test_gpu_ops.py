@@ -50,15 +50,17 @@ def test_reference_layout_ops_bit_exact(ops, tag):
 
 
 def test_frame_count_limit(ops):
-    """the restated torch summation orders hold below 64 frames (ATen's cascade takes another level there): more is refused"""
-    Phi = torch.zeros(4, 4, 64, 4, device='cuda')
+    """the restated torch summation orders (ATen cascade_sum incl. its level-1 flush at 64 strided addends) hold up to 511
+    frames -- the contiguous order takes its next level at 64 eight-float vectors: more is refused"""
+    Phi = torch.zeros(2, 2, 512, 4, device='cuda')
     with pytest.raises(ValueError):
         ops.phisum(Phi)
     with pytest.raises(ValueError):
-        ops.pm_setup(torch.zeros(64, 4, 4, 4, device='cuda'), torch.zeros(4, 4, 4, device='cuda'))
+        ops.pm_setup(torch.zeros(512, 4, 2, 2, device='cuda'), torch.zeros(4, 2, 2, device='cuda'))
 
 
-@pytest.mark.parametrize('B', [1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 23, 24, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63])
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 23, 24, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63,
+                               64, 65, 67, 71, 72, 100, 127, 128, 131, 200, 256, 300, 511])
 def test_any_frame_count_bit_exact_against_torch_orders(ops, B):
     """Phi_sum (strided torch.sum), A_ (contiguous torch.sum of the fresh product), At_ and both projections, in the
     reference's (M,N,B,4) layout and in the plane-major engine, for every class of frame count: below one 8-float vector,
@@ -145,12 +147,14 @@ def test_layout_conversions_bit_exact(ops):
     assert torch.equal(ops.rgb_to_cube(rgb).cpu(), cube.cpu())
 
 
-@pytest.mark.parametrize('kernel', [1, 2], ids=['tiled', 'whole-plane'])
+@pytest.mark.parametrize('kernel', [1, 2, 3], ids=['tiled', 'whole-plane', 'banded'])
 def test_tv_chambolle_matches_skimage_golden(ops, kernel):
     g = load_gold('tv_chambolle')
     v = dev(g['v']).permute(2, 0, 1).contiguous()     # (C, M, N)
     C_, M, N = v.shape
     for key, w, n in (('w01_n5', 0.1, 5), ('w01_n50', 0.1, 50), ('w003_n5', 0.03, 5)):
+        if kernel == 3 and n > 5:
+            continue                                  # the banded kernel's halo covers five iterations
         plan = ops.TvPlan(M, N, C_, n, v.device)
         out = torch.empty_like(v)
         ops.tv_chambolle(v, None, 0.0, out, plan, w, kernel=kernel)
@@ -161,7 +165,7 @@ def test_tv_chambolle_matches_skimage_golden(ops, kernel):
         assert rel_l2(out.cpu().numpy(), ref.numpy()) == 0.0, key
 
 
-@pytest.mark.parametrize('kernel', [1, 2], ids=['tiled', 'whole-plane'])
+@pytest.mark.parametrize('kernel', [1, 2, 3], ids=['tiled', 'whole-plane', 'banded'])
 def test_tv_fused_input_and_ragged_size(ops, kernel):
     from oracle.tv_chambolle import tv_chambolle_multichannel
     rng = np.random.default_rng(4)
@@ -175,6 +179,45 @@ def test_tv_fused_input_and_ragged_size(ops, kernel):
     ops.tv_chambolle(xs, bs, float(coef), out, plan, 0.1, kernel=kernel)
     assert rel_l2(out.permute(1, 2, 0).cpu().numpy(), ref) == 0.0
     assert (plan.stop_iter.cpu().numpy() == stops).all()
+
+
+@pytest.mark.parametrize('shape', [(128, 128, 32), (256, 256, 8), (300, 256, 3), (127, 128, 3), (128, 65, 3), (64, 63, 40), (9, 130, 2),
+                                   (1, 1, 2), (3, 200, 2), (7, 5, 3), (100, 64, 5), (64, 100, 2), (65, 64, 2), (33, 17, 2),
+                                   (16, 255, 2), (17, 129, 3), (48, 64, 70)])
+@pytest.mark.parametrize('n_iter', [1, 2, 3, 5])
+def test_tv_banded_kernel_equals_the_tiled_kernel(ops, shape, n_iter):
+    """planes up to 256 columns run all (<= 5) iterations in one launch of MANY workgroups per channel (csrc/tv.hip
+    tv_band_kernel: bands of 16 / 32 rows computed with a 4-row halo, stop test and recomputation of early-stopped channels
+    in a second launch): same float32 operations per pixel, so `out` and the stop iterations must be identical to the
+    per-iteration tiled kernel at every size, band / strip / wave seam and iteration count"""
+    M, N, C_ = shape
+    rng = np.random.default_rng(M * 1000 + N)
+    x = dev(rng.uniform(0, 1, (C_, M, N)).astype(np.float32))
+    x[0] *= 1000.0                                    # large-amplitude channels: the dual field saturates and the energy
+    x[-1] *= 50.0                                     # settles within 2e-4 before the last iteration (the recomputation path)
+    b = dev(rng.normal(0, 0.1, (C_, M, N)).astype(np.float32))
+    plan1, plan2 = ops.TvPlan(M, N, C_, n_iter, x.device), ops.TvPlan(M, N, C_, n_iter, x.device)
+    o1, o2 = torch.empty_like(x), torch.full_like(x, -7.0)
+    ops.tv_chambolle(x, b, -1.0, o1, plan1, 0.1, kernel=1)
+    ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=3)
+    assert torch.equal(plan1.stop_iter, plan2.stop_iter), (plan1.stop_iter, plan2.stop_iter)
+    assert torch.equal(o1, o2)
+    o0 = torch.full_like(x, -3.0)
+    ops.tv_chambolle(x, b, -1.0, o0, plan2, 0.1, kernel=0)      # the library's own choice
+    assert torch.equal(o0, o1)
+
+
+def test_tv_banded_kernel_early_stop_is_exercised(ops):
+    rng = np.random.default_rng(0)
+    x = dev(rng.uniform(0, 1, (6, 96, 128)).astype(np.float32))
+    x[1] *= 50.0                                      # large amplitudes saturate the dual field: early stop
+    x[4] *= 1000.0
+    plan1, plan2 = ops.TvPlan(96, 128, 6, 5, x.device), ops.TvPlan(96, 128, 6, 5, x.device)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    ops.tv_chambolle(x, None, 0.0, o1, plan1, 0.1, kernel=1)
+    ops.tv_chambolle(x, None, 0.0, o2, plan2, 0.1, kernel=3)
+    assert torch.equal(plan1.stop_iter, plan2.stop_iter) and torch.equal(o1, o2)
+    assert int(plan1.stop_iter.min()) < 4 and int(plan1.stop_iter.max()) == 4
 
 
 @pytest.mark.parametrize('shape', [(128, 128, 8), (127, 128, 3), (128, 65, 3), (64, 63, 4), (9, 130, 2), (1, 1, 2), (3, 200, 2),
@@ -195,7 +238,7 @@ def test_tv_whole_plane_kernel_equals_the_tiled_kernel(ops, shape, n_iter):
     if N > 128 or M > 128:
         with pytest.raises(ValueError):              # SCIPNP_EINVAL
             ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=2)
-        ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=0)
+        ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=1 if n_iter > 5 and N > 256 else 0)
     else:
         ops.tv_chambolle(x, b, -1.0, o2, plan2, 0.1, kernel=2)
     assert torch.equal(o1, o2)

@@ -8,12 +8,12 @@ from adaptivepnp_sci_amd import ops, synth, admm_denoise_bayer_demosaic_pre
 from adaptivepnp_sci_amd.solver import AdmmRun
 
 dev = torch.device('cuda', 0)
-for (C_, M, N) in ((32, 128, 128), (64, 128, 128), (32, 64, 64)):
+for (C_, M, N) in ((32, 128, 128), (64, 128, 128), (32, 64, 64), (32, 256, 256)):
     x = torch.rand(C_, M, N, device=dev)
     b = torch.randn(C_, M, N, device=dev) * 0.1
     out = torch.empty_like(x)
     plan = ops.TvPlan(M, N, C_, 5, dev)
-    for kernel in (1, 2):
+    for kernel in ((1, 2, 3) if M <= 128 else (1, 3)):
         for _ in range(5):
             ops.tv_chambolle(x, b, -1.0, out, plan, 0.1, kernel=kernel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
