@@ -90,6 +90,42 @@ def test_config2_fastdvdnet_512x512x8(solver, precision, monkeypatch):
     assert rel_l2(res[0], o['rgb']) <= REL_TOL
 
 
+def test_config2_fastdvdnet_full_driver_schedule(solver, monkeypatch):
+    """configs[2] with the reference driver's whole schedule at full size (two_stage_ADMM_Online_FastDVD_Warm.py:68-75:
+    sigma 8/255 x 18 iterations, rho 0.55, online finetune lr 2e-6 x 2 steps firing once at k = 9, update_times = 1) --
+    too long for the CPU oracle inside the suite (18 x 6.5 s), so the full run is checked through size-independent
+    properties: the three convolution forms (fp32 Winograd, fp32 direct, split-fp16), each already pinned per iterate
+    against the oracle on the first iterations (test above) and on the 64x64x8 goldens incl. the finetune, must stay
+    together over all 18 free-running iterations and through the weight update; PSNR must not collapse."""
+    from adaptivepnp_sci_amd import synth
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=1)
+    warm = solver.admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [10], False, [0], logf=io.StringIO())[0]
+    runs = {}
+    for form in ('f32-winograd', 'f32-direct', 'f16x3'):
+        monkeypatch.setenv('SCIPNP_CONV_PRECISION', form.split('-')[0])
+        monkeypatch.setenv('SCIPNP_F32_CONV', form.split('-')[1] if '-' in form else 'winograd')
+        net = cpu_data_parallel(synth_fastdvdnet_weights(1))
+        np.random.seed(42)                                       # the finetune's noise comes from the global NumPy RNG
+        res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [18], False, [8 / 255], x0_bayer=warm,
+                                                X_orig=orig, model_denoise=net, logf=io.StringIO(), lr_=2e-6, inital_iter=1,
+                                                interval_iter=9, update_=True, update_per_iter=2, update_times=1)
+        runs[form] = (res[1], np.array(res[4]), {k: v.clone() for k, v in net.state_dict().items()})
+    base = runs['f32-direct']
+    assert len(base[1]) == 18 and np.isfinite(base[1]).all()
+    for form in ('f32-winograd', 'f16x3'):
+        mosaic, psnr, sd = runs[form]
+        assert rel_l2(mosaic, base[0]) <= REL_TOL, (form, rel_l2(mosaic, base[0]))
+        assert np.abs(psnr - base[1]).max() <= PSNR_TOL, (form, np.abs(psnr - base[1]).max())
+    # the finetune event did change the weights, in all three runs alike (Adam steps ~ lr * sign(g))
+    w0 = synth_fastdvdnet_weights(1).state_dict()
+    key = 'temp2.outc.convblock.3.weight'
+    d = {f: (runs[f][2]['module.' + key] - w0[key]).double() for f in runs}
+    assert float(d['f32-direct'].abs().max()) > 0
+    for f in ('f32-winograd', 'f16x3'):
+        assert float((d[f] - d['f32-direct']).norm() / d['f32-direct'].norm()) < 5e-2, f
+
+
 def test_config4_tile_256x256x16_with_online_finetune(solver, ffdnet_state_dict):
     """configs[4]: one 256x256 tile of the 1024x1024x16 colour cube (16 frames), FFDNet with online finetune firing
     once (gate at k = 2), per-tile model copy as in shard.reconstruct_sharded."""
