@@ -124,6 +124,14 @@ class _FFDNetTrainer:
                     for ci, co in zip(self.cin, self.cout)]
         self.bwd = [None] + [torch.empty(lib.scipnp_conv3x3_packed_floats(co, ci), dtype=F32, device=dev)
                              for ci, co in list(zip(self.cin, self.cout))[1:]]
+        # fp32 engine in Winograd form: the stash forward and the backward-data convolutions (stride 1, full 3x3: the same
+        # operator with transposed / flipped weights) run on csrc/conv_wino.hip too; weight gradients stay on the direct MFMA kernel
+        self.wino = (not self.split) and getattr(eng, 'packed_wino', None) is not None
+        if self.wino:
+            self.fwd_w = [torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev)
+                          for ci, co in zip(self.cin, self.cout)]
+            self.bwd_w = [None] + [torch.empty(lib.scipnp_conv3x3_wino_packed_floats(co, ci), dtype=F32, device=dev)
+                                   for ci, co in list(zip(self.cin, self.cout))[1:]]
         self.acts = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(self.nb - 1)]
         self.dz = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(2)]
         self.gout = torch.empty(B, 2, M, N, 8, dtype=F32, device=dev)
@@ -176,6 +184,10 @@ class _FFDNetTrainer:
             if l > 0:
                 _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), None, _ptr(self.bwd[l]), ci_r, co_r,
                                                                self.cin[l], self.cout[l], 1, _s()), 'pack bwd')
+            if self.wino:
+                ops.pack_conv3x3_wino(self.fwd[l], self.cin[l], self.cout[l], out=self.fwd_w[l])
+                if l > 0 and not final:
+                    ops.pack_conv3x3_wino(self.bwd[l], self.cout[l], self.cin[l], out=self.bwd_w[l])
 
     def forward_keep(self):
         eng = self.eng
@@ -187,10 +199,11 @@ class _FFDNetTrainer:
             ops.conv3x3_c8s(x, self.fwd_s[-1], 16, out=eng.out_c8, f32_out=True)
             return
         x = eng.in_c8
+        conv, pk = (ops.conv3x3_c8w, self.fwd_w) if self.wino else (ops.conv3x3_c8, self.fwd)
         for l in range(self.nb - 1):
-            ops.conv3x3_c8(x, self.fwd[l], self.nc, relu=True, out=self.acts[l], head=(l == 0))
+            conv(x, pk[l], self.nc, relu=True, out=self.acts[l], head=(l == 0))
             x = self.acts[l]
-        ops.conv3x3_c8(x, self.fwd[-1], 16, relu=False, out=eng.out_c8)
+        conv(x, pk[-1], 16, relu=False, out=eng.out_c8)
 
     def loss_and_grad(self, y_pm, Phi_pm):
         eng = self.eng
@@ -216,8 +229,12 @@ class _FFDNetTrainer:
             if l > 0:
                 nxt = self.dz[l & 1]
                 # backward-data: conv of dZ_l with the transposed/flipped weights, masked by ReLU'(A_{l-1})
-                _lib.check(self.lib.scipnp_conv3x3_c8(_ptr(dz), _ptr(self.bwd[l]), _ptr(nxt), _ptr(self.acts[l - 1]), B,
-                                                      self.cout[l], self.cin[l], M, N, 16, _s()), 'backward-data conv')
+                if self.wino:
+                    ops.conv3x3_c8w(dz.view(B, self.cout[l] // 8, M, N, 8), self.bwd_w[l], self.cin[l], mask_src=self.acts[l - 1],
+                                    out=nxt)
+                else:
+                    _lib.check(self.lib.scipnp_conv3x3_c8(_ptr(dz), _ptr(self.bwd[l]), _ptr(nxt), _ptr(self.acts[l - 1]), B,
+                                                          self.cout[l], self.cin[l], M, N, 16, _s()), 'backward-data conv')
                 dz = nxt
 
     def _backward_split(self):
