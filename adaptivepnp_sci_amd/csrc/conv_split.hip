@@ -106,6 +106,30 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
     *(f16x4*)lo_ptr = l;
 }
 
+// the same split, stored as ONE 16-byte vector per lane: lanes l and l+32 of the wave hold the two channel quads of one
+// pixel's 8-channel group; after exchanging a half each, lane l < 32 stores [hi quad 0 | hi quad 1] to the hi plane and lane
+// l+32 [lo' quad 0 | lo' quad 1] to the lo' plane (`dst` = that lane's plane + pixel offset).  Both lanes of a pair must be active.
+__device__ __forceinline__ void split_store16(float v0, float v1, float v2, float v3, char* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f16x4 h, l;
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        h[e] = hh;
+        l[e] = (_Float16)((v[e] - (float)hh) * CS_LO_SCALE);
+    }
+    if (!(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) < 65000.f)) g_split_overflow = 1;   // also NaN
+    union { f16x4 f; unsigned u[2]; } hu, lu;
+    hu.f = h; lu.f = l;
+    // permlane32_swap(x, y): x of lanes 32..63 <-> y of lanes 0..31
+    const auto r0 = __builtin_amdgcn_permlane32_swap(hu.u[0], lu.u[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hu.u[1], lu.u[1], false, false);
+    // lanes < 32: (r[0], r[1]) = (own hi, partner's hi);  lanes >= 32: (partner's lo', own lo')
+    *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+#endif
+}
+
 // TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
 template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4, int WS = 0>
 __global__ void __launch_bounds__((SplitCfg<COB, STRIDE, PB, NW, WS>::THREADS), (SplitCfg<COB, STRIDE, PB, NW, WS>::WAVES_PER_SIMD))
@@ -372,8 +396,12 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                             f32x4 o = {v[0], v[1], v[2], v[3]};
                             *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HWo + pix) * 8 + 4 * lh) * 4) = o;
                         } else {
+                            // c8s store: this lane holds channels 4*lh .. 4*lh+3 of the group, lane li+32 the other four.  The two
+                            // exchange one half each (v_permlane32_swap), after which lane (li, 0) owns the eight hi values and
+                            // lane (li, 1) the eight lo' values of the pixel: ONE 16-byte store per lane and plane instead of two
+                            // 8-byte ones (8-byte vector stores run at 0.54-0.70 of the 16-byte rate; the head layers are store-bound)
                             char* grp = a.out + ((size_t)n * a.CGout + cog) * (2 * HWo * 16);
-                            split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 8 * lh, grp + HWo * 16 + pix * 16 + 8 * lh);
+                            split_store16(v[0], v[1], v[2], v[3], grp + (lh ? HWo * 16 : 0) + pix * 16);
                         }
                     }
                 }
