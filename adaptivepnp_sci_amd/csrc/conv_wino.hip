@@ -62,7 +62,7 @@ struct WinoArgs {
     int flags;
 };
 
-// TAG only changes the symbol name (1 = network head layer) so profiler statistics of the body layers stay clean.
+// TAG only changes the symbol name (1 = first / last layer of a network) so profiler statistics of the body layers stay clean.
 //
 // Software pipeline, one barrier per channel group g:  the MFMAs of group g run on V_g (registers) and U_g (LDS) while
 // the same wave reads the raw patch of group g+1 from LDS and transforms it into V_{g+1} between the MFMAs; the raw tile
@@ -395,7 +395,7 @@ int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* co
         if (rc) return rc;
         cur ^= 1;
     }
-    return scipnp_conv3x3_c8w(buf[cur], packed_wino[nb - 1], out_c8, nullptr, nullptr, B, nc, 16, M, N, 0, s);
+    return scipnp_conv3x3_c8w(buf[cur], packed_wino[nb - 1], out_c8, nullptr, nullptr, B, nc, 16, M, N, 0x100, s);
 }
 
 }  // extern "C"

@@ -158,7 +158,9 @@ class FFDNetEngine:
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        conv(buf[cur], pk[self.nb - 1], self.cout_last, relu=False, out=out_c8)
+        # (head=True only selects the kernel symbol of the first / last layer, so that profiler statistics of the body
+        # layers' symbol hold body launches only)
+        conv(buf[cur], pk[self.nb - 1], self.cout_last, relu=False, out=out_c8, head=True)
         return out_c8
 
     def _forward_split(self, in_c8, out_c8, events):
