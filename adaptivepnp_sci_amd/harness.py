@@ -122,22 +122,34 @@ def _is_hdf5(path):
 
 
 def load_scene(path):
-    """Read a scene file: MATLAB v7.3 (HDF5, via h5py), MATLAB <= v7.2 (scipy.io) or .npz."""
+    """Read a scene file: MATLAB v7.3 (HDF5: h5py if installed, else the built-in minimal reader), MATLAB <= v7.2
+    (scipy.io) or .npz."""
     name = os.path.splitext(os.path.basename(path))[0]
     if path.endswith('.npz'):
         d = np.load(path)
         return Scene(name, d['meas_bayer'], d['mask_bayer'], d['orig_bayer'] if 'orig_bayer' in d else None,
                      d['orig'] if 'orig' in d else None)
     if _is_hdf5(path):
+        want = ('meas_bayer', 'mask_bayer', 'orig_bayer', 'orig')
         try:
             import h5py
-        except ImportError as e:
-            raise RuntimeError(f'{path} is a MATLAB v7.3 (HDF5) file and h5py is not installed; install h5py or '
-                               'convert the file to MATLAB v7 / .npz') from e
-        with h5py.File(path, 'r') as f:
-            meas, mask = np.array(f['meas_bayer']), np.array(f['mask_bayer'])
-            orig = np.array(f['orig_bayer']) if 'orig_bayer' in f else None
-            real = np.array(f['orig']) if 'orig' in f else None
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(path, 'r') as f:
+                d = {k: np.array(f[k]) for k in want if k in f}
+        else:
+            # no h5py here: the package's own reader of the HDF5 subset MATLAB writes (hdf5_min.py) -- same arrays,
+            # same (reversed) axis order as h5py returns
+            from .hdf5_min import Hdf5Unsupported, read_mat73
+            try:
+                d = read_mat73(path, want)
+            except Hdf5Unsupported as e:
+                raise RuntimeError(f'{path}: MATLAB v7.3 (HDF5) file outside what the built-in reader handles ({e}); '
+                                   'install h5py or convert the file to MATLAB v7 / .npz') from e
+        if 'meas_bayer' not in d or 'mask_bayer' not in d:
+            raise RuntimeError(f'{path}: no meas_bayer / mask_bayer variables')
+        meas, mask, orig, real = d['meas_bayer'], d['mask_bayer'], d.get('orig_bayer'), d.get('orig')
         # h5py hands MATLAB arrays over with reversed axes (reference :189-195)
         mask = np.float32(mask).transpose((2, 1, 0))
         meas = np.float32(meas).transpose((1, 0)) if meas.ndim < 3 else np.float32(meas).transpose((2, 1, 0))
