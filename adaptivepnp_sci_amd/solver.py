@@ -503,11 +503,15 @@ class _LogStream:
         self.no_orig = run.orig is None
         self.pending = []
         self.n = float(run.H) * run.W * run.B
+        self._pool, self._free = torch.empty(0, dtype=torch.float64), 0
 
     def after_step(self, k, nsig):
         """k = index of the iteration that has just been enqueued (0-based)"""
         if self.have_orig and (k + 1) % 2 == 0:
-            host = torch.empty(1, dtype=torch.float64).pin_memory()
+            if self._free >= self._pool.numel():                       # page-locked slots, 64 at a time
+                self._pool, self._free = torch.empty(64, dtype=torch.float64).pin_memory(), 0
+            host = self._pool[self._free:self._free + 1]
+            self._free += 1
             host.copy_(self.run.sse_rows[k].sum().reshape(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
