@@ -374,7 +374,7 @@ def _load_model(denoiser, weights):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description='ADMM-TV warm start + two-stage adaptive PnP-ADMM on one scene file')
-    ap.add_argument('scene', help='.mat (v7.3 needs h5py) or .npz with meas_bayer, mask_bayer, orig_bayer')
+    ap.add_argument('scene', help='.mat (v7.3 / HDF5 or v7) or .npz with meas_bayer, mask_bayer, orig_bayer')
     ap.add_argument('--denoiser', default='ffdnet_color', choices=sorted(_SHORT))
     ap.add_argument('--weights', help='denoiser checkpoint (.pth state dict or .npz)')
     ap.add_argument('--ddnet-weights', help='DDnet checkpoint -> deep demosaicking instead of Malvar')

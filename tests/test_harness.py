@@ -170,3 +170,19 @@ def test_cli_runs_a_scene_end_to_end(tmp_path, capsys):
     mtime = os.path.getmtime(warm)
     assert harness.main([scene, '--denoiser', 'ffdnet_color', '--weights', weights, '--results', res, '--no-update']) == 0
     assert os.path.getmtime(warm) == mtime                       # the saved warm start was loaded, not recomputed
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_v73_scene(tmp_path):
+    """the reference's own scene container -- MATLAB v7.3 -- through the CLI, with no h5py in the image: 12 x 16 pixels,
+    4 masks, 2 measurements; TV warm start then two-stage FFDNet without finetune"""
+    import shutil
+    from conftest import GOLD
+    scene = str(tmp_path / 'Toy_bayer.mat')
+    shutil.copy(os.path.join(GOLD, 'scene_v73_chunked.mat'), scene)
+    weights = os.path.join(GOLD, 'ffdnet_color_weights.npz')
+    res = str(tmp_path / 'results')
+    assert harness.main([scene, '--denoiser', 'ffdnet_color', '--weights', weights, '--results', res, '--no-update']) == 0
+    sc = harness.load_scene(scene)
+    assert os.path.exists(harness.warm_start_path(res, sc))
+    assert harness.load_warm_start(harness.warm_start_path(res, sc)).shape == (12, 16, 8)
