@@ -466,25 +466,46 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
                                      part + ((size_t)c * nbands + band) * 2 * n_iter);
         return;
     }
-    // ---- stop test of the channel (every workgroup of the channel evaluates it identically)
+    // ---- stop test of the channel (every workgroup of the channel evaluates it identically): wave 0 sums the band partials
+    // of every iteration -- lane l takes bands l, l+64, ... in order, then a fixed shuffle tree; all loads are issued before
+    // the first sum -- and lane 0 walks skimage's test over the iterations
     __shared__ int s_stop_at;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         const double* pc = part + (size_t)c * nbands * 2 * n_iter;
-        double E0 = 0.0, Eprev = 0.0;
-        int stop_at = n_iter - 1;
-        for (int it = 0; it < n_iter - 1; ++it) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < nbands; ++k) { s1 += pc[(size_t)k * 2 * n_iter + 2 * it]; s2 += pc[(size_t)k * 2 * n_iter + 2 * it + 1]; }
-            // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
-            double E = (double)(float)s1;
-            E += weight * (double)(float)s2;
-            E /= (double)((size_t)M * N);
-            if (it == 0) { E0 = E; Eprev = E; }
-            else if (fabs(Eprev - E) < eps * E0) { stop_at = it; break; }
-            else Eprev = E;
+        double s1[TVB_HALO], s2[TVB_HALO];
+#pragma unroll
+        for (int it = 0; it < TVB_HALO; ++it) {
+            s1[it] = 0.0;
+            s2[it] = 0.0;
+            if (it < n_iter - 1)
+                for (int k = threadIdx.x; k < nbands; k += 64) {
+                    s1[it] += pc[(size_t)k * 2 * n_iter + 2 * it];
+                    s2[it] += pc[(size_t)k * 2 * n_iter + 2 * it + 1];
+                }
         }
-        s_stop_at = stop_at;
-        if (stop_iter && band == 0) stop_iter[c] = stop_at;
+#pragma unroll
+        for (int it = 0; it < TVB_HALO; ++it)
+            for (int off = 32; off > 0; off >>= 1) {
+                s1[it] += __shfl_down(s1[it], off, 64);
+                s2[it] += __shfl_down(s2[it], off, 64);
+            }
+        if (threadIdx.x == 0) {
+            double E0 = 0.0, Eprev = 0.0;
+            int stop_at = n_iter - 1;
+#pragma unroll
+            for (int it = 0; it < TVB_HALO; ++it) {
+                if (it >= n_iter - 1 || stop_at != n_iter - 1) continue;
+                // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
+                double E = (double)(float)s1[it];
+                E += weight * (double)(float)s2[it];
+                E /= (double)((size_t)M * N);
+                if (it == 0) { E0 = E; Eprev = E; }
+                else if (fabs(Eprev - E) < eps * E0) stop_at = it;
+                else Eprev = E;
+            }
+            s_stop_at = stop_at;
+            if (stop_iter && band == 0) stop_iter[c] = stop_at;
+        }
     }
     __syncthreads();
     const int stop_at = s_stop_at;
