@@ -101,6 +101,9 @@ SIGNATURES = {
     'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_negate': (_int, [_vp, _vp, _sz, _vp]),
+    'scipnp_fastdvd_noisy_input': (_int, [_vp, _vp, _vp, _sz, _vp]),
+    'scipnp_sum_rows_f64': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_gray_net_input': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _vp]),
     'scipnp_gray_net_output': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_cube_to_frames': (_int, [_vp, _vp, _int, _int, _int, _vp]),

@@ -5,6 +5,7 @@
 //   FFDNet.forward's output assembly  models/network_ffdnet.py:66-69  (pixel-shuffle, crop)
 //   test_ddnet's channel sum          packages/DDnet/DDnet_test.py:166-216 (the network sees the mosaic only)
 #include "common.hpp"
+#include <cstddef>
 
 namespace scipnp {
 
@@ -60,6 +61,32 @@ __global__ void cube_sum3_kernel(const float* __restrict__ cube, float* __restri
     out[i] = (s[0] + s[B]) + s[2 * B];                   // torch.sum(dim=2) order for 3 addends
 }
 
+// out = -in (the one-stage CNN branches run the shared pre / post kernels on -b: x + 1*(-b) = x - b exactly)
+__global__ void negate_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -in[i];
+}
+
+// FastDVDnet finetune input (test_fastdvdnet.py:359 with utils_image.py:183-192): v + float32(float64(v) + noise)
+__global__ void noisy_input_kernel(const float* __restrict__ v, const double* __restrict__ noise, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[i] + (float)((double)v[i] + noise[i]);
+}
+
+// out[r] = sum of row r of a [rows][n] table of fp64 partial sums, sequential per lane then a fixed shuffle / LDS tree
+// (one workgroup per row; deterministic)
+__global__ void __launch_bounds__(256)
+sum_rows_f64_kernel(const double* __restrict__ part, double* __restrict__ out, int n) {
+    __shared__ double red[4];
+    const double* p = part + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 }  // namespace scipnp
 
 using namespace scipnp;
@@ -94,6 +121,24 @@ int scipnp_cube_sum3(const float* cube, float* out, int H, int W, int B, scipnp_
     hipLaunchKernelGGL(cube_sum3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, cube, out, B,
                        total);
     return launch_status("cube_sum3_kernel");
+}
+
+int scipnp_negate(const float* in, float* out, size_t n, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && out && n > 0, "null pointer or empty");
+    hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, out, n);
+    return launch_status("negate_kernel");
+}
+
+int scipnp_fastdvd_noisy_input(const float* v, const double* noise, float* out, size_t n, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(v && noise && out && n > 0, "null pointer or empty");
+    hipLaunchKernelGGL(noisy_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, v, noise, out, n);
+    return launch_status("noisy_input_kernel");
+}
+
+int scipnp_sum_rows_f64(const double* part, double* out, int rows, int n, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(part && out && rows > 0 && n > 0, "null pointer or empty");
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, part, out, n);
+    return launch_status("sum_rows_f64_kernel");
 }
 
 }  // extern "C"

@@ -88,6 +88,16 @@ def _carve(flat, like):
     return out
 
 
+class _DeviceMean:
+    """a sum left on the device by scipnp_sum_rows_f64 and its divisor: `.item()` reads it back (the only sync of a step)"""
+
+    def __init__(self, total, count):
+        self.total, self.count = total, count
+
+    def item(self):
+        return float(self.total.item()) / self.count
+
+
 # Test/diagnostic hook: callable({state-dict key: gradient tensor (a device copy)}) invoked after the FIRST backward pass of
 # every online-finetune event, before the Adam step -- the quantity the reference holds in `.grad` after its first
 # total_loss.backward() (test_ffdnet_ipol.py:296, test_fastdvdnet.py:444).  None in production.
@@ -211,7 +221,7 @@ class _FFDNetTrainer:
         _lib.check(self.lib.scipnp_ffdnet_loss_grad(_ptr(eng.out_c8), _ptr(Phi_pm), _ptr(y_pm), _ptr(self.gout),
                                                     _ptr(self.loss_part), eng.M, eng.N, eng.B, C.byref(nb_), _s()),
                    'scipnp_ffdnet_loss_grad')
-        return self.loss_part.sum() / (4.0 * eng.M * eng.N)        # device scalar (float64)
+        return _DeviceMean(ops.sum_rows_f64(self.loss_part), 4.0 * eng.M * eng.N)     # read back by .item()
 
     def backward(self):
         if self.split:
@@ -480,7 +490,7 @@ class _FastDVDTrainer:
         _lib.check(self.lib.scipnp_fastdvd_loss_grad(_ptr(self.out), _ptr(Phi_pm), _ptr(y_pm), _ptr(self.dout),
                                                      _ptr(self.loss_part), eng.H // 2, eng.W // 2, eng.B, C.byref(nb_), _s()),
                    'scipnp_fastdvd_loss_grad')
-        return self.loss_part.sum() / float(eng.H * eng.W)
+        return _DeviceMean(ops.sum_rows_f64(self.loss_part), float(eng.H * eng.W))
 
     def _bwd(self, blk, i, dz, out, n, h, w, residual=None, mask=None):
         """backward-data of layer i: out = [mask]( conv(dz; W_i^T flipped, BN scale folded) [+ residual] );
@@ -658,7 +668,7 @@ def fastdvdnet_online_finetune(model, eng, frames, y_pm, Phi_pm, sigma, lr_, upd
         noise = legacy_normal(0, 5 / 255, tuple(frames.shape))
     # frames + float32(float64(frames) + noise): the float64 sum and its rounding are done on the device (same IEEE result)
     noise_d = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float64)).to(frames.device)
-    v_plus = (frames + (frames.double() + noise_d).float()).contiguous()
+    v_plus = ops.fastdvd_noisy_input(frames.contiguous(), noise_d)
     del noise_d
     tr = _FastDVDTrainer(model, eng)
     tr.pack()

@@ -513,6 +513,29 @@ def frames_to_cube(frames):
     return out
 
 
+def negate(x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _call('scipnp_negate', _p(x, 'x'), _p(out, 'out'), x.numel(), _stream())
+    return out
+
+
+def fastdvd_noisy_input(v, noise_f64):
+    """v + float32(float64(v) + noise): the FastDVDnet finetune's network input (reference test_fastdvdnet.py:359)"""
+    out = torch.empty_like(v)
+    _call('scipnp_fastdvd_noisy_input', _p(v, 'v'), _p(noise_f64, 'noise', torch.float64), _p(out, 'out'), v.numel(), _stream())
+    return out
+
+
+def sum_rows_f64(part, out=None):
+    """row sums of a contiguous fp64 table [rows][n] (or one row [n]) on the device, fixed summation order"""
+    t = part.reshape(1, -1) if part.dim() == 1 else part
+    if out is None:
+        out = torch.empty(t.shape[0], dtype=torch.float64, device=part.device)
+    _call('scipnp_sum_rows_f64', _p(t, 'part', torch.float64), _p(out, 'out', torch.float64), t.shape[0], t.shape[1], _stream())
+    return out
+
+
 def split_overflow(reset=True):
     """True if the split-fp16 kernels saw a value outside fp16's range since the last reset (synchronises)."""
     flag = C.c_int(0)

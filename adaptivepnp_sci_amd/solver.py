@@ -236,7 +236,7 @@ class AdmmRun:
         else:
             # one-stage CNN branches (:439-496): demosaic(x - b), no w dual, b -= x - theta.  Run the
             # kernels on -b:  x + 1*(-b) = x - b exactly, and (-b) + (x - theta) = -(b - (x - theta)).
-            b_in, inv_rho, inv_tau, w = self.b.neg(), 1.0, 0.0, None
+            b_in, inv_rho, inv_tau, w = ops.negate(self.b), 1.0, 0.0, None
         closed = self.close_form and k > 0      # closed-form RGB update (reference :175-182 / :224-230), Malvar at k = 0
         if self.denoiser == 'ffdnet_color':
             split = self.eng.precision == 'f16x3'
@@ -281,7 +281,7 @@ class AdmmRun:
                             self.x, self.x_rgb if self.two_stage else None, self.theta, b_in, w, k == 0,
                             self.orig if iqa_here else None, part)
         if not self.two_stage:
-            self.b = b_in.neg()
+            ops.negate(b_in, out=self.b)
             if self.iqa:
                 ops.sse_partials(self.orig, self.x, self._new_sse(ops.sse_nblocks(self.x.numel())))
         if last:
@@ -310,7 +310,11 @@ class AdmmRun:
         """One read-back for all iterations: PSNR_k = 10 log10(1 / mean sq err) (skimage formula)."""
         if not self.sse_rows:
             return []
-        sse = torch.stack([r.sum() for r in self.sse_rows]).cpu().numpy()
+        n0 = self.sse_rows[0].numel()
+        if all(r.numel() == n0 for r in self.sse_rows):            # one launch for the whole table
+            sse = ops.sum_rows_f64(torch.stack(self.sse_rows)).cpu().numpy()
+        else:
+            sse = torch.cat([ops.sum_rows_f64(r) for r in self.sse_rows]).cpu().numpy()
         n = float(self.H) * self.W * self.B
         return [float(10 * np.log10(1.0 / (s / n))) for s in sse]
 
@@ -512,7 +516,7 @@ class _LogStream:
                 self._pool, self._free = torch.empty(64, dtype=torch.float64).pin_memory(), 0
             host = self._pool[self._free:self._free + 1]
             self._free += 1
-            host.copy_(self.run.sse_rows[k].sum().reshape(1), non_blocking=True)
+            host.copy_(ops.sum_rows_f64(self.run.sse_rows[k]), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self.pending.append((k, nsig, host, ev))

@@ -446,6 +446,13 @@ int scipnp_ffdnet_pack_input(const float* x, float sigma, float* out_c8, int n, 
  * pixel-shuffled and cropped y planar [n][C][H][W]. */
 int scipnp_ffdnet_unpack_output(const float* out_c8, float* y, int n, int C, int H, int W, scipnp_stream_t s);
 
+/* small elementwise / reduction steps of the host loops, so that no PyTorch arithmetic runs on the path:
+ * out = -in;  out = v + float32(float64(v) + noise) (FastDVDnet finetune input, test_fastdvdnet.py:359 with
+ * utils_image.py:183-192);  out[r] = sum of row r of an fp64 table [rows][n] (PSNR / loss partial sums, fixed order) */
+int scipnp_negate(const float* in, float* out, size_t n, scipnp_stream_t s);
+int scipnp_fastdvd_noisy_input(const float* v, const double* noise, float* out, size_t n, scipnp_stream_t s);
+int scipnp_sum_rows_f64(const double* part, double* out, int rows, int n, scipnp_stream_t s);
+
 /* (H,W,3,B) cube -> (H,W,B) sum over the colour axis (packages/DDnet/DDnet_test.py: the demosaicker's input is the
  * mosaic, i.e. the channel sum of a CFA-sampled cube). */
 int scipnp_cube_sum3(const float* cube, float* out, int H, int W, int B, scipnp_stream_t s);
