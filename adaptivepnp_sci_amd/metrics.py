@@ -16,7 +16,7 @@ def frame_metrics(ref_state, img_state, data_range=1.0, win=7):
         raise ValueError('win_size exceeds image extent')
     part = torch.empty(B, ops.frame_metrics_nblocks(M, N, B, win), 2, dtype=torch.float64, device=ref_state.device)
     ops.frame_metrics(ref_state, img_state, part, win, data_range)
-    s = part.sum(1).cpu().numpy()
+    s = ops.to_host(part).sum(1)                       # [B][blocks][2] fp64 partials: the last reduction on the host
     mse = s[:, 0] / (H * W)
     psnr = [float(10 * np.log10((data_range ** 2) / e)) for e in mse]
     ssim = [float(v / ((H - win + 1) * (W - win + 1))) for v in s[:, 1]]
