@@ -896,3 +896,45 @@ def test_conv3x3_winograd_identity_asymmetric(ops):
     got = ops.from_c8(ops.conv3x3_c8w(ops.to_c8(x.cuda()), ops.pack_conv3x3_wino(packed, cin, cout), cout)).cpu()
     perm = [(c * 7 + 3) % cin for c in range(cout)]
     assert torch.equal(got, x[:, perm])
+
+
+def test_conv3x3_winograd_random_shapes(ops):
+    """seeded sweep of small / ragged / thin shapes through the fp32 Winograd kernel (both workgroup forms) against the
+    direct fp32-MFMA kernel and fp64: tiles cut by every border, single channel groups, co-blocks with padding"""
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(2024)
+    for _ in range(40):
+        n = int(rng.integers(1, 4))
+        cin, cout = 8 * int(rng.integers(1, 7)), 8 * int(rng.integers(1, 14))
+        h, w = int(rng.integers(1, 41)), int(rng.integers(1, 75))
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        bias = torch.randn(cout, generator=g)
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+        pw = ops.pack_conv3x3_wino(packed, cin, cout)
+        xc = ops.to_c8(x.cuda())
+        got = ops.conv3x3_c8w(xc, pw, cout)
+        assert torch.equal(got, ops.conv3x3_c8w(xc, pw, cout, rows16=True)), (n, cin, cout, h, w)
+        err = rel_l2(ops.from_c8(got).cpu().numpy(), ref.numpy())
+        assert err < 2e-6, (n, cin, cout, h, w, err)
+        direct = ops.from_c8(ops.conv3x3_c8(xc, packed, cout)).cpu()
+        assert rel_l2(ops.from_c8(got).cpu().numpy(), direct.numpy()) < 2e-6
+
+
+def test_tv_banded_kernel_random_shapes(ops):
+    """seeded sweep of plane shapes and channel counts through the banded TV kernel against the tiled one: bit-identical
+    `out` and stop iterations whatever the band / strip / wave seams and the iteration count"""
+    rng = np.random.default_rng(77)
+    for _ in range(40):
+        M, N, C_ = int(rng.integers(1, 300)), int(rng.integers(1, 257)), int(rng.integers(1, 40))
+        n_iter = int(rng.integers(1, 6))
+        x = dev((rng.uniform(0, 1, (C_, M, N)) * rng.choice([1.0, 1.0, 60.0, 900.0], (C_, 1, 1))).astype(np.float32))
+        b = dev(rng.normal(0, 0.1, (C_, M, N)).astype(np.float32))
+        coef = float(rng.choice([-1.0, 1.0, 1 / 0.55]))
+        p1, p3 = ops.TvPlan(M, N, C_, n_iter, x.device), ops.TvPlan(M, N, C_, n_iter, x.device)
+        o1, o3 = torch.empty_like(x), torch.full_like(x, -5.0)
+        ops.tv_chambolle(x, b, coef, o1, p1, 0.1, kernel=1)
+        ops.tv_chambolle(x, b, coef, o3, p3, 0.1, kernel=3)
+        assert torch.equal(p1.stop_iter, p3.stop_iter), (M, N, C_, n_iter)
+        assert torch.equal(o1, o3), (M, N, C_, n_iter)
