@@ -209,29 +209,32 @@ bayer_reorder_kernel(const float* __restrict__ src, float* __restrict__ dst, int
 // whole lines: a block handles one mosaic row pair (2 rows) x 32 quads x all B frames.
 constexpr int CONV_TQ = 32;
 
+constexpr int CONV_FC = 64;       // frames per block (LDS tile); more frames: blockIdx.z walks chunks of 64
+
 template <bool TO_STATE>
 __global__ void __launch_bounds__(256)
-state_mosaic_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int N, int B) {
+state_mosaic_kernel(const float* __restrict__ src, float* __restrict__ dst, int M, int N, int Bt) {
     extern __shared__ float tile[];  // [2 rows][CONV_TQ*2 px][B+1]
     const int m = blockIdx.y;
     const int n0 = blockIdx.x * CONV_TQ;
     const int nq = min(CONV_TQ, N - n0);
+    const int t0 = blockIdx.z * CONV_FC, B = min(CONV_FC, Bt - t0);       // this block's frames t0 .. t0+B-1
     const int W = 2 * N;
     const int pitch = B + 1;
-    const int per_row = 2 * nq * B;  // floats of one mosaic row segment
+    const int per_row = 2 * nq * B;  // floats of one mosaic row segment (this chunk of frames)
     const size_t plane = (size_t)M * N;
     if (TO_STATE) {
         for (int i = threadIdx.x; i < 2 * per_row; i += blockDim.x) {
             const int dy = i / per_row, j = i % per_row;
             const int px = j / B, t = j % B;
             tile[(dy * 2 * CONV_TQ + px) * pitch + t] =
-                src[((size_t)(2 * m + dy) * W + 2 * n0) * B + j];
+                src[((size_t)(2 * m + dy) * W + 2 * n0 + px) * Bt + t0 + t];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < B * 4 * nq; i += blockDim.x) {
             const int q = i % nq, ib = (i / nq) & 3, t = i / (4 * nq);
             const int dy = ib >> 1, dx = ib & 1;
-            dst[((size_t)t * 4 + ib) * plane + (size_t)m * N + n0 + q] =
+            dst[((size_t)(t0 + t) * 4 + ib) * plane + (size_t)m * N + n0 + q] =
                 tile[(dy * 2 * CONV_TQ + 2 * q + dx) * pitch + t];
         }
     } else {
@@ -239,13 +242,13 @@ state_mosaic_kernel(const float* __restrict__ src, float* __restrict__ dst, int 
             const int q = i % nq, ib = (i / nq) & 3, t = i / (4 * nq);
             const int dy = ib >> 1, dx = ib & 1;
             tile[(dy * 2 * CONV_TQ + 2 * q + dx) * pitch + t] =
-                src[((size_t)t * 4 + ib) * plane + (size_t)m * N + n0 + q];
+                src[((size_t)(t0 + t) * 4 + ib) * plane + (size_t)m * N + n0 + q];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * per_row; i += blockDim.x) {
             const int dy = i / per_row, j = i % per_row;
             const int px = j / B, t = j % B;
-            dst[((size_t)(2 * m + dy) * W + 2 * n0) * B + j] = tile[(dy * 2 * CONV_TQ + px) * pitch + t];
+            dst[((size_t)(2 * m + dy) * W + 2 * n0 + px) * Bt + t0 + t] = tile[(dy * 2 * CONV_TQ + px) * pitch + t];
         }
     }
 }
@@ -261,33 +264,38 @@ y_to_meas_kernel(const float* __restrict__ y, float* __restrict__ meas, int M, i
     meas[gid] = y[(size_t)(2 * m + (ib >> 1)) * (2 * N) + 2 * n + (ib & 1)];
 }
 
-// planar rgb [B][3][H][W] <-> cube (H,W,3,B): block = one image row x 64 columns, through LDS
+// planar rgb [B][3][H][W] <-> cube (H,W,3,B): block = one image row x 64 columns x up to 64 frames, through LDS
 template <bool TO_CUBE>
 __global__ void __launch_bounds__(256)
-rgb_cube_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int B) {
+rgb_cube_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Bt) {
     extern __shared__ float tile[];  // [64 px][3*B + 1]
     const int r = blockIdx.y;
     const int c0 = blockIdx.x * 64;
     const int nc = min(64, W - c0);
+    const int t0 = blockIdx.z * CONV_FC, B = min(CONV_FC, Bt - t0);
     const int CB = 3 * B, pitch = CB + 1;
     const size_t HW = (size_t)H * W;
     if (TO_CUBE) {
         for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
             const int px = i % nc, ch_t = i / nc;  // ch_t = t*3 + c in the planar source order
             const int t = ch_t / 3, c = ch_t % 3;
-            tile[px * pitch + c * B + t] = src[(size_t)ch_t * HW + (size_t)r * W + c0 + px];
+            tile[px * pitch + c * B + t] = src[((size_t)(t0 + t) * 3 + c) * HW + (size_t)r * W + c0 + px];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x)
-            dst[((size_t)r * W + c0) * CB + i] = tile[(i / CB) * pitch + (i % CB)];
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
+            const int px = i / CB, ct = i % CB, c = ct / B, t = ct % B;
+            dst[(((size_t)r * W + c0 + px) * 3 + c) * Bt + t0 + t] = tile[px * pitch + ct];
+        }
     } else {
-        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x)
-            tile[(i / CB) * pitch + (i % CB)] = src[((size_t)r * W + c0) * CB + i];
+        for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
+            const int px = i / CB, ct = i % CB, c = ct / B, t = ct % B;
+            tile[px * pitch + ct] = src[(((size_t)r * W + c0 + px) * 3 + c) * Bt + t0 + t];
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < CB * nc; i += blockDim.x) {
             const int px = i % nc, ch_t = i / nc;
             const int t = ch_t / 3, c = ch_t % 3;
-            dst[(size_t)ch_t * HW + (size_t)r * W + c0 + px] = tile[px * pitch + c * B + t];
+            dst[((size_t)(t0 + t) * 3 + c) * HW + (size_t)r * W + c0 + px] = tile[px * pitch + c * B + t];
         }
     }
 }
@@ -579,9 +587,9 @@ int scipnp_bayer_merge(const float* planes, float* mosaic, int M, int N, int B, 
 }
 
 static int state_mosaic(const float* src, float* dst, int M, int N, int B, bool to_state, hipStream_t st) {
-    SCIPNP_REQUIRE(src && dst && M > 0 && N > 0 && B > 0 && B <= 64, "bad arguments (B <= 64)");
-    const dim3 grid((N + CONV_TQ - 1) / CONV_TQ, M);
-    const size_t lds = (size_t)2 * 2 * CONV_TQ * (B + 1) * sizeof(float);
+    SCIPNP_REQUIRE(src && dst && M > 0 && N > 0 && M <= 65535 && B > 0 && B <= 64 * 65535, "bad arguments");
+    const dim3 grid((N + CONV_TQ - 1) / CONV_TQ, M, (B + CONV_FC - 1) / CONV_FC);
+    const size_t lds = (size_t)2 * 2 * CONV_TQ * ((B < CONV_FC ? B : CONV_FC) + 1) * sizeof(float);
     if (to_state) hipLaunchKernelGGL(state_mosaic_kernel<true>, grid, dim3(256), lds, st, src, dst, M, N, B);
     else hipLaunchKernelGGL(state_mosaic_kernel<false>, grid, dim3(256), lds, st, src, dst, M, N, B);
     return launch_status("state_mosaic_kernel");
@@ -602,9 +610,9 @@ int scipnp_y_to_meas(const float* y, float* meas, int M, int N, scipnp_stream_t 
 }
 
 static int rgb_cube(const float* src, float* dst, int H, int W, int B, bool to_cube, hipStream_t st) {
-    SCIPNP_REQUIRE(src && dst && H > 0 && W > 0 && B > 0 && B <= 64, "bad arguments (B <= 64)");
-    const dim3 grid((W + 63) / 64, H);
-    const size_t lds = (size_t)64 * (3 * B + 1) * sizeof(float);
+    SCIPNP_REQUIRE(src && dst && H > 0 && W > 0 && H <= 65535 && B > 0 && B <= 64 * 65535, "bad arguments");
+    const dim3 grid((W + 63) / 64, H, (B + CONV_FC - 1) / CONV_FC);
+    const size_t lds = (size_t)64 * (3 * (B < CONV_FC ? B : CONV_FC) + 1) * sizeof(float);
     if (to_cube) hipLaunchKernelGGL(rgb_cube_kernel<true>, grid, dim3(256), lds, st, src, dst, H, W, B);
     else hipLaunchKernelGGL(rgb_cube_kernel<false>, grid, dim3(256), lds, st, src, dst, H, W, B);
     return launch_status("rgb_cube_kernel");

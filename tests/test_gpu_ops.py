@@ -145,6 +145,15 @@ def test_layout_conversions_bit_exact(ops):
     rgb = ops.cube_to_rgb(cube)
     assert torch.equal(rgb.cpu(), cube.cpu().permute(3, 2, 0, 1))
     assert torch.equal(ops.rgb_to_cube(rgb).cpu(), cube.cpu())
+    # more than 64 frames: the conversions walk the frames in chunks of 64
+    for B in (64, 65, 130, 200):
+        m = dev(rng.uniform(size=(6, 70, B)).astype(np.float32))
+        st = ops.mosaic_to_state(m)
+        assert torch.equal(state_to_planes(st).cpu(), OO.bayer_split(m.cpu()))
+        assert torch.equal(ops.state_to_mosaic(st), m)
+        c = dev(rng.uniform(size=(3, 70, 3, B)).astype(np.float32))
+        r = ops.cube_to_rgb(c)
+        assert torch.equal(r.cpu(), c.cpu().permute(3, 2, 0, 1)) and torch.equal(ops.rgb_to_cube(r), c)
 
 
 @pytest.mark.parametrize('kernel', [1, 2, 3], ids=['tiled', 'whole-plane', 'banded'])
