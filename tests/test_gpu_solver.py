@@ -664,3 +664,22 @@ def test_ffdnet_solver_single_frame_and_sigma_lists(solver, ffdnet_state_dict):
     a = solver.twoStageAdmm_denoise_bayer(y, Phi, denoiser='ffdnet_color', iter_max=2, sigma=25 / 255, model_denoise=net, logf=io.StringIO())
     b = solver.twoStageAdmm_denoise_bayer(y, Phi, denoiser='ffdnet_color', iter_max=[2], sigma=[25 / 255], model_denoise=net, logf=io.StringIO())
     assert np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 11])
+def test_fastdvdnet_solver_short_and_odd_cubes(solver, B):
+    """the 5-frame circular temporal window on cubes shorter than the window and with odd frame counts
+    (fastdvdnet.py:104-115: indices modulo the number of frames): per-iterate parity with the oracle"""
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
+    y, Phi, orig = synth.make_problem(32, 48, B, seed=30 + B)
+    net = cpu_data_parallel(synth_fastdvdnet_weights(3))
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [2], False, [8 / 255], X_orig=orig,
+                                            model_denoise=net, logf=io.StringIO())
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [2], [8 / 255], X_orig=orig, model_denoise=net)
+    for k in range(2):
+        assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, (B, k, rel_l2(tr.it[k], o['theta_iterates'][k]))
+    assert rel_l2(res[0], o['rgb']) <= REL_TOL
