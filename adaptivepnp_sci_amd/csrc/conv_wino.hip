@@ -67,7 +67,9 @@ struct WinoArgs {
 // Software pipeline, one barrier per channel group g:  the MFMAs of group g run on V_g (registers) and U_g (LDS) while
 // the same wave reads the raw patch of group g+1 from LDS and transforms it into V_{g+1} between the MFMAs; the raw tile
 // of group g+2 travels global -> registers -> LDS and U_{g+1} global -> LDS (LDS-DMA) under the same MFMAs.
-template <int TAG, int NW>
+// NH = 16-channel halves of the 32-channel output block that hold real channels (1 for layers with <= 16 outputs, e.g.
+// the 12-channel FFDNet tail: the padding half is never multiplied).
+template <int TAG, int NW, int NH = 2>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv3x3_c8w_kernel(const WinoArgs a) {
     using K = WinoCfg<NW>;
@@ -146,11 +148,11 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         }
     };
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NH];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) acc[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NH; ++h) acc[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS offsets (floats)
     const int b_off = q * K::PLANE + ((2 * wv) * K::TWP + 2 * tn) * 2;              // + (dy*TWP + dx)*2
@@ -237,7 +239,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
                     acc[p][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[h * 2 + j], V[p >> 2][p & 3][j], acc[p][h], 0, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);                 // keep every slice under its own four MFMAs
@@ -257,7 +259,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int cog = split * 4 + h * 2 + (q >> 1);
         if (cog >= a.CGout) continue;
         const f32x4 bs = *(const f32x4*)(bias + cog * 8 + 4 * (q & 1));
@@ -373,6 +375,16 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
         attr_set[vi] = true;
     }
     const dim3 grid((unsigned)total), block(big ? 512 : 256);
+    if (!big && Cout <= 16) {                                   // one real 16-channel half: TAG 1 (first / last layers) only
+        static bool half_set = false;
+        if (!half_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w half): %s", hipGetErrorString(e));
+            half_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 4, 1>), grid, block, lds, (hipStream_t)s, a);
+        return launch_status("conv3x3_c8w_kernel<1,4,1>");
+    }
     switch (vi) {
         case 0: hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4>), grid, block, lds, (hipStream_t)s, a); break;
         case 1: hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 8>), grid, block, lds, (hipStream_t)s, a); break;
