@@ -10,8 +10,10 @@ extern "C" {
 
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s) {
     SCIPNP_REQUIRE(a, "null argument block");
-    SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_in_c8s &&
-                   a->net_out_c8 && a->packed_split && a->scratch0 && a->scratch1, "null pointer in argument block");
+    const bool f32 = a->packed_wino != nullptr;
+    SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_out_c8 && a->scratch0 &&
+                   a->scratch1 && (f32 ? (a->net_in_c8 != nullptr) : (a->net_in_c8s && a->packed_split)),
+                   "null pointer in argument block");
     SCIPNP_REQUIRE(a->rho > 0.0 && a->tau > 0.0, "rho and tau must be positive");
     const int M = a->M, N = a->N, B = a->B;
     // one rounding from double, like the reference's Python scalars handed to PyTorch (1 / rou, alpha * rou, 1 / tau)
@@ -19,12 +21,16 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
     // x = p + Phi^T((y - Phi p)/(alpha rho + Phi Phi^T)),  p = theta - b/rho                      (:128-140)
     int rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, inv_rho, alpha_rho, s);
     if (rc) return rc;
-    // mosaic of x + b/rho, Malvar demosaic, x_rgb - w/tau, FFDNet input (pixel-unshuffle + sigma map, c8s)   (:168-198)
-    rc = scipnp_pm_pre_denoise_ex(a->x, a->b, a->w, a->x_rgb, nullptr, nullptr, a->net_in_c8s, M, N, B, inv_rho, inv_tau,
-                                  a->sigma, s);
+    // mosaic of x + b/rho, Malvar demosaic, x_rgb - w/tau, FFDNet input (pixel-unshuffle + sigma map, c8s or fp32 c8)   (:168-198)
+    rc = scipnp_pm_pre_denoise_ex(a->x, a->b, a->w, a->x_rgb, nullptr, f32 ? a->net_in_c8 : nullptr,
+                                  f32 ? nullptr : a->net_in_c8s, M, N, B, inv_rho, inv_tau, a->sigma, s);
     if (rc) return rc;
-    rc = scipnp_ffdnet_forward_c8s(a->net_in_c8s, a->net_out_c8, a->packed_split, a->nb, a->nc, a->scratch0, a->scratch1, B, M,
-                                   N, s);
+    if (f32)
+        rc = scipnp_ffdnet_forward_c8w(a->net_in_c8, a->net_out_c8, a->packed_wino, a->nb, a->nc, (float*)a->scratch0,
+                                       (float*)a->scratch1, B, M, N, s);
+    else
+        rc = scipnp_ffdnet_forward_c8s(a->net_in_c8s, a->net_out_c8, a->packed_split, a->nb, a->nc, a->scratch0, a->scratch1,
+                                       B, M, N, s);
     if (rc) return rc;
     // theta = clip(CFA samples of the denoised frames), b += x - theta, w += x_rgb - out, PSNR partials   (:206-209, :265-281)
     return scipnp_pm_post_denoise(nullptr, a->net_out_c8, a->out_rgb, a->x, a->x_rgb, a->theta, a->b, a->w, a->orig,

@@ -406,6 +406,11 @@ typedef struct {
                                          * (1.0f/0.55f is one ulp away from float(1/0.55)) */
     float sigma;
     int first_iter;                     /* 1 on the very first iteration (x and theta are one tensor there) */
+    /* fp32 arithmetic instead of split-fp16 (zero-initialised blocks keep the split path): when packed_wino != NULL the
+     * FFDNet pass runs on the Winograd fp32 kernel (scipnp_ffdnet_forward_c8w) from net_in_c8; packed_split / net_in_c8s
+     * may then be NULL */
+    const float* const* packed_wino;    /* nb layers packed by scipnp_pack_conv3x3_wino */
+    float* net_in_c8;                   /* FFDNet input [B][2][M][N][8] fp32 */
 } scipnp_twostage_ffdnet_args;
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
 

@@ -64,6 +64,19 @@ def test_plain_c_host_reconstructs_like_the_python_solver(tmp_path):
     ref = twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [iters], False, [float(sigma)], x0_bayer=warm,
                                      model_denoise=net, logf=io.StringIO())[1]
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    # the same from C in fp32 arithmetic (Winograd kernels; scipnp_twostage_ffdnet_args.packed_wino / net_in_c8)
+    out32 = str(tmp_path / 'out32.bin')
+    r = subprocess.run([exe, blob, out32, 'f32'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'fp32 Winograd' in r.stdout, r.stdout + r.stderr
+    got32 = np.fromfile(out32, np.float32).reshape(H, W, B)
+    os.environ['SCIPNP_CONV_PRECISION'] = 'f32'
+    try:
+        ref32 = twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [iters], False, [float(sigma)], x0_bayer=warm,
+                                           model_denoise=net, logf=io.StringIO())[1]
+    finally:
+        os.environ.pop('SCIPNP_CONV_PRECISION', None)
+    assert np.array_equal(got32, ref32), float(np.abs(got32 - ref32).max())
+    assert not np.array_equal(got32, got) and float(np.abs(got32 - got).max()) < 1e-4
 
 
 @pytest.mark.gpu
