@@ -209,11 +209,8 @@ def alloc_denblock_buffers_split(B, H, W, device, alias=True):
     return b
 
 
-def denblock_forward_split(pk, frames, sigma, out, b):
-    """denblock_forward on the split-fp16 kernels: c8s activations; the two UpBlock convs store their PixelShuffle-d
-    result plus the skip tensor straight into c8s (epilogue flag bit6)."""
+def _denblock_convs_split(pk, b):
     c = ops.conv3x3_c8s
-    ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'])
     c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
     c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
     c(b['x0'], pk[2], 64, relu=True, stride2=True, out=b['a0'])
@@ -230,6 +227,15 @@ def denblock_forward_split(pk, frames, sigma, out, b):
     c(b['c1'], pk[13], 128, shuffle=True, residual=b['x0'], out=b['s32'])      # x0 + upc1(.)
     c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
     c(b['o32'], pk[15], 8, out=b['x8'], f32_out=True)
+
+
+def denblock_forward_split(pk, frames, sigma, out, b):
+    """denblock_forward on the split-fp16 kernels: c8s activations; the two UpBlock convs store their PixelShuffle-d
+    result plus the skip tensor straight into c8s (epilogue flag bit6).  The 16 convolutions run as two half-batches of
+    frames on two HIP streams (SCIPNP_STREAMS=1 keeps one): the quarter- and half-resolution layers are grids of 1.3 - 2.7
+    generations of workgroups, and the second stream's launches fill the CUs the first one's last generation leaves idle."""
+    ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'])
+    ops.on_side_streams(b['t_in'].shape[0], lambda sl: _denblock_convs_split(pk, {k: v[sl] for k, v in b.items()}))
     return ops.fastdvd_finish(frames, b['x8'], out)
 
 

@@ -3,6 +3,7 @@ device allocator and stream provider: every function takes CUDA(ROCm) float32 te
 them, and passes raw device pointers plus the current HIP stream to libscipnp.so.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -534,6 +535,46 @@ def sum_rows_f64(part, out=None):
         out = torch.empty(t.shape[0], dtype=torch.float64, device=part.device)
     _call('scipnp_sum_rows_f64', _p(t, 'part', torch.float64), _p(out, 'out', torch.float64), t.shape[0], t.shape[1], _stream())
     return out
+
+
+_SIDE_STREAMS = {}                  # (device, caller's stream) -> its side streams
+_SIDE_LOCK = threading.Lock()
+
+
+def side_stream_count():
+    """SCIPNP_STREAMS (default 2): HIP streams a batched network pass is spread over, 1 = everything on the caller's stream"""
+    import os
+    n = int(os.environ.get('SCIPNP_STREAMS', '2'))
+    if n < 1 or n > 8:
+        raise ValueError('SCIPNP_STREAMS must be 1..8')
+    return n
+
+
+def on_side_streams(n_items, fn):
+    """fn(slice) for contiguous chunks of range(n_items), one chunk per side stream; the side streams start behind the
+    caller's stream and the caller's stream continues behind all of them.  Independent items (frames of a batched
+    network pass) only: grids that do not fill the last generation of workgroups overlap with the other streams' launches."""
+    n = min(side_stream_count(), n_items)
+    if n <= 1:
+        fn(slice(0, n_items))
+        return
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev)
+    key = (dev, cur.cuda_stream)
+    with _SIDE_LOCK:                     # harness.py drives several scenes from threads, each on its own stream
+        pool = _SIDE_STREAMS.get(key, [])
+        if len(pool) < n:
+            pool = _SIDE_STREAMS[key] = pool + [torch.cuda.Stream(dev) for _ in range(n - len(pool))]
+    bounds = [round(i * n_items / n) for i in range(n + 1)]
+    used = []
+    for st, lo, hi in zip(pool, bounds[:-1], bounds[1:]):
+        if hi > lo:
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                fn(slice(lo, hi))
+            used.append(st)
+    for st in used:
+        cur.wait_stream(st)
 
 
 def split_overflow(reset=True):
