@@ -550,6 +550,17 @@ def side_stream_count():
     return n
 
 
+def _side_pool(n):
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev)
+    key = (dev, cur.cuda_stream)
+    with _SIDE_LOCK:                     # harness.py drives several scenes from threads, each on its own stream
+        pool = _SIDE_STREAMS.get(key, [])
+        if len(pool) < n:
+            pool = _SIDE_STREAMS[key] = pool + [torch.cuda.Stream(dev) for _ in range(n - len(pool))]
+    return cur, pool
+
+
 def on_side_streams(n_items, fn):
     """fn(slice) for contiguous chunks of range(n_items), one chunk per side stream; the side streams start behind the
     caller's stream and the caller's stream continues behind all of them.  Independent items (frames of a batched
@@ -558,13 +569,7 @@ def on_side_streams(n_items, fn):
     if n <= 1:
         fn(slice(0, n_items))
         return
-    dev = torch.cuda.current_device()
-    cur = torch.cuda.current_stream(dev)
-    key = (dev, cur.cuda_stream)
-    with _SIDE_LOCK:                     # harness.py drives several scenes from threads, each on its own stream
-        pool = _SIDE_STREAMS.get(key, [])
-        if len(pool) < n:
-            pool = _SIDE_STREAMS[key] = pool + [torch.cuda.Stream(dev) for _ in range(n - len(pool))]
+    cur, pool = _side_pool(n)
     bounds = [round(i * n_items / n) for i in range(n + 1)]
     used = []
     for st, lo, hi in zip(pool, bounds[:-1], bounds[1:]):
