@@ -33,6 +33,7 @@ namespace scipnp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int WN_STAMP_WORDS = 80;                    // per workgroup, diagnostic instantiation only
 constexpr int WN_SLAB = 16 * 32 * 8;                  // 4096 floats = 16 KiB: U of one (channel group, co block)
 
 // NW = waves per workgroup = tile rows of 2 output rows each: the workgroup covers 2*NW rows x 32 columns x 32 co
@@ -60,7 +61,20 @@ struct WinoArgs {
     int H, W;
     int ntx, nty;
     int flags;
+    unsigned long long* dbg; // diagnostic build only (STAMP): 8 words per workgroup, see scipnp_conv3x3_c8w_stamped
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// one clock stamp (cdna_hip_programming.md 7, In-kernel stamps): only ever executed by the STAMP instantiation
+#define WINO_STAMP(t)                                                                        \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define WINO_STAMP(t) (t) = 0
+#endif
 
 // TAG only changes the symbol name (1 = first / last layer of a network) so profiler statistics of the body layers stay clean.
 //
@@ -69,10 +83,17 @@ struct WinoArgs {
 // of group g+2 travels global -> registers -> LDS and U_{g+1} global -> LDS (LDS-DMA) under the same MFMAs.
 // NH = 16-channel halves of the 32-channel output block that hold real channels (1 for layers with <= 16 outputs, e.g.
 // the 12-channel FFDNet tail: the padding half is never multiplied).
-template <int TAG, int NW, int NH = 2>
+template <int TAG, int NW, int NH = 2, bool STAMP = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv3x3_c8w_kernel(const WinoArgs a) {
     using K = WinoCfg<NW>;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, rt0 = 0;
+    if constexpr (STAMP) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        WINO_STAMP(ts0);
+    }
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
     float* const raw_lds = smem_w;                     // [2][RAW]
     float* const u_lds = smem_w + 2 * K::RAW;          // [2][SLAB]
@@ -128,16 +149,18 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 #endif
         if (!last) in_g += HW * 8;
     };
-    auto issue_u = [&](float* dst, bool last) {
+    auto issue_u_piece = [&](float* dst, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
         auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, WN_SLAB * 4, 0x00020000);
         char* ub = (char*)dst;
-#pragma unroll
-        for (int k = 0; k < K::U_ITERS; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r_w, (__attribute__((address_space(3))) void*)(ub + 16 * (wvu * 64 + k * K::THREADS)), 16,
-                (unsigned)(16 * (tid + k * K::THREADS)), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            r_w, (__attribute__((address_space(3))) void*)(ub + 16 * (wvu * 64 + k * K::THREADS)), 16,
+            (unsigned)(16 * (tid + k * K::THREADS)), 0, 0, 0);
 #endif
+    };
+    auto issue_u = [&](float* dst, bool last) {
+#pragma unroll
+        for (int k = 0; k < K::U_ITERS; ++k) issue_u_piece(dst, k);
         if (!last) w_g += w_step;
     };
     auto write_raw = [&](float* dst, const f32x4 (&st)[K::IN_ITERS]) {
@@ -176,6 +199,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         write_raw(raw_lds + K::RAW, st_b);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (STAMP) WINO_STAMP(ts1);
         float d[4][4][2];
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) load_patch_row(raw_lds, dy, d[dy]);
@@ -201,9 +225,10 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     auto group_step = [&](int cig, const float (&V)[4][4][2], float (&Vn)[4][4][2]) {
         const int cur = cig & 1;
         const float* ucur = u_lds + cur * WN_SLAB;
+        float* const udst = u_lds + (cur ^ 1) * WN_SLAB;        // U of group cig+1 -> LDS
+        const bool ulast = cig + 2 >= CG;
         const float* rnext = raw_lds + (cur ^ 1) * K::RAW;      // raw tile of group cig+1 (stale after the last group: unused)
         issue_raw(st_in, cig + 3 >= CG);                        // raw tile of group cig+2 -> registers
-        issue_u(u_lds + (cur ^ 1) * WN_SLAB, cig + 2 >= CG);    // U of group cig+1 -> LDS
         float d[4][4][2];
         f32x4 af[3];                                            // U fragments of positions p, p+1, p+2 (rotating)
         af[0] = *(const f32x4*)(ucur + a_off);
@@ -211,6 +236,10 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             if (p < 14) af[(p + 2) % 3] = *(const f32x4*)(ucur + a_off + (p + 2) * 256);
+            // the LDS-DMA pieces of the next group's U slab one at a time under positions 1, 3, 5, 7: four in a row at the
+            // head of the group cost 3 % (tools/probes/wino_stamps.py: position 0 took twice a middle position's time)
+            if ((p & 1) && (p >> 1) < K::U_ITERS) issue_u_piece(udst, p >> 1);
+            if (p == 2 * K::U_ITERS - 1 && !ulast) w_g += w_step;
             // slices of the next group's input transform, spread under the MFMAs of this group
             if (p < 4) {
                 load_patch_row(rnext, p, d[p]);
@@ -244,16 +273,30 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);                 // keep every slice under its own four MFMAs
 #endif
+            if constexpr (STAMP) {                             // detail (flags bit11): after every position of groups 4 and 5
+                if ((a.flags & 0x800) && (cig == 4 || cig == 5)) {
+                    unsigned long long tq;
+                    WINO_STAMP(tq);
+                    if (tid == 0) a.dbg[(size_t)blockIdx.x * WN_STAMP_WORDS + 32 + (cig - 4) * 16 + p] = tq;
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next group's U slab (LDS-DMA) has landed
         __syncthreads();
+        if constexpr (STAMP) {                                 // end of group cig, words 8.. of the workgroup's record
+            unsigned long long tg;
+            WINO_STAMP(tg);
+            if (tid == 0 && a.dbg && cig < 24) a.dbg[(size_t)blockIdx.x * WN_STAMP_WORDS + 8 + cig] = tg;
+        }
     };
+    if constexpr (STAMP) WINO_STAMP(ts2);
     int cig = 0;
     for (; cig + 1 < CG; cig += 2) {
         group_step(cig, Va, Vb);
         group_step(cig + 1, Vb, Va);
     }
     if (cig < CG) group_step(cig, Va, Vb);
+    if constexpr (STAMP) WINO_STAMP(ts3);
 
     // ---- output transform  Y = A^T M A, bias, epilogue; lane: tile (wv, tn), channels 32*split + 16*h + 4*q + r
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
@@ -290,6 +333,21 @@ conv3x3_c8w_kernel(const WinoArgs a) {
                 }
                 *(f32x4*)(a.out + o) = v;
             }
+    }
+    if constexpr (STAMP) {
+        WINO_STAMP(ts4);                                       // output transform done, stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WINO_STAMP(ts5);                                       // stores acknowledged
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (tid == 0 && a.dbg) {
+            unsigned long long* d = a.dbg + (size_t)blockIdx.x * WN_STAMP_WORDS;
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = ts5;
+            d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |      // XCC_ID
+                   (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));                             // HW_ID
+            d[7] = __builtin_amdgcn_s_memrealtime();
+            d[31] = rt0;
+        }
+#endif
     }
 }
 
@@ -356,7 +414,7 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     WinoArgs a;
     a.in = in; a.wpk = packed_wino; a.out = out; a.residual = residual; a.mask_src = mask_src;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w(Cout, 32) / 32;
-    a.H = h; a.W = w;
+    a.H = h; a.W = w; a.dbg = nullptr;
     const bool big = (flags & 0x200) != 0;                      // 16-row workgroups of 8 waves (default: 8 rows, 4 waves)
     const int th = big ? WinoCfg<8>::TH : WinoCfg<4>::TH;
     a.ntx = (w + 31) / 32; a.nty = (h + th - 1) / th;
@@ -392,6 +450,26 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
         default: hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 8>), grid, block, lds, (hipStream_t)s, a); break;
     }
     return launch_status("conv3x3_c8w_kernel");
+}
+
+int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float* out, int n, int Cin, int Cout, int h, int w,
+                               int flags, unsigned long long* stamps, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && packed_wino && out && stamps, "null pointer");
+    SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 16 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
+    SCIPNP_REQUIRE((long long)h * w * 8 < (1ll << 31), "image too large for 32-bit tile offsets");
+    WinoArgs a;
+    a.in = in; a.wpk = packed_wino; a.out = out; a.residual = nullptr; a.mask_src = nullptr; a.dbg = stamps;
+    a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w(Cout, 32) / 32;
+    a.H = h; a.W = w;
+    a.ntx = (w + 31) / 32; a.nty = (h + WinoCfg<4>::TH - 1) / WinoCfg<4>::TH;
+    a.flags = flags & (1 | 0x800);
+    const long long total = (long long)a.ntx * a.nty * n * a.NCB;
+    SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    const size_t lds = WinoCfg<4>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<0, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w stamped): %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4, 2, true>), dim3((unsigned)total), dim3(256), lds, (hipStream_t)s, a);
+    return launch_status("conv3x3_c8w_kernel<stamped>");
 }
 
 int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,

@@ -324,6 +324,16 @@ int scipnp_pack_conv3x3_wino(const float* packed_f32, float* packed_wino, int Ci
 int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, const float* residual,
                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* DIAGNOSTIC instantiation of scipnp_conv3x3_c8w (layers with more than 16 outputs, flags bit0 only): the same kernel
+ * with six s_memtime stamps per workgroup; no product path calls it and the product kernel executes no stamp.
+ * stamps: 80 words per workgroup (grid = ceil(w/32)*ceil(h/8)*n*ceil(Cout/32)), written by its first lane:
+ * [0] kernel entry, [1] first raw tiles + U slab in LDS, [2] first input transform done, [3] channel-group loop done,
+ * [4] output transform done and stores issued, [5] stores acknowledged, [6] XCC_ID << 32 | HW_ID, [7] s_memrealtime
+ * (100 MHz) at the end ([31]: at entry), [8 + g] end of channel group g (g < 24); with flags bit11 also
+ * [32 + 16(g - 4) + p] after Winograd position p of groups g = 4, 5.  tools/probes/wino_stamps.py reads them. */
+int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float* out, int n, int Cin, int Cout, int h, int w,
+                               int flags, unsigned long long* stamps, scipnp_stream_t s);
+
 /* The whole FFDNet-colour pass (test_ffdnet_ipol.py:340-359 -> network_ffdnet.py:65-66) as ONE call on the Winograd
  * kernel: same arguments as scipnp_ffdnet_forward with every layer packed by scipnp_pack_conv3x3_wino. */
 int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,
