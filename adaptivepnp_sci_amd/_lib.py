@@ -95,6 +95,7 @@ SIGNATURES = {
     'scipnp_host_legacy_normal': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_double), C.c_double, C.c_double,
                                         _vp, _sz]),
     'scipnp_bench_mfma': (_int, [_vp, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_valu': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),

@@ -32,6 +32,7 @@ namespace scipnp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WN_STAMP_WORDS = 80;                    // per workgroup, diagnostic instantiation only
 constexpr int WN_SLAB = 16 * 32 * 8;                  // 4096 floats = 16 KiB: U of one (channel group, co block)
@@ -183,13 +184,30 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 
     const int CG = a.CGin;
     // one patch row of this lane's tile: pixels 2tn .. 2tn+3 of halo row 2wv + dy, channels (2q, 2q+1)
-    auto load_patch_row = [&](const float* rawp, int dy, float (&row)[4][2]) {
+    // B^T d B of one 4x4 patch for the lane's channel PAIR at once: the pair sits in adjacent registers, so every add of the
+    // transform is one v_pk_add_f32 -- beside v_mfma_f32_16x16x4_f32 a packed add costs the issue time of a scalar one
+    // (tools/probes/mfma_valu_coissue.py), 32 instructions per group instead of 64
+    auto load_patch_row = [&](const float* rawp, int dy, f32x2 (&row)[4]) {
         const f32x4 lo = *(const f32x4*)(rawp + b_off + dy * K::TWP * 2), hi = *(const f32x4*)(rawp + b_off + dy * K::TWP * 2 + 4);
-        row[0][0] = lo[0]; row[0][1] = lo[1]; row[1][0] = lo[2]; row[1][1] = lo[3];
-        row[2][0] = hi[0]; row[2][1] = hi[1]; row[3][0] = hi[2]; row[3][1] = hi[3];
+        row[0] = f32x2{lo[0], lo[1]}; row[1] = f32x2{lo[2], lo[3]};
+        row[2] = f32x2{hi[0], hi[1]}; row[3] = f32x2{hi[2], hi[3]};
+    };
+    auto transform = [&](f32x2 (&d)[4][4], f32x2 (&Vo)[4][4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x2 t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+            d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Vo[r][0] = d[r][0] - d[r][2];
+            Vo[r][1] = d[r][1] + d[r][2];
+            Vo[r][2] = d[r][2] - d[r][1];
+            Vo[r][3] = d[r][1] - d[r][3];
+        }
     };
     f32x4 st_in[K::IN_ITERS];
-    float Va[4][4][2], Vb[4][4][2];          // B^T d B of the current / next group: [xi][nu][channel of the pair]
+    f32x2 Va[4][4], Vb[4][4];                // B^T d B of the current / next group: [xi][nu] x the channel pair
     {   // prologue: raw tiles of groups 0 and 1, U of group 0; then V_0
         f32x4 st_b[K::IN_ITERS];
         issue_raw(st_in, CG <= 1);
@@ -200,36 +218,21 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if constexpr (STAMP) WINO_STAMP(ts1);
-        float d[4][4][2];
+        f32x2 d[4][4];
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) load_patch_row(raw_lds, dy, d[dy]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t0 = d[0][c][e] - d[2][c][e], t1 = d[1][c][e] + d[2][c][e], t2 = d[2][c][e] - d[1][c][e],
-                            t3 = d[1][c][e] - d[3][c][e];
-                d[0][c][e] = t0; d[1][c][e] = t1; d[2][c][e] = t2; d[3][c][e] = t3;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Va[r][0][e] = d[r][0][e] - d[r][2][e];
-                Va[r][1][e] = d[r][1][e] + d[r][2][e];
-                Va[r][2][e] = d[r][2][e] - d[r][1][e];
-                Va[r][3][e] = d[r][1][e] - d[r][3][e];
-            }
-        }
+        transform(d, Va);
     }
 
     // one channel group: MFMAs on (V, U_cig), transform of group cig+1 into Vn, staging of group cig+2 / U_{cig+1}
-    auto group_step = [&](int cig, const float (&V)[4][4][2], float (&Vn)[4][4][2]) {
+    auto group_step = [&](int cig, const f32x2 (&V)[4][4], f32x2 (&Vn)[4][4]) {
         const int cur = cig & 1;
         const float* ucur = u_lds + cur * WN_SLAB;
         float* const udst = u_lds + (cur ^ 1) * WN_SLAB;        // U of group cig+1 -> LDS
         const bool ulast = cig + 2 >= CG;
         const float* rnext = raw_lds + (cur ^ 1) * K::RAW;      // raw tile of group cig+1 (stale after the last group: unused)
         issue_raw(st_in, cig + 3 >= CG);                        // raw tile of group cig+2 -> registers
-        float d[4][4][2];
+        f32x2 d[4][4];
         f32x4 af[3];                                            // U fragments of positions p, p+1, p+2 (rotating)
         af[0] = *(const f32x4*)(ucur + a_off);
         af[1] = *(const f32x4*)(ucur + a_off + 256);
@@ -240,26 +243,16 @@ conv3x3_c8w_kernel(const WinoArgs a) {
             // head of the group cost 3 % (tools/probes/wino_stamps.py: position 0 took twice a middle position's time)
             if ((p & 1) && (p >> 1) < K::U_ITERS) issue_u_piece(udst, p >> 1);
             if (p == 2 * K::U_ITERS - 1 && !ulast) w_g += w_step;
-            // slices of the next group's input transform, spread under the MFMAs of this group
+            // the next group's input transform as ONE block of 32 packed adds: v_mfma_f32_16x16x4_f32 shares the fp32 vector
+            // lanes, so a vector add beside it is never hidden (tools/probes/mfma_valu_coissue.py: 32 cycles per MFMA alone,
+            // 42 + 4 NV with NV adds behind each) -- the transform is issue time to minimise, not work to spread under MFMAs
             if (p < 4) {
                 load_patch_row(rnext, p, d[p]);
-            } else if (p < 8) {
-                const int c = p - 4;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float t0 = d[0][c][e] - d[2][c][e], t1 = d[1][c][e] + d[2][c][e], t2 = d[2][c][e] - d[1][c][e],
-                                t3 = d[1][c][e] - d[3][c][e];
-                    d[0][c][e] = t0; d[1][c][e] = t1; d[2][c][e] = t2; d[3][c][e] = t3;
-                }
-            } else if (p < 12) {
-                const int r = p - 8;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    Vn[r][0][e] = d[r][0][e] - d[r][2][e];
-                    Vn[r][1][e] = d[r][1][e] + d[r][2][e];
-                    Vn[r][2][e] = d[r][2][e] - d[r][1][e];
-                    Vn[r][3][e] = d[r][1][e] - d[r][3][e];
-                }
+            } else if (p == 8) {
+                transform(d, Vn);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);             // ... and not interleaved with this position's MFMAs either
+#endif
             } else if (p == 13) {
                 // raw tile of group cig+2: its LDS buffer held group cig, whose transform finished before the last barrier
                 write_raw(raw_lds + cur * K::RAW, st_in);
@@ -298,41 +291,73 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     if (cig < CG) group_step(cig, Va, Vb);
     if constexpr (STAMP) WINO_STAMP(ts3);
 
-    // ---- output transform  Y = A^T M A, bias, epilogue; lane: tile (wv, tn), channels 32*split + 16*h + 4*q + r
+    // ---- output transform  Y = A^T M A, bias, epilogue; lane: tile (wv, tn), channels 32*split + 16*h + 4*q + r.
+    // Straight-line: the four pixels of a lane go out through a buffer descriptor over the two 8-channel planes of this
+    // 16-channel half -- pixels outside the image and padding channel groups get an offset past its range and are dropped
+    // by the hardware, the flag-dependent parts are three wave-uniform branches per half instead of branches per store
+    // (the epilogue runs beside the partner workgroup's matrix loop and every instruction of it is issue time taken there).
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        const int cog = split * 4 + h * 2 + (q >> 1);
-        if (cog >= a.CGout) continue;
-        const f32x4 bs = *(const f32x4*)(bias + cog * 8 + 4 * (q & 1));
+        const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)
+        if (cog0 >= a.CGout) continue;                         // wave-uniform
+        const bool lane_ok = cog0 + (q >> 1) < a.CGout;
+        const f32x4 bs = *(const f32x4*)(bias + (cog0 + (q >> 1)) * 8 + 4 * (q & 1));          // bias holds CoutP entries
         f32x4 tm[4][2];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
             tm[xi][0] = (acc[xi * 4 + 0][h] + acc[xi * 4 + 1][h]) + acc[xi * 4 + 2][h];
             tm[xi][1] = (acc[xi * 4 + 1][h] - acc[xi * 4 + 2][h]) - acc[xi * 4 + 3][h];
         }
+        f32x4 v[2][2];
+        unsigned off[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int y = y0 + 2 * wv + i, x = x0 + 2 * tn + j;
-                if (y >= H || x >= W) continue;
-                f32x4 v = (i == 0) ? (tm[0][j] + tm[1][j]) + tm[2][j] : (tm[1][j] - tm[2][j]) - tm[3][j];
-                v = v + bs;
-                const size_t o = (((size_t)n * a.CGout + cog) * H + y) * (size_t)W * 8 + (size_t)x * 8 + 4 * (q & 1);
-                if (add_res) v = v + *(const f32x4*)(a.residual + o);
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
-                    const f32x4 fw = *(const f32x4*)(a.mask_src + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (fw[e] > 0.f) ? v[e] : 0.f;
-                }
-                *(f32x4*)(a.out + o) = v;
+                v[i][j] = ((i == 0) ? (tm[0][j] + tm[1][j]) + tm[2][j] : (tm[1][j] - tm[2][j]) - tm[3][j]) + bs;
+                off[i][j] = (lane_ok && y < H && x < W)
+                                ? (unsigned)((y * W + x) * 32 + 16 * (q & 1)) + (unsigned)(q >> 1) * plane_bytes
+                                : 0x80000000u;
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const size_t half0 = ((size_t)n * a.CGout + cog0) * HW * 8;                            // floats
+        if (add_res) {
+            auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + half0), 0, 2 * plane_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v[i][j] = v[i][j] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[i][j], 0, 0));
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][j][e] = fmaxf(v[i][j][e], 0.f);
+        }
+        if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
+            auto r_m = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_src + half0), 0, 2 * plane_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 fw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_m, off[i][j], 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][j][e] = (fw[e] > 0.f) ? v[i][j][e] : 0.f;
+                }
+        }
+        auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + half0), 0, 2 * plane_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j]), r_out, off[i][j], 0, 0);
+#endif
     }
     if constexpr (STAMP) {
         WINO_STAMP(ts4);                                       // output transform done, stores issued
@@ -410,7 +435,7 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     SCIPNP_REQUIRE(!(flags & (4 | 8)), "the Winograd kernel is stride 1 without pixel shuffle");
     SCIPNP_REQUIRE(!(flags & 16) || mask_src, "flag bit4 needs mask_src");
     SCIPNP_REQUIRE(!(flags & 2) || residual, "flag bit1 needs residual");
-    SCIPNP_REQUIRE((long long)h * w * 8 < (1ll << 31), "image too large for 32-bit tile offsets");
+    SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
     WinoArgs a;
     a.in = in; a.wpk = packed_wino; a.out = out; a.residual = residual; a.mask_src = mask_src;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w(Cout, 32) / 32;
@@ -456,7 +481,7 @@ int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float*
                                int flags, unsigned long long* stamps, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && packed_wino && out && stamps, "null pointer");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 16 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
-    SCIPNP_REQUIRE((long long)h * w * 8 < (1ll << 31), "image too large for 32-bit tile offsets");
+    SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
     WinoArgs a;
     a.in = in; a.wpk = packed_wino; a.out = out; a.residual = nullptr; a.mask_src = nullptr; a.dbg = stamps;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w(Cout, 32) / 32;

@@ -531,6 +531,10 @@ int scipnp_host_legacy_normal(uint32_t* key, int* pos, int* has_gauss, double* c
  * floats), mode 1 copies n floats.
  * ------------------------------------------------------------------------------------------------------------- */
 int scipnp_bench_mfma(float* out, int blocks, int iters, int mode, scipnp_stream_t s);
+/* scipnp_bench_mfma_valu: how much vector-ALU issue a matrix instruction hides -- per MFMA (f32 != 0:
+ * v_mfma_f32_16x16x4_f32, else v_mfma_f32_32x32x16_f16; 32 matrix-pipe cycles either way) nv (0, 1, 2, 4, 6, 8) independent
+ * v_add_f32 of the same wave; cycles[blocks*4]: s_memtime ticks of each wave's loop of iters x 16 MFMAs. */
+int scipnp_bench_mfma_valu(float* out, unsigned long long* cycles, int blocks, int iters, int nv, int f32, scipnp_stream_t s);
 int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s);
 
 #ifdef __cplusplus
