@@ -263,7 +263,7 @@ class FastDVDEngine:
         from .nets import f32_conv_form
         self.packed = packed
         self.packed_wino = None
-        if self.precision == 'f32' and f32_conv_form() == 'winograd':
+        if self.precision == 'f32' and f32_conv_form(self.H, self.W) == 'winograd':
             self.packed_wino = {p: wino_packs(pk) for p, pk in packed.items()}
 
     def forward(self, frames, sigma):

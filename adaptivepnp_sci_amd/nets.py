@@ -63,13 +63,19 @@ def default_precision():
     return p
 
 
-def f32_conv_form():
+WINO_MAX_PIXELS = 1 << 25          # csrc/conv_wino.hip addresses a plane through 32-bit buffer offsets: h * w < 2^25
+
+
+def f32_conv_form(h=None, w=None):
     """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, csrc/conv_wino.hip -- 2.25x fewer products, every one an exact
-    fp32 product) or 'direct' (csrc/conv.hip) for the stride-1 layers of the fp32 FFDNet pass; SCIPNP_F32_CONV."""
+    fp32 product) or 'direct' (csrc/conv.hip) for the stride-1 layers of the fp32 FFDNet pass; SCIPNP_F32_CONV.
+    Planes of h x w >= 2^25 pixels (FFDNet on frames beyond 11585 x 11585) take the direct form, which has no such bound."""
     import os
     f = os.environ.get('SCIPNP_F32_CONV', 'winograd')
     if f not in ('winograd', 'direct'):
         raise ValueError("SCIPNP_F32_CONV must be 'winograd' or 'direct'")
+    if f == 'winograd' and h is not None and h * w >= WINO_MAX_PIXELS:
+        return 'direct'
     return f
 
 
@@ -80,7 +86,7 @@ class FFDNetEngine:
         self.device = device
         self.B, self.M, self.N = B, M, N
         self.precision = precision or default_precision()
-        self.f32_form = f32_conv_form() if self.precision == 'f32' else None
+        self.f32_form = f32_conv_form(M, N) if self.precision == 'f32' else None
         self.refresh(model)
         nc = self.nc
         self.scratch = [torch.empty(B * nc * M * N, dtype=torch.float32, device=device) for _ in range(2)]

@@ -316,6 +316,7 @@ int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const f
  * scipnp_pack_conv3x3_weights / _device(_scaled) (so bias, BatchNorm folding and the transposed backward-data packing
  * carry over); layout [Cin/8][CoutP/32][16 positions][co/16][ci/4][co%16][ci%4], then bias[CoutP].
  * flags: bit0 ReLU, bit1 add `residual`, bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag (as conv3x3_c8_ex).
+ * h * w < 2^25 (planes are addressed through 32-bit buffer offsets; SCIPNP_EINVAL beyond -- the engines then use scipnp_conv3x3_c8).
  * -- replaces the same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8 (models/basicblock.py:61-98,
  *    models/network_ffdnet.py:46-48, packages/fastdvdnet/models.py:16-89); the reference's fp32 cuDNN path makes the
  *    same algorithmic choice for 3x3 convolutions. */
