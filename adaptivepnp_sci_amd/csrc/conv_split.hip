@@ -907,20 +907,78 @@ int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n
     return launch_status("c8_scale_to_c8s_kernel");
 }
 
-int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
-                              void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s) {
-    SCIPNP_REQUIRE(in_c8s && out_c8 && packed_split && scratch0 && scratch1, "null pointer");
-    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
-    void* buf[2] = {scratch0, scratch1};
-    int rc = scipnp_conv3x3_c8s(in_c8s, packed_split[0], buf[0], B, 16, nc, M, N, 1 | 0x100, s);
+// frames [n0, n0 + nf) of the pass on stream st
+static int ffdnet_c8s_frames(const char* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc, char* s0,
+                             char* s1, int n0, int nf, int M, int N, scipnp_stream_t st) {
+    const size_t px = (size_t)M * N;
+    const size_t in_f = 2 * px * 32, act_f = (size_t)(nc / 8) * px * 32, out_f = 2 * px * 8;      // bytes, bytes, floats per frame
+    char* buf[2] = {s0 + n0 * act_f, s1 + n0 * act_f};
+    int rc = scipnp_conv3x3_c8s(in_c8s + n0 * in_f, packed_split[0], buf[0], nf, 16, nc, M, N, 1 | 0x100, st);
     if (rc) return rc;
     int cur = 0;
     for (int l = 1; l < nb - 1; ++l) {
-        rc = scipnp_conv3x3_c8s(buf[cur], packed_split[l], buf[cur ^ 1], B, nc, nc, M, N, 1, s);
+        rc = scipnp_conv3x3_c8s(buf[cur], packed_split[l], buf[cur ^ 1], nf, nc, nc, M, N, 1, st);
         if (rc) return rc;
         cur ^= 1;
     }
-    return scipnp_conv3x3_c8s(buf[cur], packed_split[nb - 1], out_c8, B, nc, 16, M, N, 32, s);
+    return scipnp_conv3x3_c8s(buf[cur], packed_split[nb - 1], out_c8 + n0 * out_f, nf, nc, 16, M, N, 32, st);
+}
+
+// SCIPNP_STREAMS (default 2, as adaptivepnp_sci_amd/ops.py on_side_streams): with 2, the second half of the frames runs on a
+// side stream of the calling thread, forked from and joined to the caller's stream by events (legal under hipGraph capture:
+// the side stream joins before the call returns) -- its launches fill the CUs the last generation of the other half leaves idle
+struct SideLane {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int dev = -1;
+};
+
+static int side_lane(SideLane** out) {
+    static thread_local SideLane lanes[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(SCIPNP_EHIP, "hipGetDevice");
+    SideLane& l = lanes[dev];
+    if (!l.st) {
+        if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess)
+            return fail(SCIPNP_EHIP, "side stream of the split-fp16 network pass: %s", hipGetErrorString(hipGetLastError()));
+        l.dev = dev;
+    }
+    *out = &l;
+    return SCIPNP_OK;
+}
+
+static int side_stream_count() {
+    static const int n = [] {
+        const char* e = getenv("SCIPNP_STREAMS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : v;
+    }();
+    return n;
+}
+
+int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                              void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8s && out_c8 && packed_split && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0 && B > 0, "bad network shape nb=%d nc=%d B=%d", nb, nc, B);
+    const char* in = (const char*)in_c8s;
+    char *s0 = (char*)scratch0, *s1 = (char*)scratch1;
+    if (side_stream_count() < 2 || B < 2)
+        return ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, 0, B, M, N, s);
+    SideLane* lane = nullptr;
+    int rc = side_lane(&lane);
+    if (rc) return rc;
+    const int h0 = (B + 1) / 2;
+    hipStream_t cur = (hipStream_t)s;
+    if (hipEventRecord(lane->fork, cur) != hipSuccess || hipStreamWaitEvent(lane->st, lane->fork, 0) != hipSuccess)
+        return fail(SCIPNP_EHIP, "fork of the side stream: %s", hipGetErrorString(hipGetLastError()));
+    rc = ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, h0, B - h0, M, N, (scipnp_stream_t)lane->st);
+    const int rc0 = ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, 0, h0, M, N, s);
+    // join even after a failed launch: the caller's stream must not run ahead of work already queued on the side stream
+    if (hipEventRecord(lane->join, lane->st) != hipSuccess || hipStreamWaitEvent(cur, lane->join, 0) != hipSuccess)
+        return fail(SCIPNP_EHIP, "join of the side stream: %s", hipGetErrorString(hipGetLastError()));
+    return rc ? rc : rc0;
 }
 
 }  // extern "C"

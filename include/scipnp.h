@@ -274,7 +274,9 @@ int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const*
                           float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
 /* the same on the split-fp16 kernels (the default precision): in_c8s [B][2][2][M*N][8] fp16 from
  * scipnp_pm_pre_denoise_ex, fp32 c8 output, packed_split from scipnp_pack_conv3x3_split(_device), two c8s scratch
- * buffers of B*nc*M*N*4 bytes each */
+ * buffers of B*nc*M*N*4 bytes each.  With SCIPNP_STREAMS >= 2 in the environment (the default is 2) and B >= 2 the second
+ * half of the frames runs on a side stream owned by the calling thread, forked from and joined to `s` by events inside
+ * the call (identical results; hipGraph capture on `s` records both branches). */
 int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
                               void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s);
 
