@@ -170,22 +170,27 @@ def denblock_forward(pk, frames, sigma, out, b, pkw=None):
     else:
         c = ops.conv3x3_c8
     ops.fastdvd_pack_triplets(frames, sigma, b['t_in'])
-    c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
-    c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
-    c(b['x0'], pk[2], 64, relu=True, stride2=True, out=b['a0'])
-    c(b['a0'], pk[3], 64, relu=True, out=b['a1'])
-    c(b['a1'], pk[4], 64, relu=True, out=b['x1'])
-    c(b['x1'], pk[5], 128, relu=True, stride2=True, out=b['d0'])
-    c(b['d0'], pk[6], 128, relu=True, out=b['d1'])
-    c(b['d1'], pk[7], 128, relu=True, out=b['x2'])
-    c(b['x2'], pk[8], 128, relu=True, out=b['u0'])
-    c(b['u0'], pk[9], 128, relu=True, out=b['u1'])
-    c(b['u1'], pk[10], 256, shuffle=True, residual=b['x1'], out=b['s64'])     # x1 + upc2(x2)
-    c(b['s64'], pk[11], 64, relu=True, out=b['c0'])
-    c(b['c0'], pk[12], 64, relu=True, out=b['c1'])
-    c(b['c1'], pk[13], 128, shuffle=True, residual=b['x0'], out=b['s32'])     # x0 + upc1(.)
-    c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
-    c(b['o32'], pk[15], 8, out=b['x8'])
+
+    def convs(b):
+        c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
+        c(b['t96'], pk[1], 32, relu=True, out=b['x0'])
+        c(b['x0'], pk[2], 64, relu=True, stride2=True, out=b['a0'])
+        c(b['a0'], pk[3], 64, relu=True, out=b['a1'])
+        c(b['a1'], pk[4], 64, relu=True, out=b['x1'])
+        c(b['x1'], pk[5], 128, relu=True, stride2=True, out=b['d0'])
+        c(b['d0'], pk[6], 128, relu=True, out=b['d1'])
+        c(b['d1'], pk[7], 128, relu=True, out=b['x2'])
+        c(b['x2'], pk[8], 128, relu=True, out=b['u0'])
+        c(b['u0'], pk[9], 128, relu=True, out=b['u1'])
+        c(b['u1'], pk[10], 256, shuffle=True, residual=b['x1'], out=b['s64'])     # x1 + upc2(x2)
+        c(b['s64'], pk[11], 64, relu=True, out=b['c0'])
+        c(b['c0'], pk[12], 64, relu=True, out=b['c1'])
+        c(b['c1'], pk[13], 128, shuffle=True, residual=b['x0'], out=b['s32'])     # x0 + upc1(.)
+        c(b['s32'], pk[14], 32, relu=True, out=b['o32'])
+        c(b['o32'], pk[15], 8, out=b['x8'])
+
+    # two half-batches of frames on two HIP streams, as denblock_forward_split below
+    ops.on_side_streams(b['t_in'].shape[0], lambda sl: convs({k: v[sl] for k, v in b.items()}))
     return ops.fastdvd_finish(frames, b['x8'], out)
 
 
