@@ -572,14 +572,16 @@ def on_side_streams(n_items, fn):
     cur, pool = _side_pool(n)
     bounds = [round(i * n_items / n) for i in range(n + 1)]
     used = []
-    for st, lo, hi in zip(pool, bounds[:-1], bounds[1:]):
-        if hi > lo:
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                fn(slice(lo, hi))
-            used.append(st)
-    for st in used:
-        cur.wait_stream(st)
+    try:
+        for st, lo, hi in zip(pool, bounds[:-1], bounds[1:]):
+            if hi > lo:
+                st.wait_stream(cur)
+                used.append(st)
+                with torch.cuda.stream(st):
+                    fn(slice(lo, hi))
+    finally:                             # also after a failed launch: the caller's stream never runs ahead of queued side work
+        for st in used:
+            cur.wait_stream(st)
 
 
 def split_overflow(reset=True):
