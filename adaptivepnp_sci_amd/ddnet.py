@@ -151,7 +151,13 @@ class _Bufs:
 
 def unet_forward(pk, b, split):
     """the U-Net body of a DenBlock from the packed input b.t_in to the 8-channel fp32 tail b.x8
-    (reference models/network_demosaicking.py:223-238)."""
+    (reference models/network_demosaicking.py:223-238); the evaluations are independent and run as two half-batches on
+    two HIP streams (ops.on_side_streams, SCIPNP_STREAMS) like the FastDVDnet DenBlocks."""
+    ops.on_side_streams(b.t_in.shape[0], lambda sl: _unet_convs(pk, _View(b, sl), split))
+    return b.x8
+
+
+def _unet_convs(pk, b, split):
     if split:
         c = ops.conv3x3_c8s
         c(b.t_in, pk[0], CI, relu=True, out=b.t96)
@@ -265,9 +271,10 @@ class DDnetEngine:
 
 
 class _View:
-    """first-n-evaluations view of a _Bufs (leading dimension slice keeps contiguity)."""
+    """view of a _Bufs on the evaluations n (first n) or a slice of them (a leading-dimension slice keeps contiguity)."""
 
     def __init__(self, b, n):
+        sl = n if isinstance(n, slice) else slice(0, n)
         for k, t in vars(b).items():
             if isinstance(t, torch.Tensor):
-                setattr(self, k, t[:n])
+                setattr(self, k, t[sl])
