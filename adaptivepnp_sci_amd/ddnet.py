@@ -128,6 +128,20 @@ def pack_block(sd, prefix, ch_each_frame, device, split):
     return packed
 
 
+def wino_packs(packed, ch_each_frame):
+    """Winograd-domain weights (csrc/conv_wino.hip) of a block's stride-1 layers without PixelShuffle store (and of the two
+    fusion convolutions, if present), None for the others; derived on the device from the fp32 direct packing"""
+    out = []
+    for i, pk in enumerate(packed):
+        if i < len(_LAYERS):
+            _k, cin, cout, _r, s2, shuf = _LAYERS[i]
+            cin = _p8(3 * ch_each_frame) if cin is None else cin
+            out.append(None if (s2 or shuf) else ops.pack_conv3x3_wino(pk, cin, cout))
+        else:
+            out.append(ops.pack_conv3x3_wino(pk, 8, 8))
+    return out
+
+
 class _Bufs:
     """activation buffers of one DenBlock pass over E evaluations at (h, w); dead buffers are reused."""
 
@@ -149,15 +163,15 @@ class _Bufs:
         self.x8 = f32(8, h, w)
 
 
-def unet_forward(pk, b, split):
+def unet_forward(pk, b, split, pkw=None):
     """the U-Net body of a DenBlock from the packed input b.t_in to the 8-channel fp32 tail b.x8
     (reference models/network_demosaicking.py:223-238); the evaluations are independent and run as two half-batches on
     two HIP streams (ops.on_side_streams, SCIPNP_STREAMS) like the FastDVDnet DenBlocks."""
-    ops.on_side_streams(b.t_in.shape[0], lambda sl: _unet_convs(pk, _View(b, sl), split))
+    ops.on_side_streams(b.t_in.shape[0], lambda sl: _unet_convs(pk, _View(b, sl), split, pkw))
     return b.x8
 
 
-def _unet_convs(pk, b, split):
+def _unet_convs(pk, b, split, pkw=None):
     if split:
         c = ops.conv3x3_c8s
         c(b.t_in, pk[0], CI, relu=True, out=b.t96)
@@ -177,7 +191,11 @@ def _unet_convs(pk, b, split):
         c(b.s0, pk[14], C0, relu=True, out=b.o0)
         c(b.o0, pk[15], 8, out=b.x8, f32_out=True)
     else:
-        c = ops.conv3x3_c8
+        def c(x, w, cout, **kw):                       # fp32: the stride-1 layers in Winograd form where pkw holds them
+            i = next(j for j, p_ in enumerate(pk) if p_ is w)
+            if pkw is None or pkw[i] is None:
+                return ops.conv3x3_c8(x, w, cout, **kw)
+            return ops.conv3x3_c8w(x, pkw[i], cout, **kw)
         c(b.t_in, pk[0], CI, relu=True, out=b.t96)
         c(b.t96, pk[1], C0, relu=True, out=b.x0)
         c(b.x0, pk[2], C1, relu=True, stride2=True, out=b.a0)
@@ -233,6 +251,10 @@ class DDnetEngine:
         self.pk1 = pack_block(sd, 'temp1', 1, dev, sp)
         self.pk2 = pack_block(sd, 'temp2', 3, dev, sp)
         self.pk11 = pack_block(sd, 'temp11', 4, dev, sp)
+        from .nets import f32_conv_form
+        self.pkw1 = self.pkw2 = self.pkw11 = None
+        if not sp and f32_conv_form(self.H, self.W) == 'winograd':
+            self.pkw1, self.pkw2, self.pkw11 = wino_packs(self.pk1, 1), wino_packs(self.pk2, 3), wino_packs(self.pk11, 4)
         B = self.B
         a = sd['weight_tensor_in'].detach().float().reshape(3, 3, 1)           # [j][i][c]
         a2 = sd['weight_tensor_in2'].detach().float().reshape(3, 3, 4)
@@ -248,16 +270,19 @@ class DDnetEngine:
         # stage 1a: mosaic DenBlocks
         bf.t_in = self.t_in8
         ops.ddnet_gather(mosaic, self.idx1, self.scale1, bf.t_in, 1, H, W)
-        unet_forward(self.pk1, bf, sp)
+        unet_forward(self.pk1, bf, sp, self.pkw1)
         ops.ddnet_finish(mosaic, self.idx1, self.scale1, bf.x8, self.s1[:E], 1, 3, H, W)
         # stage 1b: Bayer-plane DenBlocks at half resolution, bilinear x2, fusion
         ops.ddnet_gather(planes, self.idx1, self.scale11, bh.t_in, 4, h, w)
-        unet_forward(self.pk11, bh, sp)
+        unet_forward(self.pk11, bh, sp, self.pkw11)
         ops.ddnet_finish(planes, self.idx1, self.scale11, bh.x8, self.p4, 4, 4, h, w)
         ops.bilinear_up2_c8(self.p4, self.fu_in)
         if sp:
             ops.conv3x3_c8s(self.fu_in, self.pk11[16], 8, relu=True, out=self.fu_mid)
             ops.conv3x3_c8s(self.fu_mid, self.pk11[17], 8, out=bf.x8, f32_out=True)
+        elif self.pkw11 is not None:
+            ops.conv3x3_c8w(self.fu_in, self.pkw11[16], 8, relu=True, out=self.fu_mid)
+            ops.conv3x3_c8w(self.fu_mid, self.pkw11[17], 8, out=bf.x8)
         else:
             ops.conv3x3_c8(self.fu_in, self.pk11[16], 8, relu=True, out=self.fu_mid)
             ops.conv3x3_c8(self.fu_mid, self.pk11[17], 8, out=bf.x8)
@@ -265,7 +290,7 @@ class DDnetEngine:
         # stage 2 on both branches (2B evaluations of temp2)
         bf.t_in = self.t_in16
         ops.ddnet_gather(self.s1, self.idx2, None, bf.t_in[:2 * B], 3, H, W)
-        unet_forward(self.pk2, _View(bf, 2 * B), sp)
+        unet_forward(self.pk2, _View(bf, 2 * B), sp, self.pkw2)
         ops.ddnet_finish(self.s1, self.idx2, None, bf.x8[:2 * B], self.s2, 3, 3, H, W)
         return ops.ddnet_mix(self.s2, self.gates, out)
 
