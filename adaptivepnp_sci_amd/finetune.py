@@ -309,7 +309,7 @@ class _DenBlockTrainer:
     """Master parameters, folded/packed weights, gradients and Adam state of one DenBlock (temp1 / temp2)."""
 
     # per layer: (input buffer key, output-gradient resolution divisor, stride2, shuffle)
-    def __init__(self, sd, prefix, device, lib, split=False):
+    def __init__(self, sd, prefix, device, lib, split=False, wino=False):
         from .fastdvd import _LAYERS, _BN_EPS
         self.lib, self.dev, self.prefix = lib, device, prefix
         self.split = split
@@ -363,6 +363,14 @@ class _DenBlockTrainer:
                           for _, _, ci, co, *_ in _LAYERS]
             self.bwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(co, ci), dtype=torch.uint8, device=device)
                           for _, _, ci, co, *_ in _LAYERS]
+        # fp32 in Winograd form (csrc/conv_wino.hip): the stash forward of the stride-1 layers without PixelShuffle store and
+        # EVERY backward-data convolution (stride-2 layers convolve a zero-upsampled gradient, PixelShuffle layers an
+        # un-shuffled one: all stride-1 3x3 convolutions with the transposed weights); weight gradients stay direct
+        self.fwd_w = self.bwd_w = None
+        if wino and not split:
+            wf = lambda a, c: torch.empty(lib.scipnp_conv3x3_wino_packed_floats(a, c), dtype=F32, device=device)  # noqa: E731
+            self.fwd_w = [None if (s2 or sh) else wf(ci, co) for _, _, ci, co, _r, s2, sh in _LAYERS]
+            self.bwd_w = [wf(co, ci) for _, _, ci, co, *_ in _LAYERS]
         self.dense0 = torch.zeros(90, 12, 3, 3, dtype=F32, device=device)      # block-diagonal form of the grouped conv
         self.G = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]
         # dW[i] (i >= 1) and the grouped form of dW[0] are the flat gradient views; dW[0] itself is the dense scratch
@@ -395,6 +403,10 @@ class _DenBlockTrainer:
                                                              cout, 0, _s()), 'pack fwd')
             _lib.check(lib.scipnp_pack_conv3x3_device_scaled(_ptr(w), None, _ptr(sc), _ptr(self.bwd[i]), ci_r, co_r, cin,
                                                              cout, 1, _s()), 'pack bwd')
+            if self.bwd_w is not None:
+                if self.fwd_w[i] is not None:
+                    ops.pack_conv3x3_wino(self.fwd[i], cin, cout, out=self.fwd_w[i])
+                ops.pack_conv3x3_wino(self.bwd[i], cout, cin, out=self.bwd_w[i])
 
     def grads_of_layer(self, i, x_in, dy, n, h, w, ws, bws, nslab, inv_scale=1.0):
         """parameter gradients of layer i from its input activation and the gradient at its (BN) output; in split mode
@@ -437,8 +449,10 @@ class _FastDVDTrainer:
         self.prefixed = any(k.startswith('module.') for k in self.model_sd)
         sd = _strip(self.model_sd)
         self.split = getattr(eng, 'precision', 'f32') == 'f16x3'
-        self.blocks = {p: _DenBlockTrainer(sd, p, dev, self.lib, self.split) for p in ('temp1', 'temp2')}
         B, H, W = eng.B, eng.H, eng.W
+        from .nets import f32_conv_form
+        wino = (not self.split) and f32_conv_form(H, W) == 'winograd'
+        self.blocks = {p: _DenBlockTrainer(sd, p, dev, self.lib, self.split, wino) for p in ('temp1', 'temp2')}
         if self.split:
             # forward stash, backward-data convolutions and weight gradients on the split-fp16 kernels; gradients travel
             # pre-scaled by the power of two nearest H*W/2 (the loss carries 2/(H*W)) and are un-scaled exactly where
@@ -481,8 +495,8 @@ class _FastDVDTrainer:
             denblock_forward_split(self.blocks['temp1'].fwd_s, frames, sigma, self.s1, self.stash['temp1'])
             denblock_forward_split(self.blocks['temp2'].fwd_s, self.s1, sigma, self.out, self.stash['temp2'])
             return
-        denblock_forward(self.blocks['temp1'].fwd, frames, sigma, self.s1, self.stash['temp1'])
-        denblock_forward(self.blocks['temp2'].fwd, self.s1, sigma, self.out, self.stash['temp2'])
+        denblock_forward(self.blocks['temp1'].fwd, frames, sigma, self.s1, self.stash['temp1'], self.blocks['temp1'].fwd_w)
+        denblock_forward(self.blocks['temp2'].fwd, self.s1, sigma, self.out, self.stash['temp2'], self.blocks['temp2'].fwd_w)
 
     def loss_and_grad(self, y_pm, Phi_pm):
         eng = self.eng
@@ -498,6 +512,8 @@ class _FastDVDTrainer:
         _k, _bn, cin, cout, *_r = blk.spec[i]
         if self.split:
             return ops.conv3x3_c8s(dz, blk.bwd_s[i], cin, out=out, mask=mask, residual=residual)
+        if blk.bwd_w is not None:
+            return ops.conv3x3_c8w(dz, blk.bwd_w[i], cin, residual=residual, mask_src=mask, out=out)
         flags = (2 if residual is not None else 0) | (16 if mask is not None else 0)
         _lib.check(self.lib.scipnp_conv3x3_c8_ex(_ptr(dz), _ptr(blk.bwd[i]), _ptr(out), _ptr(residual), _ptr(mask), n, cout,
                                                  cin, h, w, flags, _s()), 'backward-data conv')
