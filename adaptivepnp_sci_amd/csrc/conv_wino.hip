@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64 * NW, 2)
 conv3x3_c8w_kernel(const WinoArgs a) {
     using K = WinoCfg<NW>;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, rt0 = 0;
+    (void)rt0;
     if constexpr (STAMP) {
 #if defined(__HIP_DEVICE_COMPILE__)
         rt0 = __builtin_amdgcn_s_memrealtime();
@@ -298,6 +299,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     // (the epilogue runs beside the partner workgroup's matrix loop and every instruction of it is issue time taken there).
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
+    (void)relu; (void)add_res; (void)mask;                     // (read by the device-only block below)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)

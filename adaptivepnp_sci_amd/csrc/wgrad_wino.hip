@@ -1,0 +1,324 @@
+// fp32 weight gradient of a 3x3 / pad 1 / stride 1 convolution in the Winograd F(2x2,3x3) domain
+// (reference packages/ffdnet/test_ffdnet_ipol.py:296, packages/fastdvdnet/test_fastdvdnet.py:449 `loss.backward()`):
+//   forward   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile
+//   gradient  dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G
+// 16 exact fp32 products per tile and channel pair instead of the 36 of the direct form (csrc/finetune.hip), accumulated in
+// fp32 on v_mfma_f32_32x32x2_f32 with the TILES as the K dimension:  dU_p[co][ci] = sum_t dM_p[co][t] V_p[ci][t].
+//
+// Workgroup = 16 waves, wave p <-> Winograd position p = 4 xi + nu, 32*COB output channels x 32 input channels; persistent
+// over chunks of 8 tiles (16 x 2 output pixels).  One thread per (tile, channel) of a chunk loads the raw 2x2 output-gradient
+// tile or the raw 4x4 input patch, transforms it in registers and writes its 16 transformed values to LDS
+// [position][tile][channel] -- the operand a lane of the MFMA needs is then ONE ds_read_b32.  The raw loads of chunk k+1 are
+// in flight under the MFMAs of chunk k, its transform + LDS writes follow them, one barrier per chunk, two LDS buffers.
+// v_mfma_f32_32x32x2_f32 shares the fp32 vector lanes with the transform adds (tools/probes/mfma_valu_coissue.py), so the
+// ~50 adds per thread and chunk are matrix time: (768 matrix cycles + ~250) per chunk and wave against 1728 in direct form.
+// fp32 slabs + fixed-order reduction (deterministic, no atomics); the reduction applies G^T . G in double.
+#include "common.hpp"
+#include <type_traits>
+
+namespace scipnp {
+
+typedef float ww_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WW_T = 8;                         // tiles per chunk, along x
+constexpr int WW_THREADS = 16 * 64;
+
+template <int COB>
+struct WwCfg {
+    static constexpr int COP = 32 * COB;                           // output channels of the workgroup
+    static constexpr int NCH = COP + 32;                           // transform threads per tile: dY channels, then input channels
+    static constexpr int M_FLOATS = 16 * WW_T * COP;               // dM [p][tile][co]
+    static constexpr int V_FLOATS = 16 * WW_T * 32;                // V  [p][tile][ci]
+    static constexpr int BUF_FLOATS = M_FLOATS + V_FLOATS;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
+    static_assert(WW_T * NCH <= WW_THREADS && (WW_T * COP) % 64 == 0, "one transform thread per (tile, channel), roles by wave");
+};
+
+// grid = (nslab, Cin/32 blocks).  act: [n][CGin][h][w][8], dz: [n][CGout][h][w][8];
+// slab layout: slabs[slab][p 16][coP][ciP]  (coP = 32*COB, ciP = 32*gridDim.y)
+template <int COB>
+__global__ void __launch_bounds__(WW_THREADS)
+conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict__ dz, float* __restrict__ slabs, int n_img,
+                          int CGin, int CGout, int cg0 /* first output channel group of this launch */, int H, int W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Cfg = WwCfg<COB>;
+    extern __shared__ __attribute__((aligned(16))) float smem_ww[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, p = tid >> 6;                      // MFMA phase: wave <-> position
+    const int li = lane & 31, lh = lane >> 5;
+    const int cib = blockIdx.y;
+    const size_t HW = (size_t)H * W;
+    const int tiles_x = (W + 1) / 2, tiles_y = (H + 1) / 2;
+    const int chunks_x = (tiles_x + WW_T - 1) / WW_T;
+    const int chunks = n_img * tiles_y * chunks_x;
+    const unsigned dz_bytes = (unsigned)((size_t)n_img * CGout * HW * 32), act_bytes = (unsigned)((size_t)n_img * CGin * HW * 32);
+    (void)dz_bytes; (void)act_bytes;
+
+    // transform role of this thread: tile tl of the chunk and one channel of the output gradient or of the input
+    // whole waves share a role (the first 8*COP threads take the output-gradient channels, the next 256 the input channels):
+    // the role is a scalar, so the two load paths are uniform branches and the loads stay asynchronous past them (with lanes
+    // of both roles in one wave the compiler merged the two paths' registers right after the loads and waited for them there)
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid);
+    const bool is_dz = wave_first < WW_T * Cfg::COP;
+    const int t2 = tid - WW_T * Cfg::COP;
+    const int tl = is_dz ? tid / Cfg::COP : t2 / 32;
+    const int chl = is_dz ? tid - tl * Cfg::COP : t2 - tl * 32;          // channel inside its tensor block
+    const bool t_on = tl < WW_T;
+    const int cgl = chl >> 3, cl = chl & 7;
+    const bool ch_on = t_on && (is_dz ? (cg0 + cgl < CGout) : (cib * 4 + cgl < CGin));
+    // LDS float offset of this thread's value of position 0; position q adds q * WW_T * (COP or 32)
+    const int w_off = is_dz ? (tl * Cfg::COP + chl) : (Cfg::M_FLOATS + tl * 32 + chl);
+    const int w_step = is_dz ? WW_T * Cfg::COP : WW_T * 32;
+
+    // raw loads through buffer descriptors over the whole tensors: the chunk origin is a scalar offset, the per-load byte
+    // offsets below are constants of the thread -- no vector arithmetic per chunk (it would be matrix time on this MFMA).
+    // The input patch origin is shifted by (-1, -1) so that every offset is non-negative; loads that fall off the image on
+    // an edge chunk (bit k of the masks for the chunk being in the first / last tile row / chunk column) get an offset past
+    // the descriptor's range and read 0 without touching memory.
+    constexpr int NL = 16;                                        // loads per thread: 4 (2x2 tile) or 16 (4x4 patch)
+    const int nl = is_dz ? 4 : 16;
+    unsigned voff[NL];
+    unsigned mT = 0, mB = 0, mL = 0, mR = 0;
+    {
+        const size_t chan = (size_t)(is_dz ? (cg0 + cgl) : (cib * 4 + cgl)) * HW * 32 + 4 * cl;
+        const int ty_last = tiles_y - 1, cx_last = chunks_x - 1;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int dy = is_dz ? (k >> 1) : (k >> 2), dx = (is_dz ? (k & 1) : (k & 3)) + 2 * tl;   // from the (shifted) origin
+            voff[k] = (ch_on && k < nl) ? (unsigned)(chan + ((size_t)dy * W + dx) * 32) : 0xFFFFFFFFu;
+            const int sh = is_dz ? 0 : -1;
+            if (dy + sh < 0) mT |= 1u << k;                                    // ty == 0
+            if (2 * ty_last + dy + sh >= H) mB |= 1u << k;                     // ty == ty_last
+            if (dx + sh < 0) mL |= 1u << k;                                    // cx == 0
+            if (2 * WW_T * cx_last + dx + sh >= W) mR |= 1u << k;              // cx == cx_last
+        }
+    }
+    const size_t img_bytes = (size_t)(is_dz ? CGout : CGin) * HW * 32;
+    (void)img_bytes;
+
+    ww_f32x16 acc[COB];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+    // MFMA operands: A[row = co][k = tile], B[k = tile][col = ci]; lane (li, lh) supplies row / column li of K index lh
+    const int a_lane = p * WW_T * Cfg::COP + lh * Cfg::COP + li;                 // + (2 ks) * COP + cb * 32
+    const int b_lane = Cfg::M_FLOATS + p * WW_T * 32 + lh * 32 + li;             // + (2 ks) * 32
+
+    // The chunk loop is instantiated once per role (a wave is wholly one or the other): each instance holds only its own raw
+    // registers, loads unconditionally (the last iteration re-fetches its own chunk) and nothing is selected or merged after a
+    // load -- the loads stay in flight under the MFMAs.
+    auto run = [&](auto role) {
+        constexpr bool DZ = decltype(role)::value;
+        constexpr int NLD = DZ ? 4 : 16;
+        float raw[NLD];
+        auto fetch = [&](int chunk) {
+            const int cx = chunk % chunks_x, ty = (chunk / chunks_x) % tiles_y, n = chunk / (chunks_x * tiles_y);
+            const bool edge = ty == 0 || ty == tiles_y - 1 || cx == 0 || cx == chunks_x - 1;        // wave-uniform
+            // scalar byte offset of the chunk origin in the tensor (input: the descriptor's base carries the (-1, -1) shift)
+            const long long so = (long long)n * (DZ ? CGout : CGin) * (long long)HW * 32 +
+                                 ((long long)2 * ty * W + (long long)2 * WW_T * cx) * 32;
+            // the bytes in front of the input tensor are only ever addressed by loads of the first tile row / chunk column of
+            // image 0, which are masked (offset out of range)
+            auto rs = DZ ? __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, dz_bytes, 0x00020000)
+                         : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)act - ((size_t)W + 1) * 32), 0,
+                                                             act_bytes + (unsigned)((W + 1) * 32), 0x00020000);
+            if (edge) {
+                const unsigned m = (ty == 0 ? mT : 0u) | (ty == tiles_y - 1 ? mB : 0u) | (cx == 0 ? mL : 0u) |
+                                   (cx == chunks_x - 1 ? mR : 0u);
+#pragma unroll
+                for (int k = 0; k < NLD; ++k) {
+                    const unsigned vo = ((m >> k) & 1u) ? 0xFFFFFFFFu : voff[k];
+                    raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)so, 0));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NLD; ++k)
+                    raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], (unsigned)so, 0));
+            }
+        };
+        auto transform_store = [&](float* buf) {
+            if (!t_on) return;
+            float o[16];
+            if constexpr (DZ) {     // A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+                float rr[4][2];
+                rr[0][0] = raw[0];          rr[0][1] = raw[1];
+                rr[1][0] = raw[0] + raw[2]; rr[1][1] = raw[1] + raw[3];
+                rr[2][0] = raw[0] - raw[2]; rr[2][1] = raw[1] - raw[3];
+                rr[3][0] = -raw[2];         rr[3][1] = -raw[3];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    o[xi * 4 + 0] = rr[xi][0];
+                    o[xi * 4 + 1] = rr[xi][0] + rr[xi][1];
+                    o[xi * 4 + 2] = rr[xi][0] - rr[xi][1];
+                    o[xi * 4 + 3] = -rr[xi][1];
+                }
+            } else {                // B^T d B, as conv_wino.hip
+                float t[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    t[0][c] = raw[0 * 4 + c] - raw[2 * 4 + c];
+                    t[1][c] = raw[1 * 4 + c] + raw[2 * 4 + c];
+                    t[2][c] = raw[2 * 4 + c] - raw[1 * 4 + c];
+                    t[3][c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r * 4 + 0] = t[r][0] - t[r][2];
+                    o[r * 4 + 1] = t[r][1] + t[r][2];
+                    o[r * 4 + 2] = t[r][2] - t[r][1];
+                    o[r * 4 + 3] = t[r][1] - t[r][3];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) buf[w_off + q * w_step] = o[q];
+        };
+
+        int chunk = blockIdx.x;
+        if (chunk >= chunks) return;                                   // (whole workgroup: blockIdx is uniform)
+        fetch(chunk);
+        transform_store(smem_ww);
+        __syncthreads();
+        int cur = 0;
+        for (; chunk < chunks; chunk += gridDim.x) {
+            const bool more = chunk + (int)gridDim.x < chunks;
+            fetch(more ? chunk + (int)gridDim.x : chunk);               // in flight under this chunk's MFMAs
+            const float* buf = smem_ww + cur * Cfg::BUF_FLOATS;
+#pragma unroll
+            for (int ks = 0; ks < WW_T / 2; ++ks) {
+                const float bv = buf[b_lane + 2 * ks * 32];
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb) {
+                    const float av = buf[a_lane + 2 * ks * Cfg::COP + cb * 32];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[cb], 0, 0, 0);
+                }
+            }
+            transform_store(smem_ww + (cur ^ 1) * Cfg::BUF_FLOATS);   // that buffer was last read before the previous barrier
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    if (is_dz) run(std::true_type{}); else run(std::false_type{});
+    // C[row = co_local][col = ci_local]: row = (r&3) + 8*(r>>2) + 4*lh, col = li
+    const int coP = Cfg::COP, ciP = 32 * gridDim.y;
+    float* slab = slabs + ((size_t)blockIdx.x * 16 + p) * coP * ciP;
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[(size_t)co * ciP + cib * 32 + li] = acc[cb][r];
+        }
+#endif
+}
+
+// sum over slabs in fixed order, one thread per (position, co, ci): the sums replace slab 0 in place (every thread reads
+// and writes only its own element)
+__global__ void __launch_bounds__(256)
+wgrad_wino_sum_kernel(float* __restrict__ slabs, int nslab, int coP, int ciP) {
+    const size_t stride = (size_t)16 * coP * ciP;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= stride) return;
+    float* pp = slabs + idx;
+    // four interleaved partial sums (slab k -> accumulator k % 4), then ((s0+s1)+s2)+s3, as wgrad_reduce_kernel
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nslab; k += 4) {
+        s0 += pp[(size_t)k * stride];
+        s1 += pp[(size_t)(k + 1) * stride];
+        s2 += pp[(size_t)(k + 2) * stride];
+        s3 += pp[(size_t)(k + 3) * stride];
+    }
+    for (; k < nslab; ++k) s0 += pp[(size_t)k * stride];
+    pp[0] = ((s0 + s1) + s2) + s3;
+}
+
+// dW[co][ci][ky][kx] (OIHW, real channel counts) = G^T S G from the summed slab, in double
+__global__ void __launch_bounds__(256)
+wgrad_wino_finish_kernel(const float* __restrict__ sums, float* __restrict__ dW, int Cin_real, int co0,
+                         int co_count /* real output channels of this chunk */, int coP, int ciP) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = co_count * Cin_real;
+    if (idx >= total) return;
+    const int ci = idx % Cin_real, co = idx / Cin_real;                   // ci fastest: coalesced reads
+    const size_t pstride = (size_t)coP * ciP;
+    const float* base = sums + (size_t)co * ciP + ci;
+    double u[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) u[q] = (double)base[q * pstride];
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    float* out = dW + ((size_t)(co0 + co) * Cin_real + ci) * 9;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            double s = 0.0;
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) s += G[xi][ky] * G[nu][kx] * u[xi * 4 + nu];
+            out[ky * 3 + kx] = (float)s;
+        }
+}
+
+static inline int ww_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace scipnp
+
+using namespace scipnp;
+
+extern "C" {
+
+size_t scipnp_conv3x3_wgrad_wino_workspace_floats(int Cin, int Cout, int nslab) {
+    if (Cin <= 0 || Cout <= 0 || nslab <= 0) return 0;
+    const int chunk = ww_round_up(Cout, 32) < 96 ? ww_round_up(Cout, 32) : 96;
+    return (size_t)nslab * 16 * chunk * ww_round_up(Cin, 32);
+}
+
+int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
+                              int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(act_c8 && dz_c8 && dW && workspace, "null pointer");
+    SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin_real <= Cin && Cout_real <= Cout &&
+                   nslab > 0 && nslab <= 65535, "bad shape");
+    SCIPNP_REQUIRE((long long)n * Cin * h * w * 4 < (1ll << 31) && (long long)n * Cout * h * w * 4 < (1ll << 31),
+                   "tensors of 2 GiB or more: use scipnp_conv3x3_wgrad");
+    SCIPNP_ALIGNED(act_c8); SCIPNP_ALIGNED(dz_c8);
+    const int ciP = ww_round_up(Cin, 32);
+    hipStream_t st = (hipStream_t)s;
+    // output channels in chunks of <= 96 (3 MFMA row blocks per wave); one slab set + reduction per chunk
+    for (int co0 = 0; co0 < Cout_real; co0 += 96) {
+        const int left = ww_round_up(Cout, 32) - co0;
+        const int coP = left < 96 ? left : 96;
+        const int COB = coP / 32;
+        const dim3 grid(nslab, ciP / 32);
+#define SCIPNP_WW(C)                                                                                                  \
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (!attr) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel<C>,                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WwCfg<C>::LDS_BYTES); \
+            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(wgrad_wino): %s", hipGetErrorString(e)); \
+            attr = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<C>), grid, dim3(WW_THREADS), WwCfg<C>::LDS_BYTES, st, act_c8,   \
+                           dz_c8, workspace, n, Cin / 8, Cout / 8, co0 / 8, h, w);                                    \
+    } while (0)
+        if (COB == 1) SCIPNP_WW(1); else if (COB == 2) SCIPNP_WW(2); else SCIPNP_WW(3);
+#undef SCIPNP_WW
+        int rc = launch_status("conv3x3_wgrad_wino_kernel");
+        if (rc) return rc;
+        const int co_count = (Cout_real - co0) < coP ? (Cout_real - co0) : coP;
+        const size_t per_slab = (size_t)16 * coP * ciP;
+        hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, st, workspace, nslab,
+                           coP, ciP);
+        const int total = co_count * Cin_real;
+        hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, dW, Cin_real, co0,
+                           co_count, coP, ciP);
+        rc = launch_status("wgrad_wino_sum / finish kernels");
+        if (rc) return rc;
+    }
+    return SCIPNP_OK;
+}
+
+}  // extern "C"

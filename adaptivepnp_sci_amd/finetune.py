@@ -47,6 +47,12 @@ def _split_slabs(cin):
     return max(1, 255 // ncib)
 
 
+def _wino_slabs(cin):
+    """persistent workgroups of the fp32 Winograd weight-gradient kernel (csrc/wgrad_wino.hip) = slabs x (Cin/32 blocks):
+    one 16-wave workgroup per CU"""
+    return max(1, 255 // ((cin + 31) // 32))
+
+
 def _upload_flat(flat_dev, srcs):
     """fill the flat device buffer from the parameter tensors: ONE host->device copy when they live on the host
     (per-tensor pageable copies cost ~0.1-0.3 ms each), per-tensor device copies otherwise"""
@@ -149,6 +155,9 @@ class _FFDNetTrainer:
         self.dw, self.db = gviews[:nl], gviews[nl:]
         self.slabs = [_split_slabs(ci) if self.split else self.NSLAB for ci in self.cin]
         ws = max(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, ns) for ci, co, ns in zip(self.cin, self.cout, self.slabs))
+        if self.wino:        # fp32: weight gradients in the Winograd domain too (16 positions per slab instead of 9 taps)
+            ws = max([ws] + [lib.scipnp_conv3x3_wgrad_wino_workspace_floats(ci, co, _wino_slabs(ci))
+                             for ci, co in zip(self.cin, self.cout)])
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty((nc // 8) * 64 * 8, dtype=F32, device=dev)
         nb_ = C.c_int(0)
@@ -232,8 +241,13 @@ class _FFDNetTrainer:
         for l in range(self.nb - 1, -1, -1):
             a_in = eng.in_c8 if l == 0 else self.acts[l - 1]
             ci_r, co_r = self._real(l)
-            _lib.check(self.lib.scipnp_conv3x3_wgrad(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB, B,
-                                                     ci_r, co_r, self.cin[l], self.cout[l], M, N, _s()), 'wgrad')
+            if self.wino:
+                _lib.check(self.lib.scipnp_conv3x3_wgrad_wino(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws),
+                                                              _wino_slabs(self.cin[l]), B, ci_r, co_r, self.cin[l],
+                                                              self.cout[l], M, N, _s()), 'wgrad wino')
+            else:
+                _lib.check(self.lib.scipnp_conv3x3_wgrad(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws), self.NSLAB, B,
+                                                         ci_r, co_r, self.cin[l], self.cout[l], M, N, _s()), 'wgrad')
             _lib.check(self.lib.scipnp_conv_bias_grad(_ptr(dz), _ptr(self.db[l]), _ptr(self.bws), B, co_r, self.cout[l],
                                                       M, N, _s()), 'bgrad')
             if l > 0:
@@ -418,6 +432,9 @@ class _DenBlockTrainer:
         if self.split:
             _lib.check(lib.scipnp_conv3x3_wgrad_split(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin,
                                                       cout, h, w, inv_scale, _s()), 'wgrad split')
+        elif self.bwd_w is not None:                       # fp32 in Winograd form (csrc/wgrad_wino.hip)
+            _lib.check(lib.scipnp_conv3x3_wgrad_wino(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), _wino_slabs(cin), n, ci_r,
+                                                     co_r, cin, cout, h, w, _s()), 'wgrad wino')
         else:
             _lib.check(lib.scipnp_conv3x3_wgrad(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin, cout,
                                                 h, w, _s()), 'wgrad')
@@ -478,6 +495,9 @@ class _FastDVDTrainer:
         self.ds1 = torch.empty_like(self.s1)
         ws = max(self.lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, _split_slabs(ci) if self.split else self.NSLAB)
                  for _, _, ci, co, *_ in self.blocks['temp1'].spec)
+        if wino:
+            ws = max([ws] + [self.lib.scipnp_conv3x3_wgrad_wino_workspace_floats(ci, co, _wino_slabs(ci))
+                             for _, _, ci, co, *_ in self.blocks['temp1'].spec])
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty(32 * 64 * 8, dtype=F32, device=dev)
         nb_ = C.c_int(0)

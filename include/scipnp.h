@@ -293,6 +293,13 @@ int scipnp_ffdnet_loss_grad(const float* out_c8, const float* Phi, const float* 
 size_t scipnp_conv3x3_wgrad_workspace_floats(int Cin, int Cout, int nslab);
 int scipnp_conv3x3_wgrad(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
                          int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s);
+/* the same gradient in the Winograd F(2x2,3x3) domain (csrc/wgrad_wino.hip): dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G,
+ * 16 exact fp32 products per 2x2 tile and channel pair instead of 36, accumulated in fp32 on v_mfma_f32_32x32x2_f32 with the
+ * tiles as the K dimension; equal to scipnp_conv3x3_wgrad up to fp32 re-association (tests/test_gpu_ops.py).  Own workspace
+ * size (16 Winograd positions per slab instead of 9 taps).  The fp32 trainers use it unless SCIPNP_F32_CONV=direct. */
+size_t scipnp_conv3x3_wgrad_wino_workspace_floats(int Cin, int Cout, int nslab);
+int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
+                              int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s);
 /* db[co] = sum dz; workspace >= (Cout/8)*64*8 floats */
 int scipnp_conv_bias_grad(const float* dz_c8, float* db, float* workspace, int n, int Cout_real, int Cout,
                           int h, int w, scipnp_stream_t s);

@@ -727,6 +727,40 @@ def test_frame_metrics_vs_skimage_restatement(ops):
         frame_metrics(ops.mosaic_to_state(dev(a[:4, :4])), ops.mosaic_to_state(dev(b[:4, :4])))
 
 
+def test_winograd_wgrad_vs_autograd(ops):
+    """the fp32 weight gradient in the Winograd domain (csrc/wgrad_wino.hip: dg = G^T [sum_tiles (A dY A^T) .* (B^T d B)] G)
+    against PyTorch autograd in float64 and against the direct-form kernel: full, head-like, wide and ragged shapes (odd
+    heights / widths, fewer tiles than one chunk, several images, more output channels than one 96-channel chunk)"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(13)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    cases = ((2, 96, 96, 96, 96, 10, 37, 16), (2, 13, 96, 16, 96, 9, 5, 3), (3, 96, 12, 96, 16, 7, 33, 5),
+             (1, 64, 128, 64, 128, 16, 16, 7), (2, 32, 64, 32, 64, 2, 2, 1), (1, 128, 256, 128, 256, 6, 20, 4),
+             (4, 24, 40, 24, 40, 12, 18, 255))
+    for n, ci_r, co_r, ci, co, h, w, nslab in cases:
+        x = torch.relu(torch.randn(n, ci_r, h, w, generator=g))
+        wt = (torch.randn(co_r, ci_r, 3, 3, generator=g) * 0.05).double().requires_grad_()
+        dz = torch.randn(n, co_r, h, w, generator=g)
+        torch.nn.functional.conv2d(x.double(), wt, None, padding=1).backward(dz.double())
+        x8, dz8 = ops.to_c8(x.cuda()), ops.to_c8(dz.cuda())
+        ws = torch.empty(lib.scipnp_conv3x3_wgrad_wino_workspace_floats(ci, co, nslab), device='cuda')
+        dW = torch.full((co_r, ci_r, 3, 3), float('nan'), device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino(p(x8), p(dz8), p(dW), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, s), 'wgrad wino')
+        err = rel_l2(dW.cpu().numpy(), wt.grad.numpy())
+        assert err < 1e-6, (n, ci_r, co_r, h, w, nslab, err)
+        ws2 = torch.empty(lib.scipnp_conv3x3_wgrad_workspace_floats(ci, co, 16), device='cuda')
+        dW2 = torch.empty(co_r, ci_r, 3, 3, device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad(p(x8), p(dz8), p(dW2), p(ws2), 16, n, ci_r, co_r, ci, co, h, w, s), 'wgrad')
+        assert rel_l2(dW.cpu().numpy(), dW2.cpu().numpy()) < 2e-6
+        # deterministic: fixed-order slab reduction, no atomics
+        dW3 = torch.empty_like(dW)
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino(p(x8), p(dz8), p(dW3), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, s), 'wgrad wino')
+        assert torch.equal(dW, dW3)
+
+
 def test_split_wgrad_bgrad_backward_data_vs_autograd(ops):
     """the finetune's split-fp16 kernels: weight / bias gradients from c8s operands (transposing LDS reads, pre-scaled
     dZ) and the backward-data conv with the ReLU-mask epilogue, against PyTorch autograd in float64"""
