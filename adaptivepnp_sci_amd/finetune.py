@@ -53,6 +53,11 @@ def _wino_slabs(cin):
     return max(1, 255 // ((cin + 31) // 32))
 
 
+def _wino_wgrad_fits(n, cin, cout, h, w):
+    """csrc/wgrad_wino.hip addresses both tensors through 32-bit buffer offsets: each must stay below 2 GiB"""
+    return n * max(cin, cout) * h * w * 4 < (1 << 31)
+
+
 def _upload_flat(flat_dev, srcs):
     """fill the flat device buffer from the parameter tensors: ONE host->device copy when they live on the host
     (per-tensor pageable copies cost ~0.1-0.3 ms each), per-tensor device copies otherwise"""
@@ -241,7 +246,7 @@ class _FFDNetTrainer:
         for l in range(self.nb - 1, -1, -1):
             a_in = eng.in_c8 if l == 0 else self.acts[l - 1]
             ci_r, co_r = self._real(l)
-            if self.wino:
+            if self.wino and _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
                 _lib.check(self.lib.scipnp_conv3x3_wgrad_wino(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws),
                                                               _wino_slabs(self.cin[l]), B, ci_r, co_r, self.cin[l],
                                                               self.cout[l], M, N, _s()), 'wgrad wino')
@@ -432,7 +437,7 @@ class _DenBlockTrainer:
         if self.split:
             _lib.check(lib.scipnp_conv3x3_wgrad_split(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), nslab, n, ci_r, co_r, cin,
                                                       cout, h, w, inv_scale, _s()), 'wgrad split')
-        elif self.bwd_w is not None:                       # fp32 in Winograd form (csrc/wgrad_wino.hip)
+        elif self.bwd_w is not None and _wino_wgrad_fits(n, cin, cout, h, w):     # fp32 in Winograd form (csrc/wgrad_wino.hip)
             _lib.check(lib.scipnp_conv3x3_wgrad_wino(_ptr(x_in), _ptr(dy), _ptr(self.G[i]), _ptr(ws), _wino_slabs(cin), n, ci_r,
                                                      co_r, cin, cout, h, w, _s()), 'wgrad wino')
         else:
