@@ -19,32 +19,41 @@
 namespace scipnp {
 
 typedef float ww_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ww_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WW_T = 8;                         // tiles per chunk, along x
-constexpr int WW_THREADS = 16 * 64;
+constexpr int WW_MFMA_WAVES = 8;                // two Winograd positions per wave
 
 template <int COB>
 struct WwCfg {
     static constexpr int COP = 32 * COB;                           // output channels of the workgroup
-    static constexpr int NCH = COP + 32;                           // transform threads per tile: dY channels, then input channels
+    static constexpr int THREADS = 64 * (WW_MFMA_WAVES + COB + 2); // + COB waves transforming dY, + 2 transforming the input
     static constexpr int M_FLOATS = 16 * WW_T * COP;               // dM [p][tile][co]
     static constexpr int V_FLOATS = 16 * WW_T * 32;                // V  [p][tile][ci]
     static constexpr int BUF_FLOATS = M_FLOATS + V_FLOATS;
     static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
-    static_assert(WW_T * NCH <= WW_THREADS && (WW_T * COP) % 64 == 0, "one transform thread per (tile, channel), roles by wave");
 };
 
 // grid = (nslab, Cin/32 blocks).  act: [n][CGin][h][w][8], dz: [n][CGout][h][w][8];
 // slab layout: slabs[slab][p 16][coP][ciP]  (coP = 32*COB, ciP = 32*gridDim.y)
+//
+// Waves are specialised: waves 0..7 only multiply (wave w <-> positions 2w, 2w+1, 96 x 32 accumulators each), waves 8.. only
+// load and transform -- one lane per (tile, four output-gradient / two input channels): 16- / 8-byte loads through a buffer descriptor whose per-lane offsets
+// are constants of the thread (the chunk origin is a scalar offset: no vector arithmetic per chunk, which would be matrix
+// time on this MFMA), the transform on four channels at once, sixteen 16-byte LDS writes [position][tile][channel].  The
+// producers work one chunk ahead of the consumers (two LDS buffers, one barrier per chunk), their loads two chunks ahead.
+// First version (every wave loading, transforming and multiplying in turn, one channel per lane): 943 us at 96 -> 96;
+// roles per wave with a chunk loop per role, so that nothing is merged behind a load: 483 us; this form: see DESIGN.md.
 template <int COB>
-__global__ void __launch_bounds__(WW_THREADS)
+__global__ void __launch_bounds__(WwCfg<COB>::THREADS)
 conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict__ dz, float* __restrict__ slabs, int n_img,
                           int CGin, int CGout, int cg0 /* first output channel group of this launch */, int H, int W) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = WwCfg<COB>;
     extern __shared__ __attribute__((aligned(16))) float smem_ww[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, p = tid >> 6;                      // MFMA phase: wave <-> position
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the role branches below are uniform
     const int li = lane & 31, lh = lane >> 5;
     const int cib = blockIdx.y;
     const size_t HW = (size_t)H * W;
@@ -52,164 +61,182 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
     const int chunks_x = (tiles_x + WW_T - 1) / WW_T;
     const int chunks = n_img * tiles_y * chunks_x;
     const unsigned dz_bytes = (unsigned)((size_t)n_img * CGout * HW * 32), act_bytes = (unsigned)((size_t)n_img * CGin * HW * 32);
-    (void)dz_bytes; (void)act_bytes;
+    const int first = blockIdx.x, step = gridDim.x;
+    const int coP = Cfg::COP, ciP = 32 * gridDim.y;
 
-    // transform role of this thread: tile tl of the chunk and one channel of the output gradient or of the input
-    // whole waves share a role (the first 8*COP threads take the output-gradient channels, the next 256 the input channels):
-    // the role is a scalar, so the two load paths are uniform branches and the loads stay asynchronous past them (with lanes
-    // of both roles in one wave the compiler merged the two paths' registers right after the loads and waited for them there)
-    const int wave_first = __builtin_amdgcn_readfirstlane(tid);
-    const bool is_dz = wave_first < WW_T * Cfg::COP;
-    const int t2 = tid - WW_T * Cfg::COP;
-    const int tl = is_dz ? tid / Cfg::COP : t2 / 32;
-    const int chl = is_dz ? tid - tl * Cfg::COP : t2 - tl * 32;          // channel inside its tensor block
-    const bool t_on = tl < WW_T;
-    const int cgl = chl >> 3, cl = chl & 7;
-    const bool ch_on = t_on && (is_dz ? (cg0 + cgl < CGout) : (cib * 4 + cgl < CGin));
-    // LDS float offset of this thread's value of position 0; position q adds q * WW_T * (COP or 32)
-    const int w_off = is_dz ? (tl * Cfg::COP + chl) : (Cfg::M_FLOATS + tl * 32 + chl);
-    const int w_step = is_dz ? WW_T * Cfg::COP : WW_T * 32;
-
-    // raw loads through buffer descriptors over the whole tensors: the chunk origin is a scalar offset, the per-load byte
-    // offsets below are constants of the thread -- no vector arithmetic per chunk (it would be matrix time on this MFMA).
-    // The input patch origin is shifted by (-1, -1) so that every offset is non-negative; loads that fall off the image on
-    // an edge chunk (bit k of the masks for the chunk being in the first / last tile row / chunk column) get an offset past
-    // the descriptor's range and read 0 without touching memory.
-    constexpr int NL = 16;                                        // loads per thread: 4 (2x2 tile) or 16 (4x4 patch)
-    const int nl = is_dz ? 4 : 16;
-    unsigned voff[NL];
-    unsigned mT = 0, mB = 0, mL = 0, mR = 0;
-    {
-        const size_t chan = (size_t)(is_dz ? (cg0 + cgl) : (cib * 4 + cgl)) * HW * 32 + 4 * cl;
-        const int ty_last = tiles_y - 1, cx_last = chunks_x - 1;
+    if (wave < WW_MFMA_WAVES) {
+        // ---------------------------------------------------------------- consumers
+        ww_f32x16 acc[2][COB];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int dy = is_dz ? (k >> 1) : (k >> 2), dx = (is_dz ? (k & 1) : (k & 3)) + 2 * tl;   // from the (shifted) origin
-            voff[k] = (ch_on && k < nl) ? (unsigned)(chan + ((size_t)dy * W + dx) * 32) : 0xFFFFFFFFu;
-            const int sh = is_dz ? 0 : -1;
-            if (dy + sh < 0) mT |= 1u << k;                                    // ty == 0
-            if (2 * ty_last + dy + sh >= H) mB |= 1u << k;                     // ty == ty_last
-            if (dx + sh < 0) mL |= 1u << k;                                    // cx == 0
-            if (2 * WW_T * cx_last + dx + sh >= W) mR |= 1u << k;              // cx == cx_last
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
+        // MFMA operands: A[row = co][k = tile], B[k = tile][col = ci]; lane (li, lh) supplies row / column li of K index lh
+        const int p0 = 2 * wave;
+        const int a_lane = p0 * WW_T * Cfg::COP + lh * Cfg::COP + li;            // + i*WW_T*COP + (2 ks)*COP + cb*32
+        const int b_lane = Cfg::M_FLOATS + p0 * WW_T * 32 + lh * 32 + li;        // + i*WW_T*32 + (2 ks)*32
+        if (first < chunks) __syncthreads();                                     // chunk `first` is in buffer 0
+        int cur = 0;
+        for (int chunk = first; chunk < chunks; chunk += step) {
+            const float* buf = smem_ww + cur * Cfg::BUF_FLOATS;
+#pragma unroll
+            for (int ks = 0; ks < WW_T / 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float bv = buf[b_lane + i * WW_T * 32 + 2 * ks * 32];
+#pragma unroll
+                    for (int cb = 0; cb < COB; ++cb) {
+                        const float av = buf[a_lane + i * WW_T * Cfg::COP + 2 * ks * Cfg::COP + cb * 32];
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][cb], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                                    // the producers have filled the other buffer meanwhile
+            cur ^= 1;
         }
+        // C[row = co_local][col = ci_local]: row = (r&3) + 8*(r>>2) + 4*lh, col = li
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* slab = slabs + ((size_t)blockIdx.x * 16 + p0 + i) * coP * ciP;
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    slab[(size_t)co * ciP + cib * 32 + li] = acc[i][cb][r];
+                }
+        }
+        return;
     }
-    const size_t img_bytes = (size_t)(is_dz ? CGout : CGin) * HW * 32;
-    (void)img_bytes;
 
-    ww_f32x16 acc[COB];
-#pragma unroll
-    for (int cb = 0; cb < COB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-
-    // MFMA operands: A[row = co][k = tile], B[k = tile][col = ci]; lane (li, lh) supplies row / column li of K index lh
-    const int a_lane = p * WW_T * Cfg::COP + lh * Cfg::COP + li;                 // + (2 ks) * COP + cb * 32
-    const int b_lane = Cfg::M_FLOATS + p * WW_T * 32 + lh * 32 + li;             // + (2 ks) * 32
-
-    // The chunk loop is instantiated once per role (a wave is wholly one or the other): each instance holds only its own raw
-    // registers, loads unconditionally (the last iteration re-fetches its own chunk) and nothing is selected or merged after a
-    // load -- the loads stay in flight under the MFMAs.
-    auto run = [&](auto role) {
+    // -------------------------------------------------------------------- producers
+    // lane <-> (tile tl of the chunk, four channels 4 q4 .. 4 q4 + 3) of the output gradient (waves 8 .. 8+COB-1) or of the
+    // input (last wave)
+    auto produce = [&](auto role) {
         constexpr bool DZ = decltype(role)::value;
-        constexpr int NLD = DZ ? 4 : 16;
-        float raw[NLD];
-        auto fetch = [&](int chunk) {
-            const int cx = chunk % chunks_x, ty = (chunk / chunks_x) % tiles_y, n = chunk / (chunks_x * tiles_y);
+        constexpr int NLD = DZ ? 4 : 16;                           // loads per lane: 2x2 tile or 4x4 patch
+        constexpr int VW = DZ ? 4 : 2;                             // channels per lane: the input's 64 adds per lane-channel are
+                                                                   // spread over two waves (every vector instruction of a
+                                                                   // producer waits for a gap between the consumers' MFMAs)
+        typedef float vec_t __attribute__((ext_vector_type(VW)));
+        constexpr int QPT = (DZ ? 32 * COB : 32) / VW;             // lanes per tile
+        const int t = tid - 64 * (WW_MFMA_WAVES + (DZ ? 0 : COB));
+        const int tl = t / QPT, q = t - tl * QPT;
+        const int cgl = (q * VW) >> 3;
+        const bool ch_on = DZ ? (cg0 + cgl < CGout) : (cib * 4 + cgl < CGin);
+        const int w_off = DZ ? (tl * Cfg::COP + VW * q) : (Cfg::M_FLOATS + tl * 32 + VW * q);
+        constexpr int w_step = DZ ? WW_T * Cfg::COP : WW_T * 32;
+        // per-load byte offsets from the chunk origin (input: from the origin shifted by (-1, -1), carried by the descriptor's
+        // base) and the loads that fall off the image when the chunk is in the first / last tile row / chunk column
+        unsigned voff[NLD];
+        unsigned mT = 0, mB = 0, mL = 0, mR = 0;
+        {
+            const size_t chan = (size_t)(DZ ? (cg0 + cgl) : (cib * 4 + cgl)) * HW * 32 + 4 * ((q * VW) & 7);
+            const int ty_last = tiles_y - 1, cx_last = chunks_x - 1;
+            constexpr int sh = DZ ? 0 : -1;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int dy = DZ ? (k >> 1) : (k >> 2), dx = (DZ ? (k & 1) : (k & 3)) + 2 * tl;
+                voff[k] = ch_on ? (unsigned)(chan + ((size_t)dy * W + dx) * 32) : 0xFFFFFFFFu;
+                if (dy + sh < 0) mT |= 1u << k;                                    // ty == 0
+                if (2 * ty_last + dy + sh >= H) mB |= 1u << k;                     // ty == ty_last
+                if (dx + sh < 0) mL |= 1u << k;                                    // cx == 0
+                if (2 * WW_T * cx_last + dx + sh >= W) mR |= 1u << k;              // cx == cx_last
+            }
+        }
+        // the bytes in front of the input tensor are only ever addressed by loads of the first tile row / chunk column of
+        // image 0, which are masked (offset out of range)
+        const auto rs = DZ ? __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, dz_bytes, 0x00020000)
+                           : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)act - ((size_t)W + 1) * 32), 0,
+                                                               act_bytes + (unsigned)((W + 1) * 32), 0x00020000);
+        vec_t raw[NLD];
+        auto load1 = [&](unsigned vo, unsigned so) {
+            if constexpr (DZ) return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+            else return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0));
+        };
+        // chunk -> (image n, tile row ty, chunk column cx) without a division per chunk: integer division runs on the vector
+        // ALU, where every instruction of a producer waits for a gap between the consumers' MFMAs.  The walker advances by
+        // `step` chunks per call with carries; the decomposition of `step` is computed once.
+        const int per_img = tiles_y * chunks_x;
+        const int d_n = step / per_img, d_ty = (step - d_n * per_img) / chunks_x, d_cx = step - d_n * per_img - d_ty * chunks_x;
+        int w_n = first / per_img, w_ty = (first - w_n * per_img) / chunks_x, w_cx = first - w_n * per_img - w_ty * chunks_x;
+        int w_chunk = first;
+        auto advance = [&]() {
+            w_chunk += step;
+            w_cx += d_cx;
+            if (w_cx >= chunks_x) { w_cx -= chunks_x; ++w_ty; }
+            w_ty += d_ty;
+            if (w_ty >= tiles_y) { w_ty -= tiles_y; ++w_n; }
+            w_n += d_n;
+        };
+        auto fetch = [&]() {                                       // the walker's chunk (clamped: past the end, the last one again)
+            const int cx = w_cx, ty = w_ty, n = w_n;
             const bool edge = ty == 0 || ty == tiles_y - 1 || cx == 0 || cx == chunks_x - 1;        // wave-uniform
-            // scalar byte offset of the chunk origin in the tensor (input: the descriptor's base carries the (-1, -1) shift)
             const long long so = (long long)n * (DZ ? CGout : CGin) * (long long)HW * 32 +
                                  ((long long)2 * ty * W + (long long)2 * WW_T * cx) * 32;
-            // the bytes in front of the input tensor are only ever addressed by loads of the first tile row / chunk column of
-            // image 0, which are masked (offset out of range)
-            auto rs = DZ ? __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, dz_bytes, 0x00020000)
-                         : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)act - ((size_t)W + 1) * 32), 0,
-                                                             act_bytes + (unsigned)((W + 1) * 32), 0x00020000);
             if (edge) {
                 const unsigned m = (ty == 0 ? mT : 0u) | (ty == tiles_y - 1 ? mB : 0u) | (cx == 0 ? mL : 0u) |
                                    (cx == chunks_x - 1 ? mR : 0u);
 #pragma unroll
-                for (int k = 0; k < NLD; ++k) {
-                    const unsigned vo = ((m >> k) & 1u) ? 0xFFFFFFFFu : voff[k];
-                    raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)so, 0));
-                }
+                for (int k = 0; k < NLD; ++k) raw[k] = load1(((m >> k) & 1u) ? 0xFFFFFFFFu : voff[k], (unsigned)so);
             } else {
 #pragma unroll
-                for (int k = 0; k < NLD; ++k)
-                    raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], (unsigned)so, 0));
+                for (int k = 0; k < NLD; ++k) raw[k] = load1(voff[k], (unsigned)so);
             }
         };
         auto transform_store = [&](float* buf) {
-            if (!t_on) return;
-            float o[16];
+            float* dst = buf + w_off;
             if constexpr (DZ) {     // A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
-                float rr[4][2];
+                vec_t rr[4][2];
                 rr[0][0] = raw[0];          rr[0][1] = raw[1];
                 rr[1][0] = raw[0] + raw[2]; rr[1][1] = raw[1] + raw[3];
                 rr[2][0] = raw[0] - raw[2]; rr[2][1] = raw[1] - raw[3];
                 rr[3][0] = -raw[2];         rr[3][1] = -raw[3];
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
-                    o[xi * 4 + 0] = rr[xi][0];
-                    o[xi * 4 + 1] = rr[xi][0] + rr[xi][1];
-                    o[xi * 4 + 2] = rr[xi][0] - rr[xi][1];
-                    o[xi * 4 + 3] = -rr[xi][1];
+                    *(vec_t*)(dst + (xi * 4 + 0) * w_step) = rr[xi][0];
+                    *(vec_t*)(dst + (xi * 4 + 1) * w_step) = rr[xi][0] + rr[xi][1];
+                    *(vec_t*)(dst + (xi * 4 + 2) * w_step) = rr[xi][0] - rr[xi][1];
+                    *(vec_t*)(dst + (xi * 4 + 3) * w_step) = -rr[xi][1];
                 }
             } else {                // B^T d B, as conv_wino.hip
-                float t[4][4];
+                vec_t tt[4][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    t[0][c] = raw[0 * 4 + c] - raw[2 * 4 + c];
-                    t[1][c] = raw[1 * 4 + c] + raw[2 * 4 + c];
-                    t[2][c] = raw[2 * 4 + c] - raw[1 * 4 + c];
-                    t[3][c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+                    tt[0][c] = raw[0 * 4 + c] - raw[2 * 4 + c];
+                    tt[1][c] = raw[1 * 4 + c] + raw[2 * 4 + c];
+                    tt[2][c] = raw[2 * 4 + c] - raw[1 * 4 + c];
+                    tt[3][c] = raw[1 * 4 + c] - raw[3 * 4 + c];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o[r * 4 + 0] = t[r][0] - t[r][2];
-                    o[r * 4 + 1] = t[r][1] + t[r][2];
-                    o[r * 4 + 2] = t[r][2] - t[r][1];
-                    o[r * 4 + 3] = t[r][1] - t[r][3];
+                    *(vec_t*)(dst + (r * 4 + 0) * w_step) = tt[r][0] - tt[r][2];
+                    *(vec_t*)(dst + (r * 4 + 1) * w_step) = tt[r][1] + tt[r][2];
+                    *(vec_t*)(dst + (r * 4 + 2) * w_step) = tt[r][2] - tt[r][1];
+                    *(vec_t*)(dst + (r * 4 + 3) * w_step) = tt[r][1] - tt[r][3];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) buf[w_off + q * w_step] = o[q];
         };
-
-        int chunk = blockIdx.x;
-        if (chunk >= chunks) return;                                   // (whole workgroup: blockIdx is uniform)
-        fetch(chunk);
+        if (first >= chunks) return;
+        fetch();                                                   // chunk `first`
         transform_store(smem_ww);
+        if (w_chunk + step < chunks) advance();                    // (past the end the last chunk is fetched again: no branch
+        fetch();                                                   //  around loads, nothing selected behind them)
         __syncthreads();
         int cur = 0;
-        for (; chunk < chunks; chunk += gridDim.x) {
-            const bool more = chunk + (int)gridDim.x < chunks;
-            fetch(more ? chunk + (int)gridDim.x : chunk);               // in flight under this chunk's MFMAs
-            const float* buf = smem_ww + cur * Cfg::BUF_FLOATS;
-#pragma unroll
-            for (int ks = 0; ks < WW_T / 2; ++ks) {
-                const float bv = buf[b_lane + 2 * ks * 32];
-#pragma unroll
-                for (int cb = 0; cb < COB; ++cb) {
-                    const float av = buf[a_lane + 2 * ks * Cfg::COP + cb * 32];
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[cb], 0, 0, 0);
-                }
-            }
-            transform_store(smem_ww + (cur ^ 1) * Cfg::BUF_FLOATS);   // that buffer was last read before the previous barrier
+        for (int chunk = first; chunk < chunks; chunk += step) {
+            // chunk + step goes to the other buffer (last read by the consumers before the previous barrier) while they
+            // multiply `chunk`; its raw values were requested a whole chunk ago
+            transform_store(smem_ww + (cur ^ 1) * Cfg::BUF_FLOATS);
+            if (w_chunk + step < chunks) advance();
+            fetch();
             __syncthreads();
             cur ^= 1;
         }
     };
-    if (is_dz) run(std::true_type{}); else run(std::false_type{});
-    // C[row = co_local][col = ci_local]: row = (r&3) + 8*(r>>2) + 4*lh, col = li
-    const int coP = Cfg::COP, ciP = 32 * gridDim.y;
-    float* slab = slabs + ((size_t)blockIdx.x * 16 + p) * coP * ciP;
-#pragma unroll
-    for (int cb = 0; cb < COB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[(size_t)co * ciP + cib * 32 + li] = acc[cb][r];
-        }
+    if (wave < WW_MFMA_WAVES + COB) produce(std::true_type{}); else produce(std::false_type{});
 #endif
 }
 
@@ -301,7 +328,7 @@ int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW
             if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(wgrad_wino): %s", hipGetErrorString(e)); \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<C>), grid, dim3(WW_THREADS), WwCfg<C>::LDS_BYTES, st, act_c8,   \
+        hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<C>), grid, dim3(WwCfg<C>::THREADS), WwCfg<C>::LDS_BYTES, st, act_c8, \
                            dz_c8, workspace, n, Cin / 8, Cout / 8, co0 / 8, h, w);                                    \
     } while (0)
         if (COB == 1) SCIPNP_WW(1); else if (COB == 2) SCIPNP_WW(2); else SCIPNP_WW(3);
