@@ -69,6 +69,28 @@ def test_workspace_queries(lib):
     nb = C.c_int(0)
     assert lib.scipnp_sse_partials(C.c_void_p(1), C.c_void_p(1), 5000, None, C.byref(nb), None) == 0
     assert nb.value == 3
+    # Winograd forms: 16 positions per (8-channel group, 32-output block) + bias; 16 positions per slab
+    assert lib.scipnp_conv3x3_wino_packed_floats(96, 96) == 12 * 3 * 4096 + 96
+    assert lib.scipnp_conv3x3_wino_packed_floats(96, 12) == 0 and lib.scipnp_conv3x3_wino_packed_floats(96, 16) == 12 * 4096 + 32
+    assert lib.scipnp_conv3x3_wgrad_wino_workspace_floats(96, 96, 85) == 85 * 16 * 96 * 96
+    assert lib.scipnp_conv3x3_wgrad_wino_workspace_floats(16, 128, 10) == 10 * 16 * 96 * 32
+    assert lib.scipnp_conv3x3_wgrad_wino_workspace_floats(0, 96, 85) == 0
+
+
+def test_f32_conv_form_switch(monkeypatch):
+    """SCIPNP_F32_CONV and the size bounds of the Winograd kernels (32-bit buffer offsets)"""
+    from adaptivepnp_sci_amd import nets
+    monkeypatch.delenv('SCIPNP_F32_CONV', raising=False)
+    assert nets.f32_conv_form() == 'winograd' and nets.f32_conv_form(256, 256) == 'winograd'
+    assert nets.f32_conv_form(8192, 4096) == 'direct' and nets.f32_conv_form(4096, 4096) == 'winograd'
+    monkeypatch.setenv('SCIPNP_F32_CONV', 'direct')
+    assert nets.f32_conv_form(256, 256) == 'direct'
+    monkeypatch.setenv('SCIPNP_F32_CONV', 'fft')
+    with pytest.raises(ValueError):
+        nets.f32_conv_form()
+    from adaptivepnp_sci_amd import finetune
+    assert finetune._wino_wgrad_fits(8, 96, 96, 256, 256) and not finetune._wino_wgrad_fits(32, 96, 96, 512, 512)
+    assert finetune._wino_slabs(96) == 85 and finetune._wino_slabs(16) == 255 and finetune._wino_slabs(128) == 63
 
 
 def test_argument_errors_are_reported(lib):
