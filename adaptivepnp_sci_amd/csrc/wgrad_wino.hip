@@ -27,7 +27,8 @@ constexpr int WW_MFMA_WAVES = 8;                // two Winograd positions per wa
 template <int COB>
 struct WwCfg {
     static constexpr int COP = 32 * COB;                           // output channels of the workgroup
-    static constexpr int THREADS = 64 * (WW_MFMA_WAVES + COB + 2); // + COB waves transforming dY, + 2 transforming the input
+    static constexpr int DZ_WAVES = 2 * COB;                       // producers of dM: one lane per (tile, channel pair)
+    static constexpr int THREADS = 64 * (WW_MFMA_WAVES + DZ_WAVES + 2); // ... + 2 waves producing V
     static constexpr int M_FLOATS = 16 * WW_T * COP;               // dM [p][tile][co]
     static constexpr int V_FLOATS = 16 * WW_T * 32;                // V  [p][tile][ci]
     static constexpr int BUF_FLOATS = M_FLOATS + V_FLOATS;
@@ -38,12 +39,12 @@ struct WwCfg {
 // slab layout: slabs[slab][p 16][coP][ciP]  (coP = 32*COB, ciP = 32*gridDim.y)
 //
 // Waves are specialised: waves 0..7 only multiply (wave w <-> positions 2w, 2w+1, 96 x 32 accumulators each), waves 8.. only
-// load and transform -- one lane per (tile, four output-gradient / two input channels): 16- / 8-byte loads through a buffer descriptor whose per-lane offsets
+// load and transform -- one lane per (tile, channel pair): 8-byte loads through a buffer descriptor whose per-lane offsets
 // are constants of the thread (the chunk origin is a scalar offset: no vector arithmetic per chunk, which would be matrix
-// time on this MFMA), the transform on four channels at once, sixteen 16-byte LDS writes [position][tile][channel].  The
+// time on this MFMA), the transform on both channels at once, sixteen 8-byte LDS writes [position][tile][channel].  The
 // producers work one chunk ahead of the consumers (two LDS buffers, one barrier per chunk), their loads two chunks ahead.
 // First version (every wave loading, transforming and multiplying in turn, one channel per lane): 943 us at 96 -> 96;
-// roles per wave with a chunk loop per role, so that nothing is merged behind a load: 483 us; this form: see DESIGN.md.
+// roles per wave with a chunk loop per role, so that nothing is merged behind a load: 483 us; this form: 440 us.
 template <int COB>
 __global__ void __launch_bounds__(WwCfg<COB>::THREADS)
 conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict__ dz, float* __restrict__ slabs, int n_img,
@@ -117,12 +118,12 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
     auto produce = [&](auto role) {
         constexpr bool DZ = decltype(role)::value;
         constexpr int NLD = DZ ? 4 : 16;                           // loads per lane: 2x2 tile or 4x4 patch
-        constexpr int VW = DZ ? 4 : 2;                             // channels per lane: the input's 64 adds per lane-channel are
-                                                                   // spread over two waves (every vector instruction of a
-                                                                   // producer waits for a gap between the consumers' MFMAs)
+        constexpr int VW = 2;                                      // channels per lane: few vector instructions per producer wave
+                                                                   // (each of them waits for a gap between the consumers' MFMAs),
+                                                                   // many producer waves
         typedef float vec_t __attribute__((ext_vector_type(VW)));
         constexpr int QPT = (DZ ? 32 * COB : 32) / VW;             // lanes per tile
-        const int t = tid - 64 * (WW_MFMA_WAVES + (DZ ? 0 : COB));
+        const int t = tid - 64 * (WW_MFMA_WAVES + (DZ ? 0 : Cfg::DZ_WAVES));
         const int tl = t / QPT, q = t - tl * QPT;
         const int cgl = (q * VW) >> 3;
         const bool ch_on = DZ ? (cg0 + cgl < CGout) : (cib * 4 + cgl < CGin);
@@ -153,8 +154,7 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
                                                                act_bytes + (unsigned)((W + 1) * 32), 0x00020000);
         vec_t raw[NLD];
         auto load1 = [&](unsigned vo, unsigned so) {
-            if constexpr (DZ) return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
-            else return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0));
+            return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0));
         };
         // chunk -> (image n, tile row ty, chunk column cx) without a division per chunk: integer division runs on the vector
         // ALU, where every instruction of a producer waits for a gap between the consumers' MFMAs.  The walker advances by
@@ -236,7 +236,7 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
             cur ^= 1;
         }
     };
-    if (wave < WW_MFMA_WAVES + COB) produce(std::true_type{}); else produce(std::false_type{});
+    if (wave < WW_MFMA_WAVES + Cfg::DZ_WAVES) produce(std::true_type{}); else produce(std::false_type{});
 #endif
 }
 
