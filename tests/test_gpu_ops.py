@@ -857,6 +857,21 @@ def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict
             a = eng.forward().clone()
             b = eng.forward_c_entry().clone()
         assert torch.equal(a, b), prec
+        if prec == 'f16x3':
+            # the C entry forks a side stream for half of the frames and joins it before returning (SCIPNP_STREAMS): legal
+            # under stream capture, as include/scipnp.h promises -- capture the call in a hipGraph and replay it
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                eng.forward_c_entry_split()                       # (side stream and events exist before the capture)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=st):
+                    out = eng.forward_c_entry_split()
+                out.zero_()
+                graph.replay()
+            torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            assert torch.equal(out, a), 'hipGraph replay of the two-stream C entry'
 
 
 def test_pm_project_with_more_than_16_frames(ops):
