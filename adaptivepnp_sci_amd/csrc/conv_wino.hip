@@ -84,7 +84,7 @@ struct WinoArgs {
 // of group g+2 travels global -> registers -> LDS and U_{g+1} global -> LDS (LDS-DMA) under the same MFMAs.
 // NH = 16-channel halves of the 32-channel output block that hold real channels (1 for layers with <= 16 outputs, e.g.
 // the 12-channel FFDNet tail: the padding half is never multiplied).
-template <int TAG, int NW, int NH = 2, bool STAMP = false>
+template <int TAG, int NW, int NH = 2, bool STAMP = false, bool SHUF = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv3x3_c8w_kernel(const WinoArgs a) {
     using K = WinoCfg<NW>;
@@ -300,6 +300,69 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     const float* bias = a.wpk + (size_t)a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
     (void)relu; (void)add_res; (void)mask;                     // (read by the device-only block below)
+    if constexpr (SHUF) {
+        // PixelShuffle(2) folded into the store (flags bit3, as scipnp_conv3x3_c8_ex): conv channel 4c + 2dy + dx -> channel
+        // c of pixel (2y + dy, 2x + dx); the 32 conv channels of this workgroup are the 8 channels of output group `split`, and a
+        // lane's four values are the 2x2 sub-pixels of ONE output channel c = 4h + q.  The shuffled 16 x 64-pixel tile is
+        // assembled in LDS (the staging buffers are free after the loop's last barrier) and leaves in whole 128-byte lines:
+        // one thread = four consecutive pixels x 8 channels, residual (same layout) added there.  out = relu?(conv + bias + res).
+        static_assert(NW == 4 && NH == 2, "shuffle epilogue: 8 x 32-pixel tiles, 32 conv channels");
+        constexpr int ROW = 64 * 8 + 16 * 4;                   // floats per shuffled row: 4 floats of padding per 4 pixels
+        float* const tile = smem_w;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const f32x4 bs = *(const f32x4*)(bias + (split * 4 + h * 2 + (q >> 1)) * 8 + 4 * (q & 1));
+            f32x4 tm[4][2];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                tm[xi][0] = (acc[xi * 4 + 0][h] + acc[xi * 4 + 1][h]) + acc[xi * 4 + 2][h];
+                tm[xi][1] = (acc[xi * 4 + 1][h] - acc[xi * 4 + 2][h]) - acc[xi * 4 + 3][h];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = ((i == 0) ? (tm[0][j] + tm[1][j]) + tm[2][j] : (tm[1][j] - tm[2][j]) - tm[3][j]) + bs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int yl = 2 * (2 * wv + i) + (e >> 1), xl = 2 * (2 * tn + j) + (e & 1);
+                        tile[yl * ROW + xl * 8 + (xl >> 2) * 4 + 4 * h + q] = v[e];
+                    }
+                }
+        }
+        __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int H2 = 2 * H, W2 = 2 * W;
+        const int yl = tid >> 4, xg = tid & 15;                // 256 threads: 16 rows x 16 groups of 4 pixels
+        const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg;
+        const size_t plane = ((size_t)n * a.NCB + split) * (size_t)H2 * W2 * 8;           // floats; NCB = Cout/32 output groups
+        const unsigned pbytes = (unsigned)((size_t)H2 * W2 * 32);
+        auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, pbytes, 0x00020000);
+        const float* src = tile + yl * ROW + xg * 36;
+        f32x4 px[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) px[k] = *(const f32x4*)(src + 4 * k);
+        unsigned off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) off[k] = (y2 < H2 && x2 + k < W2) ? (unsigned)(((size_t)y2 * W2 + x2 + k) * 32) : 0x80000000u;
+        if (add_res) {
+            auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + plane), 0, pbytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                px[k] = px[k] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[k >> 1] + 16 * (k & 1), 0, 0));
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) px[k][e] = fmaxf(px[k][e], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[k]), r_out, off[k >> 1] + 16 * (k & 1), 0, 0);
+#endif
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)
@@ -434,7 +497,10 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(packed_wino); SCIPNP_ALIGNED(out);
     if (residual) SCIPNP_ALIGNED(residual);
     if (mask_src) SCIPNP_ALIGNED(mask_src);
-    SCIPNP_REQUIRE(!(flags & (4 | 8)), "the Winograd kernel is stride 1 without pixel shuffle");
+    SCIPNP_REQUIRE(!(flags & 4), "the Winograd kernel is stride 1");
+    SCIPNP_REQUIRE(!(flags & 8) || (Cout % 32 == 0 && !(flags & (16 | 0x200))),
+                   "PixelShuffle store: Cout must be a multiple of 32, no ReLU-mask epilogue, 8-row workgroups");
+    SCIPNP_REQUIRE(!(flags & 8) || (long long)h * w * 4 * 32 < (1ll << 30), "shuffled plane too large for 32-bit buffer offsets");
     SCIPNP_REQUIRE(!(flags & 16) || mask_src, "flag bit4 needs mask_src");
     SCIPNP_REQUIRE(!(flags & 2) || residual, "flag bit1 needs residual");
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
@@ -460,6 +526,17 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
         attr_set[vi] = true;
     }
     const dim3 grid((unsigned)total), block(big ? 512 : 256);
+    if (flags & 8) {                                            // PixelShuffle(2) store (UpBlocks of FastDVDnet / DDnet)
+        static bool shuf_set = false;
+        if (!shuf_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<0, 4, 2, false, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w shuffle): %s", hipGetErrorString(e));
+            shuf_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4, 2, false, true>), grid, block, lds, (hipStream_t)s, a);
+        return launch_status("conv3x3_c8w_kernel<shuffle>");
+    }
     if (!big && Cout <= 16) {                                   // one real 16-channel half: TAG 1 (first / last layers) only
         static bool half_set = false;
         if (!half_set) {

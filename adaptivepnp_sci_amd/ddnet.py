@@ -129,14 +129,14 @@ def pack_block(sd, prefix, ch_each_frame, device, split):
 
 
 def wino_packs(packed, ch_each_frame):
-    """Winograd-domain weights (csrc/conv_wino.hip) of a block's stride-1 layers without PixelShuffle store (and of the two
-    fusion convolutions, if present), None for the others; derived on the device from the fp32 direct packing"""
+    """Winograd-domain weights (csrc/conv_wino.hip) of a block's stride-1 layers (PixelShuffle layers included) and of the two
+    fusion convolutions, if present, None for the stride-2 ones; derived on the device from the fp32 direct packing"""
     out = []
     for i, pk in enumerate(packed):
         if i < len(_LAYERS):
             _k, cin, cout, _r, s2, shuf = _LAYERS[i]
             cin = _p8(3 * ch_each_frame) if cin is None else cin
-            out.append(None if (s2 or shuf) else ops.pack_conv3x3_wino(pk, cin, cout))
+            out.append(None if (s2 or (shuf and cout % 32)) else ops.pack_conv3x3_wino(pk, cin, cout))
         else:
             out.append(ops.pack_conv3x3_wino(pk, 8, 8))
     return out

@@ -149,10 +149,11 @@ def alloc_denblock_buffers(B, H, W, device, alias=True):
 
 
 def wino_packs(packed):
-    """Winograd-domain weights (csrc/conv_wino.hip) of the stride-1 layers without PixelShuffle store of one DenBlock,
-    None for the others; derived on the device from the fp32 direct packing"""
-    return [None if (s2 or shuf) else ops.pack_conv3x3_wino(packed[i], cin, cout)
-            for i, (_k, _bn, cin, cout, _relu, s2, shuf) in enumerate(_LAYERS)]
+    """Winograd-domain weights (csrc/conv_wino.hip) of the stride-1 layers of one DenBlock (the PixelShuffle layers
+    included: the shuffle is an epilogue of that kernel too), None for the stride-2 ones; derived on the device from the
+    fp32 direct packing"""
+    return [None if s2 else ops.pack_conv3x3_wino(packed[i], cin, cout)
+            for i, (_k, _bn, cin, cout, _relu, s2, _shuf) in enumerate(_LAYERS)]
 
 
 def denblock_forward(pk, frames, sigma, out, b, pkw=None):

@@ -382,13 +382,13 @@ class _DenBlockTrainer:
                           for _, _, ci, co, *_ in _LAYERS]
             self.bwd_s = [torch.empty(lib.scipnp_conv3x3_split_packed_bytes(co, ci), dtype=torch.uint8, device=device)
                           for _, _, ci, co, *_ in _LAYERS]
-        # fp32 in Winograd form (csrc/conv_wino.hip): the stash forward of the stride-1 layers without PixelShuffle store and
+        # fp32 in Winograd form (csrc/conv_wino.hip): the stash forward of the stride-1 layers (PixelShuffle ones included) and
         # EVERY backward-data convolution (stride-2 layers convolve a zero-upsampled gradient, PixelShuffle layers an
         # un-shuffled one: all stride-1 3x3 convolutions with the transposed weights); weight gradients stay direct
         self.fwd_w = self.bwd_w = None
         if wino and not split:
             wf = lambda a, c: torch.empty(lib.scipnp_conv3x3_wino_packed_floats(a, c), dtype=F32, device=device)  # noqa: E731
-            self.fwd_w = [None if (s2 or sh) else wf(ci, co) for _, _, ci, co, _r, s2, sh in _LAYERS]
+            self.fwd_w = [None if s2 else wf(ci, co) for _, _, ci, co, _r, s2, _sh in _LAYERS]
             self.bwd_w = [wf(co, ci) for _, _, ci, co, *_ in _LAYERS]
         self.dense0 = torch.zeros(90, 12, 3, 3, dtype=F32, device=device)      # block-diagonal form of the grouped conv
         self.G = [torch.empty_like(self.dense0 if i == 0 else w) for i, w in enumerate(self.W)]

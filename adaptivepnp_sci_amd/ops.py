@@ -305,14 +305,17 @@ def pack_conv3x3_wino(packed_f32, Cin, Cout, out=None):
     return out
 
 
-def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, out=None, head=False, rows16=False):
+def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, out=None, head=False, rows16=False,
+                shuffle=False):
     """stride-1 3x3 conv on c8 activations in fp32 Winograd F(2x2,3x3) arithmetic (csrc/conv_wino.hip).
-    rows16: 16-row workgroups of 8 waves instead of the default 8-row workgroups of 4 waves (same results)."""
+    rows16: 16-row workgroups of 8 waves instead of the default 8-row workgroups of 4 waves (same results).
+    shuffle: PixelShuffle(2) folded into the store, out [n][Cout/32][2h][2w][8] (residual, if any, in that layout)."""
     n, cg, h, w, _ = x.shape
     if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+        out = (torch.empty(n, Cout // 32, 2 * h, 2 * w, 8, device=x.device, dtype=F32) if shuffle else
+               torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32))
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
-             (0x100 if head else 0) | (0x200 if rows16 else 0))
+             (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
     _call('scipnp_conv3x3_c8w', _p(x, 'x'), _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'),
           _p(mask_src, 'mask_src'), n, cg * 8, Cout, h, w, flags, _stream())
     return out

@@ -324,7 +324,9 @@ int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const f
  * packed_wino: scipnp_conv3x3_wino_packed_floats(Cin, Cout) floats, derived ON THE DEVICE from a buffer packed by
  * scipnp_pack_conv3x3_weights / _device(_scaled) (so bias, BatchNorm folding and the transposed backward-data packing
  * carry over); layout [Cin/8][CoutP/32][16 positions][co/16][ci/4][co%16][ci%4], then bias[CoutP].
- * flags: bit0 ReLU, bit1 add `residual`, bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag (as conv3x3_c8_ex).
+ * flags: bit0 ReLU, bit1 add `residual`, bit3 PixelShuffle(2) folded into the store (out and residual [n][Cout/32][2h][2w][8],
+ *        Cout a multiple of 32, as scipnp_conv3x3_c8_ex; the shuffled tile is assembled in LDS and stored in whole 128-byte lines),
+ *        bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag (as conv3x3_c8_ex).
  * h * w < 2^25 (planes are addressed through 32-bit buffer offsets; SCIPNP_EINVAL beyond -- the engines then use scipnp_conv3x3_c8).
  * -- replaces the same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8 (models/basicblock.py:61-98,
  *    models/network_ffdnet.py:46-48, packages/fastdvdnet/models.py:16-89); the reference's fp32 cuDNN path makes the

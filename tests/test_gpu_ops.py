@@ -956,6 +956,32 @@ def test_conv3x3_winograd_identity_asymmetric(ops):
     assert torch.equal(got, x[:, perm])
 
 
+def test_conv3x3_winograd_pixel_shuffle_store(ops):
+    """PixelShuffle(2) folded into the Winograd kernel's store (flags bit3: the UpBlocks of FastDVDnet / DDnet in fp32),
+    with and without the skip tensor and ReLU, against float64 conv + pixel_shuffle and against the direct kernel's shuffle
+    epilogue; ragged heights / widths, several images, 96 / 128 / 160 / 256 conv channels"""
+    g = torch.Generator().manual_seed(21)
+    for n, cin, cout, h, w in ((2, 64, 128, 16, 32), (1, 128, 256, 9, 21), (3, 40, 160, 5, 7), (2, 24, 96, 13, 70)):
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(cout, generator=g) * 0.1
+        res = torch.randn(n, cout // 4, 2 * h, 2 * w, generator=g)
+        cin_p = (cin + 7) // 8 * 8
+        pk = ops.pack_conv3x3(wt, b, Cin=cin_p, Cout=cout, device='cuda')
+        pw = ops.pack_conv3x3_wino(pk, cin_p, cout)
+        xc, rc = ops.to_c8(x.cuda()), ops.to_c8(res.cuda())
+        ref = torch.nn.functional.pixel_shuffle(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=1), 2)
+        for residual, relu in ((None, False), (rc, False), (rc, True)):
+            want = ref + (res.double() if residual is not None else 0)
+            want = torch.relu(want) if relu else want
+            got = ops.conv3x3_c8w(xc, pw, cout, relu=relu, residual=residual, shuffle=True)
+            assert got.shape == (n, cout // 32, 2 * h, 2 * w, 8)
+            err = rel_l2(ops.from_c8(got)[:, :cout // 4].cpu().numpy(), want.numpy())
+            assert err < 2e-6, (n, cin, cout, h, w, relu, err)
+            direct = ops.conv3x3_c8(xc, pk, cout, relu=relu, residual=residual, shuffle=True)
+            assert rel_l2(got.cpu().numpy(), direct.cpu().numpy()) < 2e-6
+
+
 def test_conv3x3_winograd_random_shapes(ops):
     """seeded sweep of small / ragged / thin shapes through the fp32 Winograd kernel (both workgroup forms) against the
     direct fp32-MFMA kernel and fp64: tiles cut by every border, single channel groups, co-blocks with padding"""
