@@ -33,6 +33,23 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args), name)
 
 
+# Measurement hook (bench.py's per-layer-class tables): while a list is installed, every convolution wrapper below
+# brackets its launch with a HIP event pair on the current stream and appends
+# (kernel family, n, Cin, Cout, h, w, flags, start, end).  None in production: no events, no overhead.
+LAUNCH_LOG = None
+
+
+def _timed_call(family, shape, name, *args):
+    log = LAUNCH_LOG
+    if log is None:
+        return _call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _call(name, *args)
+    e1.record()
+    log.append((family,) + tuple(shape) + (e0, e1))
+
+
 # ------------------------------------------------------------------ reference-layout operators
 def A_(x, Phi):
     """y = sum_t x*Phi on planes (M,N,B,4) -> (M,N,4); reference utilspy.py:28-33."""
@@ -291,8 +308,8 @@ def conv3x3_c8(x, packed, Cout, relu=False, residual=None, out=None, head=False,
             out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) |
              (0x100 if head else 0))
-    _call('scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'), _p(out, 'out'), _p(residual, 'residual'),
-          n, cg * 8, Cout, h, w, flags, _stream())
+    _timed_call('conv3x3_c8_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8', _p(x, 'x'), _p(packed, 'packed'),
+                _p(out, 'out'), _p(residual, 'residual'), n, cg * 8, Cout, h, w, flags, _stream())
     return out
 
 
@@ -316,8 +333,9 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
                torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32))
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
              (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
-    _call('scipnp_conv3x3_c8w', _p(x, 'x'), _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'),
-          _p(mask_src, 'mask_src'), n, cg * 8, Cout, h, w, flags, _stream())
+    _timed_call('conv3x3_c8w_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w', _p(x, 'x'),
+                _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
+                Cout, h, w, flags, _stream())
     return out
 
 
@@ -357,9 +375,10 @@ def conv3x3_c8s(x, packed, Cout, relu=False, out=None, f32_out=False, head=False
     flags = ((1 if relu else 0) | (4 if stride2 else 0) | (8 if shuffle else 0) | (32 if f32_out else 0) |
              (64 if shuffle_c8s else 0) |
              (0x100 if head else 0) | (16 if mask is not None else 0) | (2 if residual is not None else 0) | variant)
-    _call('scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16), _p(packed, 'packed', torch.uint8),
-          _p(out, 'out', F32 if fp32 else torch.float16), _p(residual, 'residual', torch.float16),
-          _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags, _stream())
+    _timed_call('conv3x3_c8s_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8s_ex', _p(x, 'x', torch.float16),
+                _p(packed, 'packed', torch.uint8), _p(out, 'out', F32 if fp32 else torch.float16),
+                _p(residual, 'residual', torch.float16), _p(mask, 'mask', torch.float16), n, cg * 8, Cout, h, w, flags,
+                _stream())
     return out
 
 

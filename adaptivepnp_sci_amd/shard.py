@@ -132,3 +132,57 @@ def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=Non
     units = tile_cube(y, Phi, tile, x0, orig)
     got = reconstruct_sharded(units, solve, (tile, tile, B), device, model=model, dst=dst, group=group, streams=streams)
     return None if got is None else stitch_tiles(got, H, W, tile)
+
+
+# ---------------------------------------------------------------------------------------------- fixed-total timed jobs
+def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=0, group=None, sync=None):
+    """A job of a FIXED total of `n_units` independent units (BASELINE configs[3]: 8 cubes; configs[4]: the 16 tiles of a
+    1024 x 1024 x 16 cube) over the ranks of `group`, timed the way bench.py's contract asks:
+
+        state_u = prepare(u)                for this rank's units (unit u on rank u % world)       -- untimed
+        barrier; t0
+        iterate(state_u, k), k < steps      for every unit of the rank, unit after unit              -- "solve"
+        finish(state_u) -> unit_shape       ONE gather of all units to rank `dst`                    -- "gather"
+        barrier; t1
+
+    `sync()` (torch.cuda.synchronize on a GPU rank, None on CPU) is called where a time is taken.  Returns
+    (units, timing): the list of all n_units tensors in unit order on rank dst (None elsewhere) and, on every rank,
+    timing = {'total_s': max over ranks of t1 - t0, 'solve_s': [per rank], 'gather_s': [per rank], 'units': [per rank]}
+    -- the per-rank figures travel in one small all_gather AFTER the timed region (metrics, not the data path)."""
+    import time
+    inited = dist.is_initialized()
+    world = dist.get_world_size(group) if inited else 1
+    rank = dist.get_rank(group) if inited else 0
+    sync = sync or (lambda: None)
+    mine = partition(n_units, world, rank)
+    states = {u: prepare(u) for u in mine}
+
+    def barrier():
+        sync()
+        if inited:
+            dist.barrier(group)
+        sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for u in mine:
+        for k in range(steps):
+            iterate(states[u], k)
+    local = {u: finish(states[u]) for u in mine}
+    sync()
+    t_solve = time.perf_counter() - t0
+    got = gather_units(local, n_units, unit_shape, device, dst=dst, group=group)
+    sync()
+    t_gather = time.perf_counter() - t0 - t_solve
+    barrier()
+    total = time.perf_counter() - t0
+    mine_t = torch.tensor([total, t_solve, t_gather, float(len(mine))], dtype=torch.float64, device=device)
+    if inited:
+        allt = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t, group=group)
+        allt = torch.stack(allt).cpu()
+    else:
+        allt = mine_t.cpu().unsqueeze(0)
+    timing = {'total_s': float(allt[:, 0].max()), 'solve_s': [float(v) for v in allt[:, 1]],
+              'gather_s': [float(v) for v in allt[:, 2]], 'units': [int(v) for v in allt[:, 3]]}
+    return got, timing

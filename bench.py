@@ -18,20 +18,23 @@ mosaics are gathered to rank 0 with ONE RCCL gather at the end of the timed regi
 The SAME invocation times both convolution precisions on the same cube:
   headline (`value`, `dtype: "f32"`) : the FFDNet convolutions in fp32 arithmetic on the fp32 MFMA
                  (the reference's precision) as Winograd F(2x2,3x3): every product an exact fp32 product, 2.25x fewer
-                 of them than the direct form, so the ALGORITHMIC rate `roofline.achieved` can exceed the MFMA peak;
+                 of them than the direct form; `roofline.achieved` / `frac` count the products of the algorithm RUN (the
+                 matrix pipes' duty, <= 1), the direct-form-equivalent rate rides beside it;
   `f32_direct_form` : the same pass with direct-form convolutions (executed = algorithmic FLOPs);
   `fast_path`  : the library default, error-compensated split-fp16 operands on the fp16 MFMA (22 significant
                  bits per operand, fp32 accumulation; meets the 1e-5 / 1e-4 dB gates but is narrower than fp32,
                  so it is reported beside the headline, not as it).
 The JSON line also carries
-  roofline     : the dominant kernel (FFDNet body layer conv3x3), ALGORITHMIC FLOP/s measured with
-                 HIP events around the body-layer launches inside the timed region; `traffic` from rocprofv3
+  roofline     : the dominant kernel (FFDNet body layer conv3x3), FLOP/s measured with HIP events around the
+                 body-layer launches inside the timed region, `peak_measured` by the library's MFMA / HBM
+                 micro-benchmarks in the same invocation; `traffic` from rocprofv3
                  --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes) run as child processes of this
                  invocation when rocprofv3 is available, else from the committed profile it names;
   phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch;
   configs      : the other single-GPU BASELINE configurations (ADMM-TV 256x256x8, FastDVDnet 512x512x8,
-                 a 256x256x16 tile with the online finetune): ms/iteration, dominant kernel, algorithmic
-                 fraction and parity against the CPU oracle for <= 3 iterations;
+                 a 256x256x16 tile with the online finetune): ms/iteration, a per-layer-class table of the
+                 convolution launches (kernel, launches, us, executed FLOPs, frac) and parity against the CPU
+                 oracle for <= 3 iterations;
   cpu_baseline : the CPU oracle (bit-exact restatement of the reference) timed on this host on a
                  bounded sample of the same workload (rank 0, N=1 only); when the budget allows it runs the
                  very iterations the GPU ran and the line carries their parity (`cpu_baseline.parity`).
@@ -268,6 +271,112 @@ def _pick(traffic, needle):
     return None
 
 
+# ------------------------------------------------------------------------------------------------ measured ceilings
+def measure_peaks(dev):
+    """The ceilings of THIS device, measured in THIS invocation (after the timed passes, clocks warm) with the library's
+    own micro-benchmarks (csrc/peaks.hip): a register-resident MFMA loop on pseudo-random operands at two waves per SIMD
+    (no memory traffic at all) and an HBM read stream over 4 GiB.  Median of 3 event-timed launches each."""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
+    p = lambda t: C.c_void_p(t.data_ptr())                                # noqa: E731
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return sorted(ts)[len(ts) // 2]
+
+    res = {'source': 'measured in this bench invocation (scipnp_bench_mfma / scipnp_bench_stream, csrc/peaks.hip)'}
+    blocks = 512                                                          # 2 waves per SIMD on 256 CUs
+    out = torch.empty(blocks * 256, device=dev)
+    for mode, name, per, iters in ((0, 'f16_32x32x16', 4 * 32768, 30000), (2, 'f32_32x32x2', 4 * 4096, 15000)):
+        t = timed(lambda: _lib.check(lib.scipnp_bench_mfma(p(out), blocks, iters, mode, st()), 'scipnp_bench_mfma'))
+        res[f'mfma_{name}_2wave_per_simd_TFLOPs'] = blocks * 4 * iters * per / t / 1e12
+    n = 1 << 30
+    a = torch.rand(n, device=dev)
+    sblocks = 256 * 16
+    sink = torch.empty(sblocks * 256, device=dev)
+    t = timed(lambda: _lib.check(lib.scipnp_bench_stream(p(a), None, n, 0, sblocks, p(sink), st()), 'scipnp_bench_stream'))
+    res['hbm_read_GBs'] = 4 * n / t / 1e9
+    del a, sink, out
+    res['device'] = torch.cuda.get_device_name(dev)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ per-layer-class tables
+def executed_flop(family, n, cin, cout, h, w, flags):
+    """(executed matrix FLOPs, output pixels per image) of one convolution launch, from the kernels' own tilings:
+      conv3x3_c8_kernel  (direct fp32, v_mfma_f32_32x32x2_f32): 2*9*Cin*CoutP FLOP per output pixel, CoutP = Cout rounded to 32;
+      conv3x3_c8w_kernel (fp32 Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32): 2*16*Cin*CoutP per 2x2 output tile (CoutP = 16
+                         for layers of <= 16 output channels, which multiply one half of the 32-channel block);
+      conv3x3_c8s_kernel (split-fp16, v_mfma_f32_32x32x16_f16): 14 MFMAs of 32768 FLOP per (8 in-ch x 9 taps x 32 out-ch x
+                         32 pixels) = 56 FLOP per (in-ch, out-ch, output pixel)."""
+    stride2 = bool(flags & 4)
+    ho, wo = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if stride2 else (h, w)
+    coutp = (cout + 31) // 32 * 32
+    if family == 'conv3x3_c8w_kernel':
+        if cout <= 16:
+            coutp = 16
+        return 2.0 * 16 * cin * coutp * ((ho + 1) // 2) * ((wo + 1) // 2) * n, ho * wo
+    if family == 'conv3x3_c8s_kernel':
+        return 56.0 * cin * coutp * ho * wo * n, ho * wo
+    return 2.0 * 9 * cin * coutp * ho * wo * n, ho * wo
+
+
+def layer_table(log, real_macs=None):
+    """Aggregate an ops.LAUNCH_LOG (single-stream pass) by (kernel family, Cin, Cout, h, w, stride / shuffle): launches,
+    average launch time, algorithmic and executed FLOPs per launch, and `frac` = min(algorithmic, executed) FLOP/s over the
+    dense MFMA peak of the instruction the kernel issues -- never above the matrix pipes' own duty.  real_macs: {(Cin, Cout):
+    multiply-adds per output pixel} for layers whose padded launch shape hides the real one (grouped / 3-channel layers)."""
+    real_macs = real_macs or {}
+    rows = {}
+    for family, n, cin, cout, h, w, flags, e0, e1 in log:
+        key = (family, cin, cout, h, w, flags & (4 | 8))
+        r = rows.setdefault(key, {'us': [], 'n': n, 'flags': flags})
+        r['us'].append(e0.elapsed_time(e1) * 1e3)
+    out = []
+    for (family, cin, cout, h, w, sf), r in rows.items():
+        ex, px = executed_flop(family, r['n'], cin, cout, h, w, sf)
+        alg = 2.0 * real_macs.get((cin, cout), 9 * cin * cout) * px * r['n']
+        us = float(np.mean(r['us']))
+        peak = PEAK_F16_MFMA if family == 'conv3x3_c8s_kernel' else PEAK_FP32_MFMA
+        out.append({'kernel': family, 'frames': r['n'], 'cin': cin, 'cout': cout, 'h': h, 'w': w,
+                    'form': ('stride2' if sf & 4 else 'pixelshuffle' if sf & 8 else 'stride1'),
+                    'launches': len(r['us']), 'avg_us': us, 'total_us': float(np.sum(r['us'])),
+                    'algorithmic_flop_per_launch': alg, 'executed_flop_per_launch': ex,
+                    'algorithmic_TFLOPs': alg / us / 1e6, 'executed_TFLOPs': ex / us / 1e6, 'peak_TFLOPs': peak / 1e12,
+                    'matrix_pipe_duty': ex / us / 1e6 / (peak / 1e12),
+                    'frac': min(alg, ex) / us / 1e6 / (peak / 1e12)})
+    out.sort(key=lambda r_: -r_['total_us'])
+    return out
+
+
+@contextlib.contextmanager
+def single_stream_launch_log():
+    """ops.LAUNCH_LOG installed and SCIPNP_STREAMS=1: event pairs around overlapping launches would time each other"""
+    from adaptivepnp_sci_amd import ops
+    old = os.environ.get('SCIPNP_STREAMS')
+    os.environ['SCIPNP_STREAMS'] = '1'
+    ops.LAUNCH_LOG = log = []
+    try:
+        yield log
+    finally:
+        ops.LAUNCH_LOG = None
+        if old is None:
+            os.environ.pop('SCIPNP_STREAMS', None)
+        else:
+            os.environ['SCIPNP_STREAMS'] = old
+
+
 # ------------------------------------------------------------------------------------------------ the timed runs
 def time_precision(prec, args, ctx):
     """W warm-up steps, K timed steps of AdmmRun.step with the FFDNet convolutions in `prec`, bracketed by
@@ -347,7 +456,13 @@ def time_precision(prec, args, ctx):
 
 
 def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_form='winograd'):
-    achieved = BODY_FLOP_PER_LAUNCH / body_launch_s
+    """Roofline of the dominant kernel.  `achieved` / `frac` count the multiply-adds of the algorithm the kernel RUNS, per
+    launch, over the event-timed launch duration -- for the Winograd kernel the 16 products per 2x2 tile and channel pair of
+    F(2x2,3x3) (= 1/2.25 of the direct form's), so `frac` is the matrix pipes' own duty and can never exceed 1; the
+    direct-form-equivalent rate is kept under `direct_form_equivalent_TFLOPs`.  For the split-fp16 kernel, which EXECUTES
+    3.11x the fp32 convolution's products as fp16 products, `frac` counts the fp32 convolution's FLOPs (the smaller figure)
+    and the pipes' duty rides in `matrix_pipe_frac_of_peak`."""
+    direct_rate = BODY_FLOP_PER_LAUNCH / body_launch_s
     if prec == 'f16x3':
         peak, exec_ratio = PEAK_F16_MFMA, SPLIT_EXEC_PER_ALGO
         kname = ('conv3x3_c8s_kernel<COB=3,TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256; error-compensated '
@@ -375,18 +490,20 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
             key = 'f32_direct' if (prec == 'f32' and f32_form == 'direct') else prec
             tr = json.load(open(tpath)).get(key, {}).get('hbm_bytes_per_launch')
             src = f'committed profile profiles/pmc_traffic.json (live PMC pass unavailable: {traffic_src})'
+    flop = BODY_FLOP_PER_LAUNCH * min(1.0, exec_ratio)       # the algorithm run: never more than the pipes execute
+    achieved = flop / body_launch_s
     return {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / peak,
             'traffic': tr, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
             'algorithmic_bytes_per_launch': BODY_BYTES_PER_LAUNCH, 'kernel': kname,
-            'flop_per_launch': BODY_FLOP_PER_LAUNCH, 'avg_launch_ms': body_launch_s * 1e3,
-            'denoiser_flop_per_iter': FFDNET_FLOP_PER_ITER,
-            # `achieved` counts ALGORITHMIC fp32-conv FLOPs; the split kernel's matrix pipes execute 3.11x that in fp16 products
-            'mfma_flop_executed_over_algorithmic': exec_ratio,
-            'matrix_pipe_frac_of_peak': achieved * exec_ratio / peak,
-            'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
-            # the ceiling MEASURED with a register-resident MFMA loop on random operands (no memory traffic)
-            'peak_measured': peak_meas,
-            'matrix_pipe_frac_of_measured_peak': (achieved / 1e12 * exec_ratio / peak_meas) if peak_meas else None}
+            'flop_per_launch': flop, 'avg_launch_ms': body_launch_s * 1e3,
+            'direct_form_flop_per_launch': BODY_FLOP_PER_LAUNCH, 'direct_form_equivalent_TFLOPs': direct_rate / 1e12,
+            'denoiser_direct_form_flop_per_iter': FFDNET_FLOP_PER_ITER,
+            # executed matrix FLOPs over the direct form's: 1/2.25 (Winograd), 1 (direct), 3.11 (split-fp16 products)
+            'mfma_flop_executed_over_direct_form': exec_ratio,
+            'matrix_pipe_frac_of_peak': direct_rate * exec_ratio / peak,
+            # the ceiling MEASURED in this invocation with a register-resident MFMA loop on random operands (no memory traffic)
+            'peak_measured': peak_meas, 'peak_measured_source': measured.get('source'),
+            'matrix_pipe_frac_of_measured_peak': (direct_rate / 1e12 * exec_ratio / peak_meas) if peak_meas else None}
 
 
 def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
@@ -545,12 +662,30 @@ def config_records(ffd_sd, budget_s=60.0):
                        'weights (model.pth absent from the reference snapshot)',
            'denoiser_flop_per_iteration': flop, 'dominant_kernel': 'conv3x3 c8/c8s kernels of the two DenBlock stages (16 blocks of 17 layers)'}
     gpu_it = {}
+    # FastDVDnet launches whose padded shape hides the real one: the grouped first conv (3 groups of 4 -> 30 channels, run
+    # as one 16 -> 96 launch) and the 32 -> 3 tail (run as 32 -> 8)
+    real = {(16, 96): 9 * 4 * 90, (32, 8): 9 * 32 * 3}
     for prec in PRECISIONS:
         run = AdmmRun(y, Phi, 'fastdvd_color', True, x0_bayer=warm, X_orig=orig, model=fnet, conv_precision=prec)
         ms = _ms_per_iter(run, 8 / 255, 5, 2)
+        # the same iteration on ONE stream with an event pair around every convolution launch: per-layer-class table
+        with single_stream_launch_log() as log:
+            for _ in range(3):
+                run.step(8 / 255)
+            torch.cuda.synchronize()
+            table = layer_table(log, real)
+        conv_us = sum(r['total_us'] for r in table) / 3
+        ex = sum(r['executed_flop_per_launch'] * r['launches'] for r in table) / 3
         peak = PEAK_FP32_MFMA if prec == 'f32' else PEAK_F16_MFMA
-        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'achieved_TFLOPs': flop / (ms * 1e-3) / 1e12,
-                     'peak_TFLOPs': peak / 1e12, 'frac': flop / (ms * 1e-3) / peak}
+        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'peak_TFLOPs': peak / 1e12,
+                     'algorithmic_TFLOPs': flop / (ms * 1e-3) / 1e12,
+                     'executed_matrix_flop_per_iteration': ex,
+                     # whole-iteration fraction: min(algorithmic, executed) FLOPs of the denoiser over the iteration time
+                     'frac': min(flop, ex) / (ms * 1e-3) / peak,
+                     'matrix_pipe_duty': ex / (ms * 1e-3) / peak,
+                     'conv_launch_us_per_iteration_single_stream': conv_us,
+                     'layers': [{k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in r.items()} for r in table],
+                     'layers_note': 'one stream, HIP event pair per launch, 3 iterations; launches = per 3 iterations'}
         with conv_precision(prec):
             gpu_it[prec] = gpu_iterates(lambda: S.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [2], False, [8 / 255],
                                                                              x0_bayer=warm, X_orig=orig, model_denoise=fnet,
@@ -601,8 +736,16 @@ def config_records(ffd_sd, budget_s=60.0):
             run2.step(SIGMA)
         torch.cuda.synchronize()
         ev = (time.perf_counter() - t0) / 3 * 1e3
-        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'achieved_TFLOPs': tile_flop / (ms * 1e-3) / 1e12,
-                     'peak_TFLOPs': peak / 1e12, 'frac': tile_flop / (ms * 1e-3) / peak,
+        with single_stream_launch_log() as log:
+            for _ in range(3):
+                run.step(SIGMA)
+            torch.cuda.synchronize()
+            table = layer_table(log, {(16, 96): 9 * 13 * 96, (96, 16): 9 * 96 * 12})
+        ex = sum(r['executed_flop_per_launch'] * r['launches'] for r in table) / 3
+        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'peak_TFLOPs': peak / 1e12,
+                     'algorithmic_TFLOPs': tile_flop / (ms * 1e-3) / 1e12, 'executed_matrix_flop_per_iteration': ex,
+                     'frac': min(tile_flop, ex) / (ms * 1e-3) / peak, 'matrix_pipe_duty': ex / (ms * 1e-3) / peak,
+                     'layers': [{k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in r.items()} for r in table],
                      'ms_per_iteration_with_finetune_event': ev}
         net3 = FFDNet()
         net3.load_state_dict(ffd_sd)
@@ -623,6 +766,131 @@ def config_records(ffd_sd, budget_s=60.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ fixed-total modes
+DRIVER_SIGMA, DRIVER_ITERS = [25 / 255, 12 / 255, 6 / 255], [15, 6, 4]     # two_stage_ADMM_Online_FFD_Warm.py:71-76 (default scene)
+
+
+def driver_sigma(k, steps):
+    """sigma of iteration k when the reference driver's 25-iteration schedule ([15,6,4] at sigma [25,12,6]/255) is run for
+    `steps` iterations: the stage boundaries scale with steps (exactly the driver's schedule at steps = 25)"""
+    pos = (k + 0.5) * sum(DRIVER_ITERS) / steps
+    acc = 0
+    for sg, n in zip(DRIVER_SIGMA, DRIVER_ITERS):
+        acc += n
+        if pos < acc:
+            return sg
+    return DRIVER_SIGMA[-1]
+
+
+def fixed_total_mode(args, ctx, net, wdesc):
+    """BASELINE configs[3] (`--cubes C`: a fixed total of C independent 512x512x8 cubes, C/N per rank) and configs[4]
+    (`--config tile1024`: one 1024x1024x16 colour cube as 16 patches of 256x256, per-tile model copy and online finetune,
+    16/N tiles per rank, stitched on rank 0).  One step = one ADMM iteration of EVERY unit of the job; the units of a rank
+    run one after the other, ONE gather (RCCL) ends the timed region; strong scaling.  Rank 0 prints the JSON line with the
+    per-rank solve and gather times."""
+    import copy
+    from adaptivepnp_sci_amd import shard, synth
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    dist, rank, world, dev, cdev = ctx['dist'], ctx['rank'], ctx['world'], ctx['dev'], ctx['coll_dev']
+    tiled = args.config == 'tile1024'
+    if tiled:
+        Hc, Wc, Bc, tile = 1024, 1024, 16, 256
+        yc, Phic, origc = synth.make_problem(Hc, Wc, Bc, seed=5)             # the same cube on every rank
+        units = shard.tile_cube(yc, Phic, tile, orig=origc)
+        n_units, ushape = len(units), (tile, tile, Bc)
+        fkw = dict(update_=True, lr_=2e-6, update_per_iter=2, inital_iter=1, interval_iter=15)   # driver: one event at k = 15
+    else:
+        n_units, ushape, fkw = args.cubes, (H, W, B), {}
+        units = None
+    events = []
+
+    def prepare(u, throwaway=False):
+        if tiled:
+            y_u, Phi_u, _x0, orig_u = units[u]
+        else:
+            y_u, Phi_u, orig_u = synth.make_problem(H, W, B, seed=u)
+        tv = AdmmRun(y_u, Phi_u, 'tv', False)                               # TV warm start, as the reference driver; untimed
+        for _ in range(40):
+            tv.step(0)
+        kw = dict(fkw, interval_iter=2) if throwaway else fkw
+        run = AdmmRun(y_u, Phi_u, 'ffdnet_color', True, x0_bayer=tv.result_mosaic(), X_orig=orig_u,
+                      model=copy.deepcopy(net) if tiled else net, conv_precision='f32', **kw)
+        if not throwaway and not events:
+            run.profile_events = events
+        return run
+
+    mine = shard.partition(n_units, world, rank)
+    if mine:
+        # device pre-heat and W warm-up steps on a throwaway run of the rank's first unit (the timed runs start at k = 0, so
+        # the finetune gate fires where the driver's schedule puts it; the throwaway fires one at k = 2 to warm those kernels)
+        warm_run = prepare(mine[0], throwaway=True)
+        warm_run.eng.in_c8.zero_()
+        for _ in range(args.preheat):
+            warm_run.eng.forward()
+        for k in range(args.warmup):
+            warm_run.step(driver_sigma(k, max(args.warmup, 1)) if tiled else SIGMA)
+        del warm_run
+    if dist is not None:                                                     # untimed: RCCL sets up its connections
+        shard.gather_units({u: torch.zeros(ushape, device=cdev) for u in mine}, n_units, ushape, cdev, dst=0)
+
+    def iterate(run, k):
+        run.step(driver_sigma(k, args.steps) if tiled else SIGMA)
+
+    def finish(run):
+        m = run.result_mosaic()
+        return m if cdev == dev else m.cpu()
+
+    got, timing = shard.timed_job(n_units, prepare, iterate, finish, ushape, cdev, args.steps, sync=torch.cuda.synchronize)
+    if rank != 0:
+        return
+    dt = timing['total_s']
+    body_s = float(np.mean([a.elapsed_time(b) for a, b in events])) / 1e3 / (NB - 2) if events else None
+    mosaic = shard.stitch_tiles(got, Hc, Wc, tile) if tiled else None
+    psnr = None
+    if tiled:
+        mse = float(((mosaic.cpu().double() - torch.from_numpy(origc).double()) ** 2).mean())
+        psnr = 10 * np.log10(1.0 / mse)
+    flop_px = 2.0 * 9 * (13 * NC + (NB - 2) * NC * NC + NC * 12) / 4           # FFDNet FLOPs per full-resolution pixel and frame
+    px = (Hc * Wc * Bc) if tiled else (H * W * B * n_units)
+    line = {
+        'metric': 'admm_iters_per_s', 'unit': 'ADMM iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'data': f'synthetic (seeded moving-sinusoid cube(s), Bernoulli(0.5) mask, noise-free y); weights: {wdesc}',
+        'ranks': world, 'units_total': n_units, 'units_per_rank': timing['units'],
+        'per_rank_solve_s': timing['solve_s'], 'per_rank_gather_s': timing['gather_s'], 'timed_region_s': dt,
+        'collective': ('none (single process)' if dist is None else
+                       'ONE RCCL gather (torch.distributed backend nccl)' if dist.get_backend() == 'nccl' else
+                       f'ONE {dist.get_backend()} gather on host copies (SCIPNP_BENCH_BACKEND test hook)'),
+        'denoiser_direct_form_TFLOPs': flop_px * px * args.steps / dt / 1e12,
+        'roofline': None if body_s is None else roofline_record('f32', body_s * (H // 2) * (W // 2) * B /
+                                                                 ((ushape[0] // 2) * (ushape[1] // 2) * ushape[2]),
+                                                                 None, 'not collected in this mode', {}, ctx['f32_form']),
+        'cpu_baseline': None, 'cpu_baseline_note': 'reported by the default mode (python bench.py), N = 1',
+    }
+    if tiled:
+        line.update({
+            'value': args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
+            'tile_iterations_per_s': n_units * args.steps / dt, 'frame_iterations_per_s': Bc * args.steps / dt,
+            'config': {'workload': 'BASELINE configs[4]: 1024x1024x16 colour cube tiled into 16 patches of 256x256, two-stage ADMM '
+                                   '+ FFDNet-color with the online finetune (per-tile model copy; lr 2e-6, 2 Adam steps per event, '
+                                   'gate k > 1 and k % 15 == 0), sigma schedule of the reference driver scaled to --steps; one step = '
+                                   'one ADMM iteration of the whole cube (all 16 tiles)',
+                       'cube': [Hc, Wc, Bc], 'tile': tile, 'parallelism': f'16 tiles over {world} rank(s), one gather, stitched on rank 0'},
+            'finetune_events_per_tile': sum(1 for k in range(args.steps) if k > 1 and k % 15 == 0),
+            'stitched_psnr_db': psnr})
+    else:
+        line.update({
+            'value': n_units * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
+            'frame_iterations_per_s': n_units * B * args.steps / dt,
+            'config': {'workload': f'BASELINE configs[3]: batch of {n_units} independent 512x512x8 Bayer cubes, two-stage ADMM + '
+                                   'FFDNet-color (Malvar, sigma 25/255, TV warm start, per-iteration PSNR on device); one step = one '
+                                   f'ADMM iteration of every cube; value = cube-iterations/s of the whole job',
+                       'cube': [H, W, B], 'cubes': n_units, 'parallelism': f'{n_units} cubes over {world} rank(s), one gather'}})
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -635,9 +903,15 @@ def main():
     ap.add_argument('--no-fast-path', action='store_true', help='time only the fp32 headline (profiling runs)')
     ap.add_argument('--preheat', type=int, default=40, help='untimed denoiser passes before the warm-up steps (device clocks)')
     ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU-oracle work per cpu_baseline run')
+    ap.add_argument('--cubes', type=int, default=0, help='BASELINE configs[3]: a FIXED total of this many 512x512x8 cubes over '
+                                                         'the ranks (strong scaling); 0 = one cube per rank (weak, the default)')
+    ap.add_argument('--config', choices=['headline', 'tile1024'], default='headline',
+                    help='tile1024 = BASELINE configs[4]: 1024x1024x16 cube as 16 tiles of 256x256 with the online finetune')
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
+    if args.cubes < 0 or (args.cubes and args.config != 'headline'):
+        ap.error('--cubes must be >= 0 and cannot be combined with --config tile1024')
 
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
@@ -682,6 +956,15 @@ def main():
     from adaptivepnp_sci_amd import synth
     from adaptivepnp_sci_amd.solver import AdmmRun
     net, wdesc = load_weights()
+    if args.cubes or args.config == 'tile1024':
+        from adaptivepnp_sci_amd.nets import f32_conv_form
+        coll_dev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
+        fixed_total_mode(args, dict(dist=dist, rank=rank, world=world, dev=dev, coll_dev=coll_dev, f32_form=f32_conv_form()),
+                         net, wdesc)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     y, Phi, orig = synth.make_problem(H, W, B, seed=rank)
     # TV warm start, as the reference driver does (two_stage_ADMM_Online_FFD_Warm.py:259-263); untimed
     tv = AdmmRun(y, Phi, 'tv', False)
@@ -707,10 +990,10 @@ def main():
         else:
             del run
     if rank == 0:
-        measured = {}
-        mpath = os.path.join(ROOT, 'profiles', 'measured_peaks.json')
-        if os.path.exists(mpath):                          # tools/peaks_bench.py on an MI355X of the pool
-            measured = json.load(open(mpath))
+        try:
+            measured = measure_peaks(dev)                  # this device, this invocation, clocks warm from the timed passes
+        except Exception as e:                             # noqa: BLE001 -- the headline must still be printed
+            measured = {'source': f'unavailable ({type(e).__name__}: {e})'}
         head = recs['f32']
         line = {
             'metric': 'admm_iters_per_s', 'value': head['value'], 'unit': 'ADMM iterations/s',
@@ -730,6 +1013,7 @@ def main():
             'frames_per_s': None,
             'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured, f32_form),
             'phi_step': phi_record(last_run, head['phi_s'], traffic, traffic_src, measured, dev),
+            'measured_peaks': measured,
             'preheat': f'{args.preheat} untimed denoiser passes before the warm-up steps (clock ramp after the TV phase)',
             'psnr_db_first_last': head['psnr_db_first_last'],
         }

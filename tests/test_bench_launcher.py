@@ -95,3 +95,38 @@ def test_bench_spawns_two_ranks_sharing_the_gpu():
     line = json.loads(out[0])
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['units_gathered_on_rank0'] == 2
     assert line['cpu_baseline'] is None and line['value'] > 0 and line['fast_path']['value'] > line['value']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [['--cubes', '4'], ['--config', 'tile1024']])
+def test_bench_fixed_total_modes_two_ranks_sharing_the_gpu(mode):
+    """BASELINE configs[3] / configs[4] as bench modes: a FIXED total of units (4 cubes here; the 16 tiles of the 1024x1024x16
+    cube) split over two ranks that share the box's GPU (gloo on host copies, as above), one gather, per-rank solve and
+    gather times in the line, strong scaling"""
+    env = _env(SCIPNP_BENCH_SHARE_GPU='1', SCIPNP_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '17', '--warmup', '3', '--preheat', '5'] + mode, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, out
+    line = json.loads(out[0])
+    n_units = 16 if 'tile1024' in mode else 4
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['units_total'] == n_units
+    assert line['units_per_rank'] == [n_units // 2] * 2
+    assert len(line['per_rank_solve_s']) == 2 and len(line['per_rank_gather_s']) == 2 and min(line['per_rank_solve_s']) > 0
+    assert line['value'] > 0 and abs(line['ms_per_step'] * line['steps'] - 1e3 * line['timed_region_s']) < 1e-6
+    assert 0 < line['roofline']['frac'] <= 1
+    if 'tile1024' in mode:
+        assert line['finetune_events_per_tile'] == 1 and line['stitched_psnr_db'] > 20
+
+
+def test_driver_sigma_schedule_scales_with_steps():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod_sigma', BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    full = [b.driver_sigma(k, 25) for k in range(25)]
+    assert full == [25 / 255] * 15 + [12 / 255] * 6 + [6 / 255] * 4             # the reference driver's own schedule
+    half = [b.driver_sigma(k, 50) for k in range(50)]
+    assert half == [25 / 255] * 30 + [12 / 255] * 12 + [6 / 255] * 8
+    assert b.driver_sigma(0, 1) == 25 / 255 or b.driver_sigma(0, 1) in b.DRIVER_SIGMA

@@ -121,3 +121,64 @@ def test_tile_grid_and_stitch_round_trip():
         shard.tile_grid(10, 8, 4)
     with pytest.raises(ValueError):
         shard.tile_grid(9, 9, 3)
+
+
+def _job_worker(rank, world, port, n_units, tiled, ret):
+    sys.path.insert(0, ROOT)
+    from adaptivepnp_sci_amd import shard
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        H, W, B, tile = (16, 16, 3, 4) if tiled else (6, 8, 3, None)
+        g = torch.Generator().manual_seed(0)
+        cube = torch.rand(H, W, B, generator=g)
+        units = shard.tile_cube(cube[:, :, 0], cube, tile) if tiled else None
+        shape = (tile, tile, B) if tiled else (H, W, B)
+        prepared = []
+
+        def prepare(u):
+            prepared.append(u)
+            base = units[u][1].clone() if tiled else torch.full(shape, float(u))
+            return {'x': base, 'k': 0}
+
+        def iterate(st, k):
+            assert st['k'] == k                       # every unit runs its own steps 0 .. steps-1, in order
+            st['x'] += 1.0
+            st['k'] += 1
+
+        got, timing = shard.timed_job(n_units, prepare, iterate, lambda st: st['x'], shape, torch.device('cpu'), steps=5)
+        assert prepared == shard.partition(n_units, world, rank)
+        assert timing['units'] == [len(shard.partition(n_units, world, r)) for r in range(world)]
+        assert len(timing['solve_s']) == world and len(timing['gather_s']) == world
+        assert timing['total_s'] >= max(timing['solve_s'])
+        if rank == 0:
+            if tiled:
+                want = cube.clone()
+                for _ in range(5):
+                    want += 1.0
+                ok = torch.equal(shard.stitch_tiles(got, H, W, tile), want)
+            else:
+                ok = all(torch.equal(got[u], torch.full(shape, float(u) + 5.0)) for u in range(n_units))
+            ret.put(bool(ok))
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_units,tiled', [(8, False), (16, True), (3, False)])
+def test_fixed_total_timed_job_gloo(n_units, tiled):
+    """bench.py --cubes 8 / --config tile1024 plumbing (BASELINE configs[3] / [4]): a fixed total of units over 2 ranks,
+    K steps per unit, ONE gather, per-rank solve / gather times collected after the timed region"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    port = 33500 + (os.getpid() + n_units) % 2000
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_units, tiled, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
