@@ -72,6 +72,8 @@ SIGNATURES = {
     'scipnp_pack_conv3x3_split_bn': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_split_overflow': (_int, [_int, C.POINTER(_int), _vp]),
+    'scipnp_bind_overflow_word': (_int, [_vp]),
+    'scipnp_read_overflow_word': (_int, [_vp, _int, C.POINTER(_int), _vp]),
     'scipnp_c8_to_c8s': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_c8_add_to_c8s': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8s_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
@@ -117,16 +119,39 @@ SIGNATURES = {
     'scipnp_cube_sum3': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8w': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_ffdnet_forward_c8s_2s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
 class AdmmTvArgs(C.Structure):
-    """scipnp_admm_tv_args of include/scipnp.h"""
-    _fields_ = [('M', C.c_int), ('N', C.c_int), ('B', C.c_int), ('two_stage', C.c_int),
+    """scipnp_admm_tv_args of include/scipnp.h (struct_size is filled in by the constructor)"""
+    _fields_ = [('struct_size', C.c_size_t), ('M', C.c_int), ('N', C.c_int), ('B', C.c_int), ('two_stage', C.c_int),
                 ('theta', C.c_void_p), ('b', C.c_void_p), ('x', C.c_void_p), ('theta_raw', C.c_void_p),
                 ('Phi', C.c_void_p), ('y', C.c_void_p), ('Phisum', C.c_void_p),
                 ('c0', C.c_double), ('c1', C.c_double), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
                 ('tv_workspace', C.c_void_p), ('tv_workspace_bytes', C.c_size_t),
                 ('orig', C.c_void_p), ('sse_part', C.c_void_p)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class TwoStageFfdnetArgs(C.Structure):
+    """scipnp_twostage_ffdnet_args of include/scipnp.h (struct_size is filled in by the constructor; set the rest by name)"""
+    _fields_ = [('struct_size', C.c_size_t), ('M', C.c_int), ('N', C.c_int), ('B', C.c_int),
+                ('theta', C.c_void_p), ('b', C.c_void_p), ('x', C.c_void_p),
+                ('Phi', C.c_void_p), ('y', C.c_void_p), ('Phisum', C.c_void_p),
+                ('w', C.c_void_p), ('x_rgb', C.c_void_p), ('out_rgb', C.c_void_p),
+                ('net_in_c8s', C.c_void_p), ('net_out_c8', C.c_void_p), ('packed_split', C.c_void_p),
+                ('nb', C.c_int), ('nc', C.c_int), ('scratch0', C.c_void_p), ('scratch1', C.c_void_p),
+                ('orig', C.c_void_p), ('sse_part', C.c_void_p),
+                ('rho', C.c_double), ('alpha', C.c_double), ('tau', C.c_double),
+                ('sigma', C.c_float), ('first_iter', C.c_int),
+                ('packed_wino', C.c_void_p), ('net_in_c8', C.c_void_p),
+                ('overflow_word', C.c_void_p), ('side_stream', C.c_void_p),
+                ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p)]
+
+    def __init__(self, **kw):
+        super().__init__(C.sizeof(type(self)), **kw)
 
 
 _lib = None

@@ -1,6 +1,7 @@
 // Shared helpers for the scipnp HIP sources (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -149,6 +150,36 @@ __device__ __forceinline__ T torch_contig_sum_rt(int nB, T zero, F term) {
     return f;
 }
 
+// range-guard word of the split-fp16 kernels (csrc/conv_split.hip): binds `w` for the calling thread's following launches
+// and returns the previous binding (nullptr = the process-wide word)
+int* exchange_overflow_word(int* w);
+struct OverflowScope {                 // binds a word for one call's launches when given one; restores the thread's binding
+    int* prev = nullptr;
+    bool on;
+    explicit OverflowScope(int* w) : on(w != nullptr) { if (on) prev = exchange_overflow_word(w); }
+    ~OverflowScope() { if (on) exchange_overflow_word(prev); }
+    OverflowScope(const OverflowScope&) = delete;
+    OverflowScope& operator=(const OverflowScope&) = delete;
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one of these per launch site sets it
+// once per device the site is used on; racing first calls from several host threads both set it (idempotent).
+struct LdsAttrOnce {
+    std::atomic<unsigned long long> done{0};
+    int ensure(const void* fn, size_t bytes, const char* what) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(SCIPNP_EHIP, "hipGetDevice (%s)", what);
+        const unsigned long long bit = 1ull << dev;
+        if (done.load(std::memory_order_acquire) & bit) return SCIPNP_OK;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(%s, %zu B LDS): %s", what, bytes, hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_release);
+        return SCIPNP_OK;
+    }
+};
+
+// tv.hip: can the banded one-launch Chambolle kernel take planes of M x N with n_iter iterations?
+bool tv_band_fits(int M, int N, int n_iter);
 // tv.hip: Chambolle TV + ADMM dual update of planes up to 128 x 128 in one launch (used by iterate.hip)
 bool tv_plane_dual_fits(int M, int N, int C, int nfill, bool want_sse);
 int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int N, int C, float weight, float eps,

@@ -240,14 +240,8 @@ conv3x3_c8_kernel(const ConvArgs a) {
 template <int COB, int TAG, int STRIDE, int SHUF>
 static int launch_conv(const ConvArgs& a, int n, hipStream_t st) {
     using Cfg = ConvCfg<COB, STRIDE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8_kernel<COB, TAG, STRIDE, SHUF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3, %zu B LDS): %s", Cfg::LDS_BYTES,
-                                         hipGetErrorString(e));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;
+    if (int rc = attr.ensure((const void*)conv3x3_c8_kernel<COB, TAG, STRIDE, SHUF>, Cfg::LDS_BYTES, "conv3x3_c8")) return rc;
     const dim3 grid((a.Wo + CV_TW - 1) / CV_TW, (a.Ho + CV_TH - 1) / CV_TH, n * a.nsplit);
     hipLaunchKernelGGL((conv3x3_c8_kernel<COB, TAG, STRIDE, SHUF>), grid, dim3(CV_THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8_kernel");

@@ -86,13 +86,17 @@ struct SplitArgs {
     int Ho, Wo;          // conv output size (before any pixel shuffle)
     int flags;           // bit0 ReLU, bit1 (2) residual, bit4 (16) ReLU-mask, bit5 (32) fp32 c8 output, bit3 (8) pixel-shuffle
                          // store (fp32 c8, or c8s with bit6 (64), where the residual has the shuffled shape)
+    int* ovf;            // range-guard word of this launch (see below)
 };
 
-// set when a value leaves fp16's finite range on its way into the c8s format (results are then invalid and the
-// host must rerun with the fp32 kernels); queried once per solve by scipnp_split_overflow
+// Range guard: a launch raises ITS word when a value leaves fp16's finite range on its way into the c8s format (results
+// are then invalid and the host must rerun with the fp32 kernels).  The word is a kernel argument: the device int the
+// calling thread bound with scipnp_bind_overflow_word (one per solve / engine, owned and zeroed by the caller), or -- for
+// callers that never bound one -- the process-wide word below.  Overlapping solves on different host threads therefore
+// never see each other's report.
 __device__ int g_split_overflow = 0;
 
-__device__ __forceinline__ void split_store(float v0, float v1, float v2, float v3, char* hi_ptr, char* lo_ptr) {
+__device__ __forceinline__ void split_store(float v0, float v1, float v2, float v3, char* hi_ptr, char* lo_ptr, int* ovf) {
     f16x4 h, l;
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -101,7 +105,7 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
         h[e] = hh;
         l[e] = (_Float16)((v[e] - (float)hh) * CS_LO_SCALE);
     }
-    if (!(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) < 65000.f)) g_split_overflow = 1;   // also NaN
+    if (!(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) < 65000.f)) *ovf = 1;   // also NaN
     *(f16x4*)hi_ptr = h;
     *(f16x4*)lo_ptr = l;
 }
@@ -109,7 +113,7 @@ __device__ __forceinline__ void split_store(float v0, float v1, float v2, float 
 // the same split, stored as ONE 16-byte vector per lane: lanes l and l+32 of the wave hold the two channel quads of one
 // pixel's 8-channel group; after exchanging a half each, lane l < 32 stores [hi quad 0 | hi quad 1] to the hi plane and lane
 // l+32 [lo' quad 0 | lo' quad 1] to the lo' plane (`dst` = that lane's plane + pixel offset).  Both lanes of a pair must be active.
-__device__ __forceinline__ void split_store16(float v0, float v1, float v2, float v3, char* dst) {
+__device__ __forceinline__ void split_store16(float v0, float v1, float v2, float v3, char* dst, int* ovf) {
 #if defined(__HIP_DEVICE_COMPILE__)
     f16x4 h, l;
     const float v[4] = {v0, v1, v2, v3};
@@ -119,7 +123,7 @@ __device__ __forceinline__ void split_store16(float v0, float v1, float v2, floa
         h[e] = hh;
         l[e] = (_Float16)((v[e] - (float)hh) * CS_LO_SCALE);
     }
-    if (!(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) < 65000.f)) g_split_overflow = 1;   // also NaN
+    if (!(fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) < 65000.f)) *ovf = 1;   // also NaN
     union { f16x4 f; unsigned u[2]; } hu, lu;
     hu.f = h; lu.f = l;
     // permlane32_swap(x, y): x of lanes 32..63 <-> y of lanes 0..31
@@ -348,8 +352,8 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                                 for (int c = 0; c < 8; ++c) o8[dx][c] = o8[dx][c] + ((float)rh[c] + (float)rl[c] * CS_LO_INV);
                             }
                             char* og_ptr = a.out + grp + (pix + dx) * 16;
-                            split_store(o8[dx][0], o8[dx][1], o8[dx][2], o8[dx][3], og_ptr, og_ptr + HWs * 16);
-                            split_store(o8[dx][4], o8[dx][5], o8[dx][6], o8[dx][7], og_ptr + 8, og_ptr + HWs * 16 + 8);
+                            split_store(o8[dx][0], o8[dx][1], o8[dx][2], o8[dx][3], og_ptr, og_ptr + HWs * 16, a.ovf);
+                            split_store(o8[dx][4], o8[dx][5], o8[dx][6], o8[dx][7], og_ptr + 8, og_ptr + HWs * 16 + 8, a.ovf);
                         }
                     }
                 }
@@ -401,7 +405,7 @@ conv3x3_c8s_kernel(const SplitArgs a) {
                             // lane (li, 1) the eight lo' values of the pixel: ONE 16-byte store per lane and plane instead of two
                             // 8-byte ones (8-byte vector stores run at 0.54-0.70 of the 16-byte rate; the head layers are store-bound)
                             char* grp = a.out + ((size_t)n * a.CGout + cog) * (2 * HWo * 16);
-                            split_store16(v[0], v[1], v[2], v[3], grp + (lh ? HWo * 16 : 0) + pix * 16);
+                            split_store16(v[0], v[1], v[2], v[3], grp + (lh ? HWo * 16 : 0) + pix * 16, a.ovf);
                         }
                     }
                 }
@@ -584,7 +588,7 @@ conv3x3_c8s_k32_kernel(const SplitArgs a) {
                         *(f32x4*)(a.out + ((((size_t)n * a.CGout + cog) * HWo + pix) * 8 + sub) * 4) = o;
                     } else {
                         char* grp = a.out + ((size_t)n * a.CGout + cog) * (2 * HWo * 16);
-                        split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 2 * sub, grp + HWo * 16 + pix * 16 + 2 * sub);
+                        split_store(v[0], v[1], v[2], v[3], grp + pix * 16 + 2 * sub, grp + HWo * 16 + pix * 16 + 2 * sub, a.ovf);
                     }
                 }
             }
@@ -595,13 +599,8 @@ conv3x3_c8s_k32_kernel(const SplitArgs a) {
 template <int COB, int TAG>
 static int launch_split_k32(const SplitArgs& a, int n, hipStream_t st) {
     using Cfg = SplitCfg<COB, 1>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_k32_kernel<COB, TAG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s_k32): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;
+    if (int rc = attr.ensure((const void*)conv3x3_c8s_k32_kernel<COB, TAG>, Cfg::LDS_BYTES, "conv3x3_c8s_k32")) return rc;
     const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + Cfg::TH - 1) / Cfg::TH, n * a.nsplit);
     hipLaunchKernelGGL((conv3x3_c8s_k32_kernel<COB, TAG>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_k32_kernel");
@@ -610,13 +609,9 @@ static int launch_split_k32(const SplitArgs& a, int n, hipStream_t st) {
 template <int COB, int TAG, int STRIDE, int SHUF, int PB = 2, int NW = 4, int WS = 0>
 static int launch_split(const SplitArgs& a, int n, hipStream_t st) {
     using Cfg = SplitCfg<COB, STRIDE, PB, NW, WS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW, WS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8s): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;
+    if (int rc = attr.ensure((const void*)conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW, WS>, Cfg::LDS_BYTES, "conv3x3_c8s"))
+        return rc;
     const dim3 grid((a.Wo + CS_TW - 1) / CS_TW, (a.Ho + Cfg::TH - 1) / Cfg::TH, n * a.nsplit);
     hipLaunchKernelGGL((conv3x3_c8s_kernel<COB, TAG, STRIDE, SHUF, PB, NW, WS>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     return launch_status("conv3x3_c8s_kernel");
@@ -662,7 +657,7 @@ static inline void split_host(float v, _Float16* hi, _Float16* lo) {
 // fp32 c8 (+ optional c8s residual) -> c8s
 __global__ void __launch_bounds__(256)
 c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, char* __restrict__ out, size_t HW,
-                 size_t total /* n*CG*HW */) {
+                 size_t total /* n*CG*HW */, int* ovf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t grp = i / HW, pix = i - grp * HW;
@@ -677,15 +672,15 @@ c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, cha
             b[e] = b[e] + ((float)rh[4 + e] + (float)rl[4 + e] * CS_LO_INV);
         }
     }
-    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16);
-    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
+    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16, ovf);
+    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8, ovf);
 }
 
 // device-side packing of (updated) fp32 master weights for the online finetune: forward layout, or the backward-data
 // convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (no bias).  One thread per (cig, tap, co, c8) element pair.
 __global__ void __launch_bounds__(256)
 pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
-                         char* __restrict__ packed, int Cin_real, int Cout_real, int Kin, int KoutP, int transpose) {
+                         char* __restrict__ packed, int Cin_real, int Cout_real, int Kin, int KoutP, int transpose, int* ovf) {
     const size_t nw = (size_t)(Kin / 8) * 9 * KoutP * 8;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + KoutP) return;
@@ -711,7 +706,7 @@ pack_split_device_kernel(const float* __restrict__ w, const float* __restrict__ 
             if (scale) val = val * scale[in_ch];
         }
     }
-    if (!(fabsf(val) < 31.9f)) g_split_overflow = 1;
+    if (!(fabsf(val) < 31.9f)) *ovf = 1;
     const _Float16 hi = (_Float16)val;
     const _Float16 lo = (_Float16)((val - (float)hi) * CS_LO_SCALE);
     _Float16* p = (_Float16*)packed;
@@ -739,14 +734,30 @@ c8s_to_c8_kernel(const char* __restrict__ in, float* __restrict__ out, size_t HW
 }
 
 __global__ void __launch_bounds__(256)
-c8_scale_to_c8s_kernel(const float* __restrict__ in, char* __restrict__ out, size_t HW, size_t total, float scale) {
+c8_scale_to_c8s_kernel(const float* __restrict__ in, char* __restrict__ out, size_t HW, size_t total, float scale, int* ovf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t grp = i / HW, pix = i - grp * HW;
     const f32x4 a = *(const f32x4*)(in + i * 8) * scale, b = *(const f32x4*)(in + i * 8 + 4) * scale;
     char* g = out + grp * (2 * HW * 16);
-    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16);
-    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8);
+    split_store(a[0], a[1], a[2], a[3], g + pix * 16, g + HW * 16 + pix * 16, ovf);
+    split_store(b[0], b[1], b[2], b[3], g + pix * 16 + 8, g + HW * 16 + pix * 16 + 8, ovf);
+}
+
+// the calling thread's bound word (scipnp_bind_overflow_word), else the process-wide one of the current device
+static thread_local int* t_ovf_word = nullptr;
+
+int* exchange_overflow_word(int* w) {
+    int* prev = t_ovf_word;
+    t_ovf_word = w;
+    return prev;
+}
+
+static int* current_ovf_word() {
+    if (t_ovf_word) return t_ovf_word;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_split_overflow)) != hipSuccess) return nullptr;
+    return (int*)p;
 }
 
 }  // namespace scipnp
@@ -762,6 +773,9 @@ int scipnp_pack_conv3x3_split_device_scaled(const float* w, const float* bias, c
                                             int Cout_real, int Cin, int Cout, int transpose_flip, scipnp_stream_t s);
 int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* out, const void* residual_c8s,
                           const void* mask_c8s, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+int scipnp_ffdnet_forward_c8s_2s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                                 void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s,
+                                 scipnp_stream_t side_stream, void* fork_event, void* join_event);
 
 size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
@@ -833,6 +847,8 @@ int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* ou
     a.Ho = stride2 ? (h - 1) / 2 + 1 : h;
     a.Wo = stride2 ? (w - 1) / 2 + 1 : w;
     a.flags = flags;
+    a.ovf = current_ovf_word();
+    SCIPNP_REQUIRE(a.ovf, "no range-guard word (hipGetSymbolAddress failed)");
     hipStream_t st = (hipStream_t)s;
     SCIPNP_REQUIRE((long long)n * (a.CoutP_total / 32) <= 65535, "grid too large");
     if (stride2) return dispatch_split<2, 0>(a, n, st);
@@ -840,20 +856,31 @@ int scipnp_conv3x3_c8s_ex(const void* in_c8s, const void* packed_split, void* ou
     return dispatch_split<1, 0>(a, n, st);
 }
 
-int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s) {
+int scipnp_bind_overflow_word(int* dev_word) {
+    t_ovf_word = dev_word;
+    return SCIPNP_OK;
+}
+
+int scipnp_read_overflow_word(const int* dev_word, int reset, int* flag_out, scipnp_stream_t s) {
     // synchronises the stream (one call per reconstruction, next to the final read-back)
     hipStream_t st = (hipStream_t)s;
+    int* word = dev_word ? (int*)dev_word : current_ovf_word();
+    SCIPNP_REQUIRE(word, "no range-guard word");
     int v = 0;
-    hipError_t e = hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_split_overflow), sizeof(int), 0, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(&v, word, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return fail(SCIPNP_EHIP, "scipnp_split_overflow: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(SCIPNP_EHIP, "scipnp_read_overflow_word: %s", hipGetErrorString(e));
     if (flag_out) *flag_out = v;
     if (reset && v) {
-        const int zero = 0;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow), &zero, sizeof(int), 0, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "scipnp_split_overflow reset: %s", hipGetErrorString(e));
+        e = hipMemsetAsync(word, 0, sizeof(int), st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(SCIPNP_EHIP, "scipnp_read_overflow_word reset: %s", hipGetErrorString(e));
     }
     return SCIPNP_OK;
+}
+
+int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s) {
+    return scipnp_read_overflow_word(nullptr, reset, flag_out, s);
 }
 
 int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s) {
@@ -866,8 +893,10 @@ int scipnp_c8_add_to_c8s(const float* in_c8, const void* residual_c8s, void* out
     SCIPNP_ALIGNED(in_c8); SCIPNP_ALIGNED(out_c8s);
     if (residual_c8s) SCIPNP_ALIGNED(residual_c8s);
     const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
+    int* ovf = current_ovf_word();
+    SCIPNP_REQUIRE(ovf, "no range-guard word");
     hipLaunchKernelGGL(c8_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
-                       (const char*)residual_c8s, (char*)out_c8s, HW, total);
+                       (const char*)residual_c8s, (char*)out_c8s, HW, total, ovf);
     return launch_status("c8_to_c8s_kernel");
 }
 
@@ -884,8 +913,10 @@ int scipnp_pack_conv3x3_split_device_scaled(const float* w, const float* bias, c
     const int Kin = transpose_flip ? Cout : Cin;
     const int KoutP = round_up_s(transpose_flip ? Cin : Cout, 32);
     const size_t total = (size_t)(Kin / 8) * 9 * KoutP * 8 + KoutP;
+    int* ovf = current_ovf_word();
+    SCIPNP_REQUIRE(ovf, "no range-guard word");
     hipLaunchKernelGGL(pack_split_device_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, bias,
-                       scale, (char*)packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip);
+                       scale, (char*)packed, Cin_real, Cout_real, Kin, KoutP, transpose_flip, ovf);
     return launch_status("pack_split_device_kernel");
 }
 
@@ -902,8 +933,10 @@ int scipnp_c8_scale_to_c8s(const float* in_c8, void* out_c8s, float scale, int n
     SCIPNP_REQUIRE(in_c8 && out_c8s && n > 0 && C % 8 == 0 && C > 0 && h > 0 && w > 0, "bad arguments");
     SCIPNP_ALIGNED(in_c8); SCIPNP_ALIGNED(out_c8s);
     const size_t HW = (size_t)h * w, total = (size_t)n * (C / 8) * HW;
+    int* ovf = current_ovf_word();
+    SCIPNP_REQUIRE(ovf, "no range-guard word");
     hipLaunchKernelGGL(c8_scale_to_c8s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, in_c8,
-                       (char*)out_c8s, HW, total, scale);
+                       (char*)out_c8s, HW, total, scale, ovf);
     return launch_status("c8_scale_to_c8s_kernel");
 }
 
@@ -924,59 +957,34 @@ static int ffdnet_c8s_frames(const char* in_c8s, float* out_c8, const void* cons
     return scipnp_conv3x3_c8s(buf[cur], packed_split[nb - 1], out_c8 + n0 * out_f, nf, nc, 16, M, N, 32, st);
 }
 
-// SCIPNP_STREAMS (default 2, as adaptivepnp_sci_amd/ops.py on_side_streams): with 2, the second half of the frames runs on a
-// side stream of the calling thread, forked from and joined to the caller's stream by events (legal under hipGraph capture:
-// the side stream joins before the call returns) -- its launches fill the CUs the last generation of the other half leaves idle
-struct SideLane {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    int dev = -1;
-};
-
-static int side_lane(SideLane** out) {
-    static thread_local SideLane lanes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(SCIPNP_EHIP, "hipGetDevice");
-    SideLane& l = lanes[dev];
-    if (!l.st) {
-        if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess)
-            return fail(SCIPNP_EHIP, "side stream of the split-fp16 network pass: %s", hipGetErrorString(hipGetLastError()));
-        l.dev = dev;
-    }
-    *out = &l;
-    return SCIPNP_OK;
-}
-
-static int side_stream_count() {
-    static const int n = [] {
-        const char* e = getenv("SCIPNP_STREAMS");
-        const int v = e ? atoi(e) : 2;
-        return v < 1 ? 1 : v;
-    }();
-    return n;
-}
-
 int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
                               void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    return scipnp_ffdnet_forward_c8s_2s(in_c8s, out_c8, packed_split, nb, nc, scratch0, scratch1, B, M, N, s, nullptr, nullptr,
+                                        nullptr);
+}
+
+// With a side stream: the second half of the frames runs there, forked from and joined to the caller's stream by the
+// caller's two events (legal under hipGraph capture: the side stream joins before the call returns) -- its launches fill
+// the CUs the last generation of the other half leaves idle.  The library creates no streams or events of its own.
+int scipnp_ffdnet_forward_c8s_2s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                                 void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s,
+                                 scipnp_stream_t side_stream, void* fork_event, void* join_event) {
     SCIPNP_REQUIRE(in_c8s && out_c8 && packed_split && scratch0 && scratch1, "null pointer");
     SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0 && B > 0, "bad network shape nb=%d nc=%d B=%d", nb, nc, B);
+    SCIPNP_REQUIRE(!side_stream || (fork_event && join_event), "a side stream needs the caller's fork and join events");
     const char* in = (const char*)in_c8s;
     char *s0 = (char*)scratch0, *s1 = (char*)scratch1;
-    if (side_stream_count() < 2 || B < 2)
+    if (!side_stream || B < 2)
         return ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, 0, B, M, N, s);
-    SideLane* lane = nullptr;
-    int rc = side_lane(&lane);
-    if (rc) return rc;
     const int h0 = (B + 1) / 2;
-    hipStream_t cur = (hipStream_t)s;
-    if (hipEventRecord(lane->fork, cur) != hipSuccess || hipStreamWaitEvent(lane->st, lane->fork, 0) != hipSuccess)
+    hipStream_t cur = (hipStream_t)s, side = (hipStream_t)side_stream;
+    hipEvent_t fork = (hipEvent_t)fork_event, join = (hipEvent_t)join_event;
+    if (hipEventRecord(fork, cur) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess)
         return fail(SCIPNP_EHIP, "fork of the side stream: %s", hipGetErrorString(hipGetLastError()));
-    rc = ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, h0, B - h0, M, N, (scipnp_stream_t)lane->st);
+    const int rc = ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, h0, B - h0, M, N, side_stream);
     const int rc0 = ffdnet_c8s_frames(in, out_c8, packed_split, nb, nc, s0, s1, 0, h0, M, N, s);
     // join even after a failed launch: the caller's stream must not run ahead of work already queued on the side stream
-    if (hipEventRecord(lane->join, lane->st) != hipSuccess || hipStreamWaitEvent(cur, lane->join, 0) != hipSuccess)
+    if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(cur, join, 0) != hipSuccess)
         return fail(SCIPNP_EHIP, "join of the side stream: %s", hipGetErrorString(hipGetLastError()));
     return rc ? rc : rc0;
 }

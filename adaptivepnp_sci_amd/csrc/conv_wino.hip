@@ -519,31 +519,18 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     const void* fns[4] = {(const void*)conv3x3_c8w_kernel<0, 4>, (const void*)conv3x3_c8w_kernel<0, 8>,
                           (const void*)conv3x3_c8w_kernel<1, 4>, (const void*)conv3x3_c8w_kernel<1, 8>};
     const size_t lds = big ? WinoCfg<8>::LDS_BYTES : WinoCfg<4>::LDS_BYTES;
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[vi]) {
-        hipError_t e = hipFuncSetAttribute(fns[vi], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w, %zu B LDS): %s", lds, hipGetErrorString(e));
-        attr_set[vi] = true;
-    }
+    static LdsAttrOnce attr[4];
+    if (int rc = attr[vi].ensure(fns[vi], lds, "conv3x3_c8w")) return rc;
     const dim3 grid((unsigned)total), block(big ? 512 : 256);
     if (flags & 8) {                                            // PixelShuffle(2) store (UpBlocks of FastDVDnet / DDnet)
-        static bool shuf_set = false;
-        if (!shuf_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<0, 4, 2, false, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w shuffle): %s", hipGetErrorString(e));
-            shuf_set = true;
-        }
+        static LdsAttrOnce shuf_attr;
+        if (int rc = shuf_attr.ensure((const void*)conv3x3_c8w_kernel<0, 4, 2, false, true>, lds, "conv3x3_c8w shuffle")) return rc;
         hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4, 2, false, true>), grid, block, lds, (hipStream_t)s, a);
         return launch_status("conv3x3_c8w_kernel<shuffle>");
     }
     if (!big && Cout <= 16) {                                   // one real 16-channel half: TAG 1 (first / last layers) only
-        static bool half_set = false;
-        if (!half_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w half): %s", hipGetErrorString(e));
-            half_set = true;
-        }
+        static LdsAttrOnce half_attr;
+        if (int rc = half_attr.ensure((const void*)conv3x3_c8w_kernel<1, 4, 1>, lds, "conv3x3_c8w half")) return rc;
         hipLaunchKernelGGL((conv3x3_c8w_kernel<1, 4, 1>), grid, block, lds, (hipStream_t)s, a);
         return launch_status("conv3x3_c8w_kernel<1,4,1>");
     }
@@ -570,8 +557,8 @@ int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float*
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
     const size_t lds = WinoCfg<4>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c8w_kernel<0, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(conv3x3_c8w stamped): %s", hipGetErrorString(e));
+    static LdsAttrOnce stamp_attr;
+    if (int rc = stamp_attr.ensure((const void*)conv3x3_c8w_kernel<0, 4, 2, true>, lds, "conv3x3_c8w stamped")) return rc;
     hipLaunchKernelGGL((conv3x3_c8w_kernel<0, 4, 2, true>), dim3((unsigned)total), dim3(256), lds, (hipStream_t)s, a);
     return launch_status("conv3x3_c8w_kernel<stamped>");
 }

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace scipnp
 
 extern "C" {
-const char* scipnp_version(void) { return "scipnp 0.2.0 (round 2)"; }
+const char* scipnp_version(void) { return "scipnp 0.3.0 (round 3)"; }
 const char* scipnp_last_error(void) { return scipnp::g_err; }
 const char* scipnp_arch(void) { return "gfx950"; }
 }

@@ -10,6 +10,10 @@ extern "C" {
 
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s) {
     SCIPNP_REQUIRE(a, "null argument block");
+    SCIPNP_REQUIRE(a->struct_size == sizeof(scipnp_twostage_ffdnet_args),
+                   "scipnp_twostage_ffdnet_args.struct_size is %zu, this library's block has %zu bytes (set it to sizeof the "
+                   "struct of the header you compile against, and rebuild against include/scipnp.h of this library)",
+                   a->struct_size, sizeof(scipnp_twostage_ffdnet_args));
     const bool f32 = a->packed_wino != nullptr;
     SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_out_c8 && a->scratch0 &&
                    a->scratch1 && (f32 ? (a->net_in_c8 != nullptr) : (a->net_in_c8s && a->packed_split)),
@@ -25,12 +29,15 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
     rc = scipnp_pm_pre_denoise_ex(a->x, a->b, a->w, a->x_rgb, nullptr, f32 ? a->net_in_c8 : nullptr,
                                   f32 ? nullptr : a->net_in_c8s, M, N, B, inv_rho, inv_tau, a->sigma, s);
     if (rc) return rc;
-    if (f32)
+    if (f32) {
         rc = scipnp_ffdnet_forward_c8w(a->net_in_c8, a->net_out_c8, a->packed_wino, a->nb, a->nc, (float*)a->scratch0,
                                        (float*)a->scratch1, B, M, N, s);
-    else
-        rc = scipnp_ffdnet_forward_c8s(a->net_in_c8s, a->net_out_c8, a->packed_split, a->nb, a->nc, a->scratch0, a->scratch1,
-                                       B, M, N, s);
+    } else {
+        // the solve's own range-guard word for the launches of this call; the thread's binding is restored afterwards
+        OverflowScope scope(a->overflow_word);
+        rc = scipnp_ffdnet_forward_c8s_2s(a->net_in_c8s, a->net_out_c8, a->packed_split, a->nb, a->nc, a->scratch0, a->scratch1,
+                                          B, M, N, s, a->side_stream, a->side_fork_event, a->side_join_event);
+    }
     if (rc) return rc;
     // theta = clip(CFA samples of the denoised frames), b += x - theta, w += x_rgb - out, PSNR partials   (:206-209, :265-281)
     return scipnp_pm_post_denoise(nullptr, a->net_out_c8, a->out_rgb, a->x, a->x_rgb, a->theta, a->b, a->w, a->orig,
@@ -39,6 +46,9 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
 
 int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s) {
     SCIPNP_REQUIRE(a, "null argument block");
+    SCIPNP_REQUIRE(a->struct_size == sizeof(scipnp_admm_tv_args),
+                   "scipnp_admm_tv_args.struct_size is %zu, this library's block has %zu bytes", a->struct_size,
+                   sizeof(scipnp_admm_tv_args));
     SCIPNP_REQUIRE(a->theta && a->b && a->x && a->theta_raw && a->Phi && a->y && a->Phisum && a->tv_workspace,
                    "null pointer in argument block");
     const int M = a->M, N = a->N, B = a->B;
@@ -58,7 +68,7 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
     int nstd = 0;
     scipnp_sse_partials(a->x, a->x, (size_t)4 * M * N * B, nullptr, &nstd, s);          // size query: pm_dual_update's grid
     const bool want_sse = a->sse_part && a->orig;
-    const bool banded = N <= 256 && a->tv_iters <= 5 && (long long)4 * B * ((M + 31) / 32) >= 128;
+    const bool banded = tv_band_fits(M, N, a->tv_iters) && (long long)4 * B * ((M + 31) / 32) >= 128;
     if (!banded && tv_plane_dual_fits(M, N, 4 * B, nstd, want_sse)) {
         if (nblocks) *nblocks = nstd;
         return tv_plane_dual(a->x, a->b, coef, a->theta, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->orig,

@@ -514,7 +514,7 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
 }
 
 // band height for N <= 256: 16-row bands when 32-row bands would leave the chip short of workgroups
-static bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && n_iter - 1 <= TVB_HALO; }
+bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && n_iter - 1 <= TVB_HALO; }
 
 static int tv_band_launch(const float* x, const float* b, float coef, float* theta, int M, int N, int C, double weight_d,
                           float tau_over_w, double eps_d, int n_iter, double* part, int32_t* stop_iter, hipStream_t st) {
@@ -522,20 +522,20 @@ static int tv_band_launch(const float* x, const float* b, float coef, float* the
     const int RB = small ? 16 : 32;
     const int nbands = (M + RB - 1) / RB;
     const dim3 grid((unsigned)(C * nbands));
-#define SCIPNP_TVB(COLS, R, STRIPS)                                                                                     \
+#define SCIPNP_TVB(COLS, R, STRIPS, RBV)                                                                                \
     do {                                                                                                                \
-        static_assert(STRIPS * R >= 16 + 2 * TVB_HALO, "band + halo rows");                                            \
+        static_assert(STRIPS * R >= RBV + 2 * TVB_HALO, "a workgroup's rows must cover its band + both halos");        \
         hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
                            n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
         hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
                            n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
     } while (0)
     if (N <= 64) {
-        if (small) SCIPNP_TVB(64, 3, 8); else SCIPNP_TVB(64, 5, 8);
+        if (small) SCIPNP_TVB(64, 3, 8, 16); else SCIPNP_TVB(64, 5, 8, 32);
     } else if (N <= 128) {
-        if (small) SCIPNP_TVB(128, 6, 4); else SCIPNP_TVB(128, 10, 4);
+        if (small) SCIPNP_TVB(128, 6, 4, 16); else SCIPNP_TVB(128, 10, 4, 32);
     } else {
-        if (small) SCIPNP_TVB(256, 6, 4); else SCIPNP_TVB(256, 10, 4);
+        if (small) SCIPNP_TVB(256, 6, 4, 16); else SCIPNP_TVB(256, 10, 4, 32);
     }
 #undef SCIPNP_TVB
     return launch_status("tv_band_kernel");

@@ -248,13 +248,8 @@ static inline int ru32(int v) { return (v + 31) / 32 * 32; }
 template <int COB>
 static int launch_wgrad_split(const void* act, const void* dz, float* ws, int nslab, int ciP, int n, int Cin, int Cout,
                               int co0, int h, int w, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel<COB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<COB>::LDS_BYTES);
-        if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(wgrad_split): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;
+    if (int rc = attr.ensure((const void*)conv3x3_wgrad_split_kernel<COB>, WsCfg<COB>::LDS_BYTES, "wgrad_split")) return rc;
     hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<COB>), dim3(nslab, ciP / 32), dim3(WS_THREADS), WsCfg<COB>::LDS_BYTES, st,
                        (const char*)act, (const char*)dz, ws, n, Cin / 8, Cout / 8, co0 / 8, h, w);
     return launch_status("conv3x3_wgrad_split_kernel");

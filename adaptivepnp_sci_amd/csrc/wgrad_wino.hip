@@ -321,13 +321,8 @@ int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW
         const dim3 grid(nslab, ciP / 32);
 #define SCIPNP_WW(C)                                                                                                  \
     do {                                                                                                              \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel<C>,                             \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WwCfg<C>::LDS_BYTES); \
-            if (e != hipSuccess) return fail(SCIPNP_EHIP, "hipFuncSetAttribute(wgrad_wino): %s", hipGetErrorString(e)); \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        static LdsAttrOnce attr;                                                                                      \
+        if (int rc_ = attr.ensure((const void*)conv3x3_wgrad_wino_kernel<C>, WwCfg<C>::LDS_BYTES, "wgrad_wino")) return rc_; \
         hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<C>), grid, dim3(WwCfg<C>::THREADS), WwCfg<C>::LDS_BYTES, st, act_c8, \
                            dz_c8, workspace, n, Cin / 8, Cout / 8, co0 / 8, h, w);                                    \
     } while (0)

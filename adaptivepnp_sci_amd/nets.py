@@ -226,8 +226,10 @@ class FFDNetEngine:
         _lib.check(rc, 'scipnp_ffdnet_forward')
         return out_c8
 
-    def forward_c_entry_split(self, in_c8s=None, out_c8=None):
-        """The split-fp16 pass through its single C entry point scipnp_ffdnet_forward_c8s."""
+    def forward_c_entry_split(self, in_c8s=None, out_c8=None, side=None):
+        """The split-fp16 pass through its single C entry point scipnp_ffdnet_forward_c8s; side = (torch.cuda.Stream,
+        torch.cuda.Event, torch.cuda.Event): the caller's side stream and fork / join events for scipnp_ffdnet_forward_c8s_2s
+        (half of the frames on that stream; the library creates none of its own)."""
         if self.precision != 'f16x3' or self.in_ch != 13:
             raise _lib.ScipnpError('scipnp_ffdnet_forward_c8s needs the colour network and precision f16x3')
         in_c8s = self.in_c8s if in_c8s is None else in_c8s
@@ -235,6 +237,18 @@ class FFDNetEngine:
         lib = _lib.load()
         _lib.require_gpu()
         ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed_split])
+        if side is not None:
+            st, fork, join = side
+            for ev in (fork, join):                   # torch creates the hipEvent_t lazily, at the first record
+                if not ev.cuda_event:
+                    ev.record(st)
+            rc = lib.scipnp_ffdnet_forward_c8s_2s(C.c_void_p(in_c8s.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, self.nb,
+                                                  self.nc, C.c_void_p(self.scratch[0].data_ptr()),
+                                                  C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
+                                                  _lib.stream_ptr(), C.c_void_p(st.cuda_stream), C.c_void_p(fork.cuda_event),
+                                                  C.c_void_p(join.cuda_event))
+            _lib.check(rc, 'scipnp_ffdnet_forward_c8s_2s')
+            return out_c8
         rc = lib.scipnp_ffdnet_forward_c8s(C.c_void_p(in_c8s.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, self.nb,
                                            self.nc, C.c_void_p(self.scratch[0].data_ptr()),
                                            C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,

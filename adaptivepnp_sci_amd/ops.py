@@ -606,11 +606,38 @@ def on_side_streams(n_items, fn):
             cur.wait_stream(st)
 
 
-def split_overflow(reset=True):
-    """True if the split-fp16 kernels saw a value outside fp16's range since the last reset (synchronises)."""
+def split_overflow(reset=True, word=None):
+    """True if the split-fp16 kernels raised the range-guard word since it was last cleared (synchronises).  word: an int32
+    device tensor of one element (a solve's own word, see overflow_scope); None = the word the calling thread has bound, or
+    the library's process-wide one."""
     flag = C.c_int(0)
-    _call('scipnp_split_overflow', int(bool(reset)), C.byref(flag), _stream())
+    _call('scipnp_read_overflow_word', _p(word, 'word', torch.int32), int(bool(reset)), C.byref(flag), _stream())
     return bool(flag.value)
+
+
+_OVF_BOUND = threading.local()
+
+
+class overflow_scope:
+    """with overflow_scope(word): every split-fp16 launch of the calling thread raises `word` (an int32 device tensor of one
+    element owned by the solve / engine) instead of the process-wide word -- overlapping solves on different host threads
+    never see each other's report (include/scipnp.h, scipnp_bind_overflow_word).  Scopes nest; word=None is a no-op."""
+
+    def __init__(self, word):
+        self.word = word
+
+    def __enter__(self):
+        if self.word is not None:
+            self.prev = getattr(_OVF_BOUND, 'word', None)
+            _OVF_BOUND.word = self.word
+            _call('scipnp_bind_overflow_word', _p(self.word, 'word', torch.int32))
+        return self
+
+    def __exit__(self, *exc):
+        if self.word is not None:
+            _OVF_BOUND.word = self.prev
+            _call('scipnp_bind_overflow_word', _p(self.prev, 'word', torch.int32))
+        return False
 
 
 def c8s_to_float(x):

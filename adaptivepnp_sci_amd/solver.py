@@ -22,7 +22,6 @@ soon as that copy has landed (in iteration order; nothing waits for it inside th
 """
 import ctypes as C
 import os
-import threading
 
 import numpy as np
 import torch
@@ -60,28 +59,6 @@ def _as_lists(sigma, iter_max):
     if not isinstance(iter_max, list):
         iter_max = [iter_max] * len(sigma)
     return sigma, iter_max
-
-
-# Split-fp16 overflow flag (scipnp_split_overflow) is ONE device word: solves that overlap in time (two host threads /
-# HIP streams, harness.run_two_stage) must not clear each other's report.  The flag stays set until the last of the
-# overlapping solves has looked at it; a solve that ends while it is set raises -- possibly for a neighbour's overflow
-# (conservative), never the other way round.
-_ovf_lock = threading.Lock()
-_ovf_active = 0
-
-
-def _overflow_begin():
-    global _ovf_active
-    with _ovf_lock:
-        _ovf_active += 1
-
-
-def _overflow_end():
-    """-> True if the flag was set; resets it when no other solve is in flight"""
-    global _ovf_active
-    with _ovf_lock:
-        _ovf_active = max(0, _ovf_active - 1)
-        return ops.split_overflow(reset=(_ovf_active == 0))
 
 
 _OVERFLOW_MSG = ('denoiser activations left fp16 range in the split-fp16 convolution path; rerun with '
@@ -158,6 +135,9 @@ class AdmmRun:
         self.phi_events = None           # bench.py: list receiving (start,end) events around the projection launch
         self.noise_source = None         # finetune.NoisePrefetch set by _run_schedule (FastDVDnet finetune noise)
         self._sse_fixed = None
+        # range-guard word of THIS solve's split-fp16 launches (include/scipnp.h, scipnp_bind_overflow_word): bound around
+        # every step, read once at the end -- a neighbouring solve on another host thread / stream has its own
+        self.ovf_word = None
         # ---- prior workspaces
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
@@ -179,6 +159,8 @@ class AdmmRun:
                 from .fastdvd import FastDVDEngine
                 self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision)
                 self.rgb_w = torch.empty_like(self.x_rgb)
+            if self.eng.precision == 'f16x3':
+                self.ovf_word = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.dd = None
             if model_demosaic is not None:       # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
                 if not two_stage:
@@ -223,7 +205,8 @@ class AdmmRun:
             ops.pm_dual_update(self.theta_raw, self.x, self.theta, self.b, sign, self.orig if self.iqa else None,
                                part, which=which)
         else:
-            self._cnn_step(nsig, k, last)
+            with ops.overflow_scope(self.ovf_word):
+                self._cnn_step(nsig, k, last)
         if ITERATE_HOOK is not None:
             ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
         self.k += 1
@@ -293,9 +276,9 @@ class AdmmRun:
         self.dd.forward(self.dd_planes, self.dd_mosaic, self.x_rgb)
 
     def check_overflow(self):
-        """for callers that drive `step()` themselves (bench.py): raise if a split-fp16 conversion left fp16 range
-        since the flag was last cleared (the solver entry points do this at the end of their schedule)"""
-        if self.denoiser != 'tv' and self.eng.precision == 'f16x3' and ops.split_overflow():
+        """raise if a split-fp16 launch of THIS solve wrote a value outside fp16's range since its word was last cleared
+        (the solver entry points call this at the end of their schedule; bench.py after its timed steps)"""
+        if self.ovf_word is not None and ops.split_overflow(word=self.ovf_word):
             raise _lib.ScipnpError(_OVERFLOW_MSG)
 
     # ------------------------------------------------------------------ reporting
@@ -352,6 +335,7 @@ class GrayAdmmRun:
     interval_iter = 5
     noise_source = None
     phi_events = None
+    ovf_word = None
 
     def __init__(self, y, Phi, denoiser, x0=None, X_orig=None, model=None, show_iqa=True, _lambda=1, gamma=0.01,
                  Phi_sum=None, conv_precision=None):
@@ -401,6 +385,8 @@ class GrayAdmmRun:
             self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
             if self.eng.in_ch != 5:
                 raise ValueError('ffdnet_gray needs the grayscale network (5 -> nc -> 4 channels)')
+            if self.eng.precision == 'f16x3':
+                self.ovf_word = torch.zeros(1, dtype=torch.int32, device=self.device)
         else:
             if (H * W) % 16:
                 raise ValueError('tv_gray needs H*W to be a multiple of 16')
@@ -419,10 +405,11 @@ class GrayAdmmRun:
         B, M, N, H, W = self.B, self.M, self.N, self.H, self.W
         ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x)
         if self.unshuffled:
-            ops.gray_net_input(self.x, self.b, nsig, self.eng.in_c8)
-            if self.eng.in_c8s is not None:
-                ops.c8_to_c8s(self.eng.in_c8, out=self.eng.in_c8s)
-            ops.gray_net_output(self.eng.forward(), self.theta_raw)
+            with ops.overflow_scope(self.ovf_word):
+                ops.gray_net_input(self.x, self.b, nsig, self.eng.in_c8)
+                if self.eng.in_c8s is not None:
+                    ops.c8_to_c8s(self.eng.in_c8, out=self.eng.in_c8s)
+                ops.gray_net_output(self.eng.forward(), self.theta_raw)
         else:
             ops.tv_chambolle(self.x.view(B, H, W), self.b.view(B, H, W), -1.0, self.theta_raw.view(B, H, W), self.plan, 0.1)
         part = None
@@ -435,6 +422,7 @@ class GrayAdmmRun:
         self.k += 1
 
     psnr_all = AdmmRun.psnr_all
+    check_overflow = AdmmRun.check_overflow
 
     def result_cube(self):
         return self._cube(self.x)
@@ -571,8 +559,6 @@ def _run_schedule(run, sigma, iter_max, log=None):
             # now that the run exists, closed below whatever happens (unconsumed draws are given back to the global RNG)
             from .finetune import NoisePrefetch
             own_noise = run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
-    if split:
-        _overflow_begin()
     try:
         for idx, nsig in enumerate(sigma):
             for _ in range(iter_max[idx]):
@@ -586,9 +572,8 @@ def _run_schedule(run, sigma, iter_max, log=None):
         if own_noise is not None:
             own_noise.close()
             run.noise_source = None
-        overflow = _overflow_end() if split else False
-    if overflow:
-        raise _lib.ScipnpError(_OVERFLOW_MSG)
+    if split:
+        run.check_overflow()
 
 
 def _check_demosaic(denoiser, demosaic_method, model_demosaic=None):

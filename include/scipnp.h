@@ -217,9 +217,18 @@ int scipnp_pack_conv3x3_split_bn(const float* w, const float* bias, const float*
                                  int Cin_real, int Cout_real, int Cin, int Cout, void* packed);
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout,
                        int h, int w, int flags, scipnp_stream_t s);
-/* range guard of the split format: *flag_out = 1 if any value written to a c8s tensor by these kernels since the last
- * reset was >= 65000 in magnitude or NaN (results invalid: rerun with the fp32 kernels).  SYNCHRONISES the stream;
- * call once per reconstruction. */
+/* Range guard of the split format.  A kernel that writes a c8s tensor (or packs split weights on the device) raises a
+ * 4-byte DEVICE word when a value is >= 65000 in magnitude or NaN (|w| >= 31.9 for weights): results are then invalid,
+ * rerun with the fp32 kernels.  WHICH word is part of the call, not of the library: every launch passes the word the
+ * calling thread bound with scipnp_bind_overflow_word -- a device int the caller owns and zeroes, one per solve / engine
+ * (scipnp_twostage_ffdnet_args.overflow_word names it per call) -- so solves that overlap in time on different host
+ * threads never see each other's report.  Threads that never bind one share the library's process-wide word.
+ *   scipnp_bind_overflow_word(w): w for this thread's following launches (NULL: back to the process-wide word).
+ *   scipnp_read_overflow_word(w, reset, flag_out, s): *flag_out = the word (w == NULL: the one this thread has bound /
+ *     the process-wide one), zeroed afterwards if reset; SYNCHRONISES the stream -- call once per reconstruction.
+ *   scipnp_split_overflow(reset, flag_out, s) = scipnp_read_overflow_word(NULL, ...). */
+int scipnp_bind_overflow_word(int* dev_word);
+int scipnp_read_overflow_word(const int* dev_word, int reset, int* flag_out, scipnp_stream_t s);
 int scipnp_split_overflow(int reset, int* flag_out, scipnp_stream_t s);
 /* fp32 c8 -> c8s; _add adds a c8s residual first (skip connections behind a PixelShuffle conv) */
 int scipnp_c8_to_c8s(const float* in_c8, void* out_c8s, int n, int C, int h, int w, scipnp_stream_t s);
@@ -274,9 +283,15 @@ int scipnp_ffdnet_forward(const float* in_c8, float* out_c8, const float* const*
                           float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
 /* the same on the split-fp16 kernels (the default precision): in_c8s [B][2][2][M*N][8] fp16 from
  * scipnp_pm_pre_denoise_ex, fp32 c8 output, packed_split from scipnp_pack_conv3x3_split(_device), two c8s scratch
- * buffers of B*nc*M*N*4 bytes each.  With SCIPNP_STREAMS >= 2 in the environment (the default is 2) and B >= 2 the second
- * half of the frames runs on a side stream owned by the calling thread, forked from and joined to `s` by events inside
- * the call (identical results; hipGraph capture on `s` records both branches). */
+ * buffers of B*nc*M*N*4 bytes each; everything on `s`.
+ * _2s: with side_stream != NULL (and B >= 2) the second half of the frames runs on the CALLER's side stream, forked from
+ * and joined to `s` inside the call through the caller's two events (hipEvent_t, passed as void*; created with
+ * hipEventDisableTiming) -- identical results, the other stream's launches fill the CUs a grid's last generation of
+ * workgroups leaves idle; hipGraph capture on `s` records both branches.  The library itself creates no stream or event
+ * and reads no environment variable here. */
+int scipnp_ffdnet_forward_c8s_2s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
+                                 void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s,
+                                 scipnp_stream_t side_stream, void* fork_event, void* join_event);
 int scipnp_ffdnet_forward_c8s(const void* in_c8s, float* out_c8, const void* const* packed_split, int nb, int nc,
                               void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s);
 
@@ -404,12 +419,16 @@ int scipnp_frame_metrics(const float* ref_state, const float* img_state, double*
  * Whole ADMM iterations as single calls: the launch sequences of the solver loop for hosts that run it natively
  * (the Python stepper issues the same launches one by one).  All pointers are device pointers in the plane-major
  * layouts above; nothing is allocated or synchronised.
+ * ABI guard: the first member of either argument block is `struct_size`, which the caller sets to sizeof(the struct it was
+ * compiled against) (memset the block to 0 first); a block of any other size is refused with SCIPNP_EINVAL instead of
+ * being misread (the blocks changed layout between library versions 0.1 and 0.2).
  * ------------------------------------------------------------------------------------------------------------- */
 
 /* two-stage ADMM + FFDNet-colour, Malvar demosaic (dvp...:121-271, one pass of the loop body):
  *   x = project(theta, b);  x_rgb = malvar(mosaic(x + b/rho));  out = FFDNet(x_rgb - w/tau, sigma);
  *   theta = clip(CFA(out));  b += x - theta;  w += x_rgb - out;  optional squared-error partials vs orig. */
 typedef struct {
+    size_t struct_size;                 /* = sizeof(scipnp_twostage_ffdnet_args) */
     int M, N, B;                        /* quarter-resolution plane size (H/2, W/2), frames */
     float *theta, *b, *x;               /* state [B][4][M][N]; theta holds the start point at the first iteration */
     const float *Phi, *y, *Phisum;      /* [B][4][M][N], [4][M][N], [4][M][N] (scipnp_pm_setup) */
@@ -433,6 +452,10 @@ typedef struct {
      * may then be NULL */
     const float* const* packed_wino;    /* nb layers packed by scipnp_pack_conv3x3_wino */
     float* net_in_c8;                   /* FFDNet input [B][2][M][N][8] fp32 */
+    /* split-fp16 path only (NULL / zero: the thread's bound word; everything on one stream) */
+    int* overflow_word;                 /* range-guard word of THIS solve (device int, zeroed by the caller) */
+    scipnp_stream_t side_stream;        /* the caller's second stream for half of the frames of the network pass ... */
+    void *side_fork_event, *side_join_event;   /* ... and its two hipEvent_t (as scipnp_ffdnet_forward_c8s_2s) */
 } scipnp_twostage_ffdnet_args;
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
 
@@ -446,6 +469,7 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
  * sse_part must hold the partials of scipnp_pm_dual_update's grid (size query: scipnp_sse_partials); all of them are
  * written (the fused kernel zero-fills the entries it does not use), *nblocks receives their number. */
 typedef struct {
+    size_t struct_size;                 /* = sizeof(scipnp_admm_tv_args) */
     int M, N, B, two_stage;
     float *theta, *b, *x, *theta_raw;   /* state [B][4][M][N]; theta_raw: scratch for the unclipped TV output */
     const float *Phi, *y, *Phisum;

@@ -26,8 +26,76 @@ def _build(src, exe):
     gcc = shutil.which('gcc') or 'gcc'
     libdir = os.path.join(ROOT, 'adaptivepnp_sci_amd')
     subprocess.run([gcc, '-std=c11', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I', os.path.join(ROOT, 'include'), src,
-                    '-L', libdir, '-lscipnp', '-L/opt/rocm/lib', '-lamdhip64', '-lm', f'-Wl,-rpath,{libdir}',
+                    '-L', libdir, '-lscipnp', '-L/opt/rocm/lib', '-lamdhip64', '-lm', '-lpthread', f'-Wl,-rpath,{libdir}',
                     '-Wl,-rpath,/opt/rocm/lib', '-o', exe], check=True, timeout=300)
+
+
+def _write_problem(path, H, W, B, tv_iters, iters, sigma, seed):
+    import numpy as np
+    from adaptivepnp_sci_amd import synth
+    y, Phi, _orig = synth.make_problem(H, W, B, seed=seed)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'ffdnet_color_weights.npz'))
+    with open(path, 'wb') as f:
+        np.array([H, W, B, 12, tv_iters, iters], np.int32).tofile(f)
+        np.array([sigma], np.float32).tofile(f)
+        y.astype(np.float32).tofile(f)
+        np.ascontiguousarray(Phi, np.float32).tofile(f)
+        for l in range(12):
+            w, b = g[f'model.{2 * l}.weight'], g[f'model.{2 * l}.bias']
+            np.array([w.shape[0], w.shape[1]], np.int32).tofile(f)
+            np.ascontiguousarray(w, np.float32).tofile(f)
+            np.ascontiguousarray(b, np.float32).tofile(f)
+    return y, Phi, g
+
+
+@pytest.mark.gpu
+def test_two_concurrent_c_solves_own_their_streams_and_overflow_words(tmp_path):
+    """examples/host_c/two_solves_host.c: two host threads reconstruct at the same time through the iteration-level ABI, each
+    with its own stream, side stream + events (scipnp_twostage_ffdnet_args.side_*: the library creates none) and range-guard
+    word.  Solve B is driven out of fp16 range: its word is set, solve A's and the process-wide word are not (the program's
+    exit code), and solve A's mosaic is bit-identical to the same solve run alone on one stream."""
+    import numpy as np
+    H, W, B = 96, 128, 8
+    blob = str(tmp_path / 'problem.bin')
+    _write_problem(blob, H, W, B, 6, 3, np.float32(25 / 255), seed=21)
+    one, two = str(tmp_path / 'pnp_host'), str(tmp_path / 'two_host')
+    _build(os.path.join(ROOT, 'examples', 'host_c', 'pnp_admm_ffdnet_host.c'), one)
+    _build(os.path.join(ROOT, 'examples', 'host_c', 'two_solves_host.c'), two)
+    alone, alone2s = str(tmp_path / 'alone.bin'), str(tmp_path / 'alone2s.bin')
+    r = subprocess.run([one, blob, alone], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([one, blob, alone2s, '2s'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'two streams' in r.stdout, r.stdout + r.stderr
+    ref = np.fromfile(alone, np.float32)
+    assert np.array_equal(np.fromfile(alone2s, np.float32), ref)          # the caller's side stream changes no bit
+    out_a, out_b = str(tmp_path / 'a.bin'), str(tmp_path / 'b.bin')
+    r = subprocess.run([two, blob, out_a, out_b], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'solve A overflow 0, solve B overflow 1, process-wide word 0' in r.stdout
+    assert np.array_equal(np.fromfile(out_a, np.float32), ref)
+
+
+def test_iterate_entries_refuse_a_block_of_another_size():
+    """scipnp_*_iterate check struct_size (the blocks changed layout between library versions): a host compiled against
+    another header gets SCIPNP_EINVAL and a message instead of misread fields"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    tv = _lib.AdmmTvArgs()
+    assert tv.struct_size == C.sizeof(_lib.AdmmTvArgs)
+    tv.struct_size -= 8
+    assert lib.scipnp_admm_tv_iterate(C.byref(tv), None, None) == -1
+    assert 'struct_size' in lib.scipnp_last_error().decode()
+    a = _lib.TwoStageFfdnetArgs()
+    assert a.struct_size == C.sizeof(_lib.TwoStageFfdnetArgs)
+    a.struct_size = 0
+    assert lib.scipnp_twostage_ffdnet_iterate(C.byref(a), None, None) == -1
+    assert 'struct_size' in lib.scipnp_last_error().decode()
+    # a side stream without the caller's two events is refused before anything is launched
+    p = C.c_void_p(256)
+    ptrs = (C.c_void_p * 12)(*[256] * 12)
+    assert lib.scipnp_ffdnet_forward_c8s_2s(p, p, ptrs, 12, 96, p, p, 8, 16, 16, None, C.c_void_p(512), None, None) == -1
+    assert 'events' in lib.scipnp_last_error().decode()
 
 
 @pytest.mark.gpu

@@ -634,6 +634,49 @@ def test_split_overflow_guard(ops):
     assert ops.split_overflow() and not ops.split_overflow()       # reported once, then reset
 
 
+def test_split_overflow_words_are_per_solve(ops):
+    """the range guard raises the word the CALLING THREAD bound (scipnp_bind_overflow_word), not one process-wide flag:
+    two solves that overlap in time -- here two host threads on two streams -- never see each other's report"""
+    import threading
+    wt = torch.zeros(8, 8, 3, 3)
+    wt[:, :, 1, 1] = 30.0
+    packed = ops.pack_conv3x3_split(wt, None, Cin=8, Cout=8, device='cuda')
+    ops.split_overflow()                                           # clear the process-wide word
+    words = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(2)]
+    torch.cuda.synchronize()
+    seen, errs = [None, None], []
+    barrier = threading.Barrier(2)
+
+    def solve(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), ops.overflow_scope(words[i]):
+                barrier.wait()                                     # both scopes are open at the same time
+                x = torch.zeros(1, 8, 8, 32, device='cuda') + (400.0 if i == 1 else 1.0)    # thread 1 overflows
+                for _ in range(4):
+                    ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(x)), packed, 8)
+                barrier.wait()
+                seen[i] = ops.split_overflow(word=words[i])
+        except Exception as e:                                     # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=solve, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert seen == [False, True]
+    assert not ops.split_overflow()                                # the process-wide word was never touched
+    # scopes nest and restore: after the inner scope the outer word is bound again
+    with ops.overflow_scope(words[0]):
+        with ops.overflow_scope(words[1]):
+            pass
+        ops.conv3x3_c8s(ops.c8_to_c8s(ops.to_c8(torch.zeros(1, 8, 8, 32, device='cuda') + 400.0)), packed, 8)
+    assert ops.split_overflow(word=words[0]) and not ops.split_overflow(word=words[1]) and not ops.split_overflow()
+
+
 def test_conv3x3_split_stride2_shuffle_bn(ops):
     g = torch.Generator().manual_seed(17)
     x = torch.randn(2, 32, 12, 36, generator=g)
@@ -858,15 +901,17 @@ def test_ffdnet_single_call_c_entries_equal_the_layerwise_path(ffdnet_state_dict
             b = eng.forward_c_entry().clone()
         assert torch.equal(a, b), prec
         if prec == 'f16x3':
-            # the C entry forks a side stream for half of the frames and joins it before returning (SCIPNP_STREAMS): legal
-            # under stream capture, as include/scipnp.h promises -- capture the call in a hipGraph and replay it
+            # scipnp_ffdnet_forward_c8s_2s: half of the frames on the CALLER's side stream, forked from and joined to the
+            # calling stream through the caller's two events inside the call (the library creates neither) -- bit-identical,
+            # and legal under stream capture as include/scipnp.h promises: capture the call in a hipGraph and replay it
+            side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            assert torch.equal(eng.forward_c_entry_split(side=side), a), 'two-stream C entry'
             st = torch.cuda.Stream()
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                eng.forward_c_entry_split()                       # (side stream and events exist before the capture)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=st):
-                    out = eng.forward_c_entry_split()
+                    out = eng.forward_c_entry_split(side=side)
                 out.zero_()
                 graph.replay()
             torch.cuda.current_stream().wait_stream(st)
