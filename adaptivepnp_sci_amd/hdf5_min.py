@@ -16,6 +16,9 @@ import numpy as np
 
 SIG = b'\x89HDF\r\n\x1a\n'
 UNDEF = 0xFFFFFFFFFFFFFFFF
+MAX_DEPTH = 64                      # B-tree levels; a real file has 1-3
+# what a damaged file can trip inside the decoder; read_mat73 re-raises all of it as Hdf5Unsupported
+_DAMAGE = (struct.error, IndexError, ValueError, TypeError, OverflowError, MemoryError, zlib.error, RecursionError)
 
 
 class Hdf5Unsupported(RuntimeError):
@@ -44,13 +47,18 @@ class _File:
         self.base = off if base_addr in (0, UNDEF) else base_addr
         self.root = self._symbol_entry(p + 32)
 
-    # ---- primitives
+    # ---- primitives (every address is bounds-checked: a truncated or corrupt file raises Hdf5Unsupported, nothing else)
     def at(self, addr, n):
         a = self.base + addr
+        if addr < 0 or n < 0 or a + n > len(self.buf):
+            raise Hdf5Unsupported(f'address {addr:#x} + {n} lies outside the file (truncated or corrupt)')
         return self.buf[a:a + n]
 
     def u(self, addr, fmt):
-        return struct.unpack_from('<' + fmt, self.buf, self.base + addr)
+        a = self.base + addr
+        if addr < 0 or a + struct.calcsize('<' + fmt) > len(self.buf):
+            raise Hdf5Unsupported(f'address {addr:#x} lies outside the file (truncated or corrupt)')
+        return struct.unpack_from('<' + fmt, self.buf, a)
 
     def _symbol_entry(self, abs_pos):
         name_off, hdr, cache = struct.unpack_from('<QQI', self.buf, abs_pos)
@@ -66,7 +74,7 @@ class _File:
         ver, _r, nmsg, _rc, size = self.u(addr, 'BBHII')
         if ver != 1:
             raise Hdf5Unsupported(f'object header version {ver}')
-        out, blocks = [], [(addr + 16, size)]
+        out, blocks, seen = [], [(addr + 16, size)], {addr + 16}
         while blocks and len(out) < nmsg:
             pos, left = blocks.pop(0)
             end = pos + left
@@ -75,6 +83,9 @@ class _File:
                 body = pos + 8
                 if mtype == 0x10:                                     # continuation
                     caddr, clen = self.u(body, 'QQ')
+                    if caddr in seen:
+                        raise Hdf5Unsupported('cyclic object-header continuation')
+                    seen.add(caddr)
                     blocks.append((caddr, clen))
                 out.append((mtype, body, msize, flags))
                 pos = body + msize
@@ -86,9 +97,16 @@ class _File:
             raise Hdf5Unsupported('bad local heap')
         data_addr, = self.u(heap + 24, 'Q')
         a = self.base + data_addr + off
-        return self.buf[a:self.buf.index(b'\x00', a)].decode('ascii', 'replace')
+        end = self.buf.find(b'\x00', a) if 0 <= a < len(self.buf) else -1
+        if end < 0:
+            raise Hdf5Unsupported('unterminated name in the local heap (truncated or corrupt)')
+        return self.buf[a:end].decode('ascii', 'replace')
 
-    def _group_nodes(self, btree):
+    def _group_nodes(self, btree, seen=None, depth=0):
+        seen = set() if seen is None else seen
+        if btree in seen or depth > MAX_DEPTH:
+            raise Hdf5Unsupported('cyclic or too deep group B-tree')
+        seen.add(btree)
         if self.at(btree, 4) != b'TREE':
             raise Hdf5Unsupported('bad group B-tree node')
         ntype, level, used = self.u(btree + 4, 'BBH')
@@ -98,7 +116,7 @@ class _File:
         for i in range(used):
             child, = self.u(pos + 8 + i * 16, 'Q')              # key(8) child(8) key child ... key
             if level > 0:
-                yield from self._group_nodes(child)
+                yield from self._group_nodes(child, seen, depth + 1)
             else:
                 yield child
 
@@ -138,6 +156,8 @@ class _File:
                 cls = cv & 15
                 if b0 & 1:
                     raise Hdf5Unsupported('big-endian datatype')
+                if size not in (1, 2, 4, 8) or (cls == 1 and size == 1):
+                    raise Hdf5Unsupported(f'datatype of {size} bytes')
                 if cls == 0:
                     dtype = np.dtype(('<i' if b0 & 8 else '<u') + str(size))
                 elif cls == 1:
@@ -177,7 +197,11 @@ class _File:
                     filters.append((fid, cvs))
         if shape is None or dtype is None or layout is None:
             raise Hdf5Unsupported('not a simple dataset')
-        n = int(np.prod(shape)) if shape else 1
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n * dtype.itemsize > max(1 << 30, 1000 * len(self.buf)):
+            raise Hdf5Unsupported(f'dataset of {n} elements in a file of {len(self.buf)} bytes (corrupt dataspace?)')
         if layout[0] == 'compact':
             raw = bytes(self.at(layout[1], layout[2]))
             return np.frombuffer(raw, dtype, n).reshape(shape).copy()
@@ -208,7 +232,11 @@ class _File:
                 out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
         return out
 
-    def _chunks(self, node, rank):
+    def _chunks(self, node, rank, seen=None, depth=0):
+        seen = set() if seen is None else seen
+        if node in seen or depth > MAX_DEPTH:
+            raise Hdf5Unsupported('cyclic or too deep chunk B-tree')
+        seen.add(node)
         if self.at(node, 4) != b'TREE':
             raise Hdf5Unsupported('bad chunk B-tree node')
         ntype, level, used = self.u(node + 4, 'BBH')
@@ -222,7 +250,7 @@ class _File:
             offs = self.u(k + 8, f'{rank}Q')
             child, = self.u(k + ksz, 'Q')
             if level > 0:
-                yield from self._chunks(child, rank)
+                yield from self._chunks(child, rank, seen, depth + 1)
             else:
                 yield offs, fmask, child, csize
 
@@ -231,13 +259,21 @@ def read_mat73(path, names=None):
     """{variable: ndarray (axes as stored = reversed MATLAB order)} of the numeric root-level variables of a v7.3 MAT-file;
     `names`: only these (missing ones are skipped).  Non-numeric variables (cells, structs, chars: groups / references) are
     skipped."""
-    f = _File(path)
+    try:
+        f = _File(path)
+        members = f.members()
+    except _DAMAGE as e:
+        raise Hdf5Unsupported(f'{path}: truncated or corrupt HDF5 structure ({type(e).__name__}: {e})') from e
     out = {}
-    for name, addr in f.members().items():
+    for name, addr in members.items():
         if name.startswith('#') or (names is not None and name not in names):
             continue
         try:
             out[name] = f.dataset(addr)
+        except _DAMAGE as e:
+            # whatever a damaged file trips over inside the decoder surfaces as the one documented exception
+            if names is not None:
+                raise Hdf5Unsupported(f'{path}: variable {name}: truncated or corrupt ({type(e).__name__}: {e})') from e
         except Hdf5Unsupported:
             if names is not None:
                 raise

@@ -97,6 +97,42 @@ def test_v73_scene_files(name):
     assert np.array_equal(d['u8_var'].T, np.arange(20, dtype=np.uint8).reshape(4, 5))
 
 
+def test_v73_reader_fails_only_with_its_own_exception_on_damaged_files(tmp_path):
+    """truncated files and files with corrupted structure bytes (object headers, B-tree nodes, heap, chunk addresses): the
+    reader raises Hdf5Unsupported -- which load_scene turns into its 'install h5py or convert' error -- and never a raw
+    struct / index / zlib error, unbounded recursion or a hang (cyclic B-tree or continuation addresses)"""
+    import glob
+    from conftest import GOLD
+    from adaptivepnp_sci_amd.hdf5_min import Hdf5Unsupported, read_mat73
+    rng = np.random.default_rng(0)
+    files = sorted(glob.glob(os.path.join(GOLD, 'scene_v73*.mat')))
+    assert files
+    n_bad = 0
+    for src in files:
+        raw = open(src, 'rb').read()
+        want = read_mat73(src)
+        cases = [raw[:n] for n in (600, 1500, len(raw) // 2, len(raw) - 40)]
+        for _ in range(60):                                        # overwrite 8 bytes of structure with a random address
+            b = bytearray(raw)
+            pos = int(rng.integers(512, len(raw) - 8))
+            b[pos:pos + 8] = int(rng.integers(0, 2 * len(raw))).to_bytes(8, 'little')
+            cases.append(bytes(b))
+        for i, blob in enumerate(cases):
+            path = tmp_path / f'damaged_{i}.mat'
+            path.write_bytes(blob)
+            try:
+                got = read_mat73(str(path), names=list(want))
+            except Hdf5Unsupported:
+                n_bad += 1
+                continue
+            assert set(got) <= set(want)                           # damage that missed the structure: still a clean load
+    assert n_bad >= 8
+    with pytest.raises(RuntimeError, match='h5py'):                # the harness's own message for such a file
+        trunc = tmp_path / 'truncated_bayer.mat'
+        trunc.write_bytes(open(files[0], 'rb').read()[:1500])
+        harness.load_scene(str(trunc))
+
+
 @pytest.mark.gpu
 def test_drivers_match_the_oracle_with_model_carry_over(tmp_path, ffdnet_state_dict):
     """TV warm start + two-stage FFDNet with online finetune on a 2-measurement scene: the finetuned model of
