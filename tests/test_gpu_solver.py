@@ -2,6 +2,7 @@
 captured from the reference itself (tests/golden/, tools/make_golden.py).  Bars (BASELINE.json
 north_star): <= 1e-5 relative L2 per iterate, <= 1e-4 dB PSNR."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,9 @@ import torch
 from conftest import load_gold, rel_l2
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# fastdvdnet finetune gradient gate: multiples of the reference's own fp32-vs-fp64 spread (see the test)
+GRAD_GATE = {'f32': 1.5, 'f16x3': 1.5}
 
 REL_TOL = 1e-5      # per-iterate relative L2 (north_star)
 PSNR_TOL = 1e-4     # dB
@@ -259,30 +263,55 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
         assert rel_l2(tr.it[k], gf['theta'][k]) <= REL_TOL, (k, rel_l2(tr.it[k], gf['theta'][k]))
     assert rel_l2(res[0], gf['rgb']) <= REL_TOL
     assert len(losses) == 2 and np.allclose(losses, gf['losses'][:2], rtol=1e-5), (losses, gf['losses'])
-    # gradients of the first backward pass against the reference's .grad (tools/make_golden.py g_fastdvd): BatchNorm
-    # affine gradients and one tensor per layer type in full, every tensor by its norm.  Tolerance: in fp32 this gradient
-    # is only determined to ~1e-4 -- the reference network evaluated in float32 and in float64 on the same input differs
-    # by 0.4 - 1.5e-4 on most layers (ReLU masks flip where an activation is within round-off of zero;
-    # tools/probes/fastdvd_grad_conditioning.py) -- so two fp32 implementations cannot be asked to agree to 1e-4 here
-    # (the FFDNet gradients above do: <= 1e-4)
+    # Gradients of the first backward pass.  The yardstick is the FLOAT64 gradient of the same step on the same inputs
+    # (tools/make_golden.py g_fastdvd, oracle/denoisers.py GRAD64_SINK): the reference's own fp32 .grad deviates from it by
+    # `grad64err` per tensor (1 - 3e-7 relative on this problem) -- that spread is what fp32 arithmetic leaves undetermined,
+    # and the HIP gradient must sit inside a small multiple of it: || g_HIP - g_fp64 || <= GRAD_GATE * || g_ref_fp32 - g_fp64 ||
+    # for every tensor kept in full (BatchNorm affine parameters and one weight tensor per layer type of both DenBlocks),
+    # plus the norm of every tensor against the fp64 norm within the same multiple.
     assert len(grads) == 1
-    n_full = 0
+    gate = GRAD_GATE[precision]
+    n_full, worst, report, norm_bad = 0, 0.0, [], []
     for k0, got in grads[0].items():
         key = k0.replace('.', '_')
-        nref = float(gf['gradnorm_' + key])
-        assert abs(float(np.linalg.norm(got.astype(np.float64))) - nref) <= 5e-4 * nref + 1e-12, (k0, nref)
-        if 'grad_' + key in gf.files:
+        spread, n64 = float(gf['grad64err_' + key]), float(gf['grad64norm_' + key])
+        dn = abs(float(np.linalg.norm(got.astype(np.float64))) - n64)
+        norm_bad += [(k0, dn / max(spread, 1e-300))] if dn > gate * spread + 1e-30 else []
+        if 'grad64_' + key in gf.files:
             n_full += 1
-            assert rel_l2(got, gf['grad_' + key]) <= 1e-3, (k0, rel_l2(got, gf['grad_' + key]))
+            err = float(np.linalg.norm(got.astype(np.float64) - gf['grad64_' + key].astype(np.float64)))
+            report.append((err / max(spread, 1e-300), err / max(n64, 1e-300), spread / max(n64, 1e-300), k0))
+            worst = max(worst, err / max(spread, 1e-300))
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', f'fastdvd_grad_parity_{precision}.txt'), 'w') as f:
+        f.write('# ||g_HIP - g_fp64|| / ||g_ref_fp32 - g_fp64||   rel(g_HIP, g_fp64)   rel(g_ref_fp32, g_fp64)   tensor\n')
+        for r in sorted(report, reverse=True):
+            f.write('%8.3f  %.3e  %.3e  %s\n' % r)
     assert n_full >= 2 * (8 + 26), n_full
+    assert worst <= gate, (worst, sorted(report, reverse=True)[:3])
+    assert not norm_bad, norm_bad[:5]
+    # The Adam updates themselves, element by element: after two steps delta = -lr * (m1_hat / (sqrt(v1_hat) + eps) + ...)
+    # is ~ -2 lr sign(g) wherever |g| is far above Adam's eps = 1e-8 and the two steps' gradients agree in sign; there the
+    # update is determined to fp32 round-off of the weight itself.  Elements whose reference gradient is below 1e3 * eps are
+    # on Adam's round-off floor (the step size depends on the last bits of g) and are left out -- and counted.
     sd = net.state_dict()
+    n_cmp = n_floor = 0
     for k0 in sd0:
+        key = k0.replace('module.', '', 1).replace('.', '_')
+        if 'delta_' + key in gf.files:
+            got_d = (sd[k0].float() - sd0[k0].float()).numpy()
+            ref_d, ref_g = gf['delta_' + key], gf['grad_' + key]
+            live = np.abs(ref_g) > 1e-5
+            n_cmp, n_floor = n_cmp + int(live.sum()), n_floor + int((~live).sum())
+            ulp = np.spacing(np.abs(sd0[k0].float().numpy()).astype(np.float32))
+            assert np.all(np.abs(got_d - ref_d)[live] <= 2 * ulp[live] + 2e-9), (k0, float(np.abs(got_d - ref_d)[live].max()))
         if sd0[k0].dim() == 4:
             dn = float(torch.norm(sd[k0].float() - sd0[k0].float()))
             ref = float(gf[k0.replace('.', '_') + '_dnorm'])
-            assert abs(dn - ref) <= 0.05 * ref, (k0, dn, ref)          # Adam steps ~ lr*sign(g): norms of the updates agree
+            assert abs(dn - ref) <= 0.05 * ref, (k0, dn, ref)          # every conv tensor: norms of the updates agree
         if k0.endswith('running_mean') or k0.endswith('running_var'):
             assert torch.equal(sd[k0], sd0[k0])                        # BatchNorm statistics stay frozen
+    assert n_cmp > 100000 and n_floor < 0.5 * n_cmp, (n_cmp, n_floor)
 
 
 def test_closed_form_demosaic_branch(solver, ffdnet_state_dict):

@@ -453,10 +453,14 @@ def g_fastdvd():
     noise = np.random.normal(0, 5 / 255, (8, 3, 64, 64))   # the draw the reference made (first use of the RNG)
     np.random.set_state(st)
     trace = []
-    with GradCapture() as ogc:
-        o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
-                              lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=2, update_times=1,
-                              finetune_trace=trace)
+    OD.GRAD64_SINK = g64 = {}                  # float64 gradients of the same first step (oracle/denoisers.py)
+    try:
+        with GradCapture() as ogc:
+            o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [4], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                                  lr=2e-6, inital_iter=1, interval_iter=2, update=True, update_per_iter=2, update_times=1,
+                                  finetune_trace=trace)
+    finally:
+        OD.GRAD64_SINK = None
     check('FastDVDnet finetune iterates', np.stack(o['theta_iterates']), ref_it)
     for k, v in ogc.named(onet).items():
         check(f'first-step gradient {k}', v, ref_grads[k])
@@ -465,17 +469,31 @@ def g_fastdvd():
     full = ('inc.convblock.0.weight', 'inc.convblock.3.weight', 'downc0.convblock.0.weight', 'downc0.convblock.3.convblock.0.weight',
             'downc1.convblock.0.weight', 'upc1.convblock.1.weight', 'outc.convblock.0.weight', 'outc.convblock.3.weight')
     grads = {}
+    assert set(g64) == set(ref_grads), (len(g64), len(ref_grads))
+    spread = []
     for k, v in ref_grads.items():
         key = k.replace('module.', '', 1)
         grads['gradnorm_' + key.replace('.', '_')] = float(torch.linalg.vector_norm(v.double()))
+        # the fp32-vs-fp64 spread of the REFERENCE's own gradient: || g_ref_fp32 - g_fp64 ||, and || g_fp64 ||, per tensor
+        grads['grad64err_' + key.replace('.', '_')] = float(torch.linalg.vector_norm(v.double() - g64[k]))
+        grads['grad64norm_' + key.replace('.', '_')] = float(torch.linalg.vector_norm(g64[k]))
+        spread.append(grads['grad64err_' + key.replace('.', '_')] / max(grads['grad64norm_' + key.replace('.', '_')], 1e-300))
         if v.dim() == 1 or any(key.endswith(f) for f in full):
             grads['grad_' + key.replace('.', '_')] = v.numpy()
+            grads['grad64_' + key.replace('.', '_')] = g64[k].numpy().astype(np.float32)   # (6e-8 rounding << the 1e-4 spread)
+    print(f'   reference fp32 gradient vs float64: rel-L2 per tensor min {min(spread):.2e} median {np.median(spread):.2e} '
+          f'max {max(spread):.2e}')
     rsd, osd = res[5].state_dict(), o['model'].state_dict()
     worst = max(rel(osd[k], rsd[k]) for k in rsd)
     print(f'   finetuned weights worst rel-L2 {worst:.3e}; losses {trace}')
     assert worst == 0.0
     dn = {k.replace('.', '_') + '_dnorm': float(torch.norm(rsd[k].float() - sd[k.replace('module.', '', 1)].float()))
           for k in rsd if k.endswith('weight') and rsd[k].dim() == 4}
+    # the Adam updates themselves (final - initial weights) of the tensors kept in full above
+    for k in rsd:
+        key = k.replace('module.', '', 1)
+        if key in sd and 'grad_' + key.replace('.', '_') in grads:
+            dn['delta_' + key.replace('.', '_')] = (rsd[k].float() - sd[key].float()).numpy()
     save('fastdvd_finetune_64x64x8', theta=ref_it, rgb=res[0], noise=noise.astype(np.float64),
          losses=np.array(trace), **dn, **grads)
 
