@@ -100,12 +100,19 @@ SIGNATURES = {
                                         _vp, _sz]),
     'scipnp_bench_mfma': (_int, [_vp, _int, _int, _int, _vp]),
     'scipnp_bench_mfma_valu': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_dep': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_bank': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
+    'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8w_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_negate': (_int, [_vp, _vp, _sz, _vp]),
     'scipnp_fastdvd_noisy_input': (_int, [_vp, _vp, _vp, _sz, _vp]),

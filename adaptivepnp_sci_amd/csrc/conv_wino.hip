@@ -23,9 +23,9 @@
 // group, double-buffered in LDS:
 //   raw input halo tile ((rows + 2) x 34 pixels x 8 channels) -> four channel-pair planes [q][rows + 2][34][2], global ->
 //     registers -> ds_write_b64; a lane reads a patch row (4 pixels x 2 channels, 32 contiguous bytes) as two ds_read_b128;
-//   U slab (16 positions x 32 co x 8 ci = 16 KiB, laid out [p][lane][co half h][k-step j] by the packer: one conflict-free
-//     ds_read_b128 per lane and position feeds the four MFMAs of that position) by LDS-DMA (buffer_load_dwordx4 ... lds),
-//     no staging registers.
+//   U slab (16 positions x 32 co x 8 ci = 16 KiB, laid out [xi][co half h][k-step j][lane][nu] by the packer: one conflict-free
+//     ds_read_b128 per lane feeds four MFMAs on the four accumulators (xi, nu = 0..3) of one half and k-step) by LDS-DMA
+//     (buffer_load_dwordx4 ... lds), no staging registers.
 #include "common.hpp"
 
 namespace scipnp {
@@ -33,6 +33,19 @@ namespace scipnp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// a - b on a float2 as ONE v_pk_add_f32 with a negated operand: the compiler selects a float2 subtraction as two v_sub_f32
+// (it turns a + (-b) back into a subtraction first), and every vector instruction beside v_mfma_f32_16x16x4_f32 is matrix
+// time lost (tools/probes/mfma_valu_coissue.py).  Same IEEE result.
+__device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a - b;
+#endif
+}
 
 constexpr int WN_STAMP_WORDS = 80;                    // per workgroup, diagnostic instantiation only
 constexpr int WN_SLAB = 16 * 32 * 8;                  // 4096 floats = 16 KiB: U of one (channel group, co block)
@@ -181,7 +194,7 @@ conv3x3_c8w_kernel(const WinoArgs a) {
 
     // per-lane LDS offsets (floats)
     const int b_off = q * K::PLANE + ((2 * wv) * K::TWP + 2 * tn) * 2;              // + (dy*TWP + dx)*2
-    const int a_off = lane * 4;                                                     // + p*256: {h0j0, h0j1, h1j0, h1j1}
+    const int a_off = lane * 4;                                                     // + vector [xi][h][j] * 256: {nu 0..3}
 
     const int CG = a.CGin;
     // one patch row of this lane's tile: pixels 2tn .. 2tn+3 of halo row 2wv + dy, channels (2q, 2q+1)
@@ -196,15 +209,15 @@ conv3x3_c8w_kernel(const WinoArgs a) {
     auto transform = [&](f32x2 (&d)[4][4], f32x2 (&Vo)[4][4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x2 t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+            const f32x2 t0 = psub(d[0][c], d[2][c]), t1 = d[1][c] + d[2][c], t2 = psub(d[2][c], d[1][c]), t3 = psub(d[1][c], d[3][c]);
             d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            Vo[r][0] = d[r][0] - d[r][2];
+            Vo[r][0] = psub(d[r][0], d[r][2]);
             Vo[r][1] = d[r][1] + d[r][2];
-            Vo[r][2] = d[r][2] - d[r][1];
-            Vo[r][3] = d[r][1] - d[r][3];
+            Vo[r][2] = psub(d[r][2], d[r][1]);
+            Vo[r][3] = psub(d[r][1], d[r][3]);
         }
     };
     f32x4 st_in[K::IN_ITERS];
@@ -234,14 +247,28 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         const float* rnext = raw_lds + (cur ^ 1) * K::RAW;      // raw tile of group cig+1 (stale after the last group: unused)
         issue_raw(st_in, cig + 3 >= CG);                        // raw tile of group cig+2 -> registers
         f32x2 d[4][4];
-        f32x4 af[3];                                            // U fragments of positions p, p+1, p+2 (rotating)
-        af[0] = *(const f32x4*)(ucur + a_off);
-        af[1] = *(const f32x4*)(ucur + a_off + 256);
+        // 16 slots per group.  A slot's U fragment is ONE 16-byte vector: the four positions (xi, nu = 0..3) of one 16-channel
+        // half h and one k-step j, feeding four MFMAs on four different accumulators; the slot order within xi is
+        // (h0, j0) (h1, j0) (h0, j1) (h1, j1), so an accumulator comes back EIGHT matrix instructions after its first use
+        // (v_mfma_f32_16x16x4_f32 runs at 0.80 of its rate when it comes back after 1, 2 or 4 and at 0.98 from 8 on:
+        // tools/probes/mfma_dep_probe.py).  NH = 1: eight fragments (xi, j) on the even slots, order (x, j0) (x+1, j0) (x, j1)
+        // (x+1, j1); the odd slots only carry the staging work below.
+        auto frag_vec = [](int sl) {                               // slab vector index [xi][h][j] of slot sl
+            if (NH == 2) return (sl >> 2) * 4 + (sl & 1) * 2 + ((sl >> 1) & 1);
+            const int k = sl >> 1, xi = (k >> 2) * 2 + (k & 1), j = (k >> 1) & 1;
+            return xi * 4 + j;
+        };
+        constexpr int STEP = NH == 2 ? 1 : 2;                      // slots between two fragments
+        f32x4 af[3];                                            // U fragments of three consecutive fragments (rotating)
+        af[0] = *(const f32x4*)(ucur + a_off + frag_vec(0) * 256);
+        af[1] = *(const f32x4*)(ucur + a_off + frag_vec(STEP) * 256);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            if (p < 14) af[(p + 2) % 3] = *(const f32x4*)(ucur + a_off + (p + 2) * 256);
-            // the LDS-DMA pieces of the next group's U slab one at a time under positions 1, 3, 5, 7: four in a row at the
-            // head of the group cost 3 % (tools/probes/wino_stamps.py: position 0 took twice a middle position's time)
+            const bool has_frag = (p % STEP) == 0;
+            const int fi = p / STEP;                            // fragment number
+            if (has_frag && p + 2 * STEP < 16) af[(fi + 2) % 3] = *(const f32x4*)(ucur + a_off + frag_vec(p + 2 * STEP) * 256);
+            // the LDS-DMA pieces of the next group's U slab one at a time under slots 1, 3, 5, 7: four in a row at the
+            // head of the group cost 3 % (tools/probes/wino_stamps.py: slot 0 took twice a middle slot's time)
             if ((p & 1) && (p >> 1) < K::U_ITERS) issue_u_piece(udst, p >> 1);
             if (p == 2 * K::U_ITERS - 1 && !ulast) w_g += w_step;
             // the next group's input transform as ONE block of 32 packed adds: v_mfma_f32_16x16x4_f32 shares the fp32 vector
@@ -252,22 +279,25 @@ conv3x3_c8w_kernel(const WinoArgs a) {
             } else if (p == 8) {
                 transform(d, Vn);
 #if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_sched_barrier(0);             // ... and not interleaved with this position's MFMAs either
+                __builtin_amdgcn_sched_barrier(0);             // ... and not interleaved with this slot's MFMAs either
 #endif
             } else if (p == 13) {
                 // raw tile of group cig+2: its LDS buffer held group cig, whose transform finished before the last barrier
                 write_raw(raw_lds + cur * K::RAW, st_in);
             }
-            const f32x4 u = af[p % 3];
+            if (has_frag) {
+                const f32x4 u = af[fi % 3];
+                int xi, h, j;
+                if (NH == 2) { xi = p >> 2; h = p & 1; j = (p >> 1) & 1; }
+                else { const int k = p >> 1; xi = (k >> 2) * 2 + (k & 1); h = 0; j = (k >> 1) & 1; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    acc[p][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[h * 2 + j], V[p >> 2][p & 3][j], acc[p][h], 0, 0, 0);
+                for (int nu = 0; nu < 4; ++nu)
+                    acc[4 * xi + nu][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[nu], V[xi][nu][j], acc[4 * xi + nu][h], 0, 0, 0);
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);                 // keep every slice under its own four MFMAs
 #endif
-            if constexpr (STAMP) {                             // detail (flags bit11): after every position of groups 4 and 5
+            if constexpr (STAMP) {                             // detail (flags bit11): after every slot of groups 4 and 5
                 if ((a.flags & 0x800) && (cig == 4 || cig == 5)) {
                     unsigned long long tq;
                     WINO_STAMP(tq);
@@ -447,13 +477,13 @@ __global__ void pack_wino_kernel(const float* __restrict__ pk, float* __restrict
     const size_t total = (size_t)CGin * NCB * WN_SLAB;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        // slab element index: [p 16][lane 64 = q*16 + tn][h 2][j 2]  ->  U_p[co = 32 cb + 16 h + tn][ci = 2 q + j]
+        // slab element index: [xi 4][h 2][j 2][lane 64 = q*16 + tn][nu 4]  ->  U_p[co = 32 cb + 16 h + tn][ci = 2 q + j],
+        // p = 4 xi + nu: one 16-byte vector per lane = the four positions of (xi, half h, k-step j)
         const int e = (int)(i % WN_SLAB);
         const size_t sl = i / WN_SLAB;
         const int cb = (int)(sl % NCB), cig = (int)(sl / NCB);
-        const int j = e & 1, h = (e >> 1) & 1, tnl = (e >> 2) & 15, ql = (e >> 6) & 3, p = e >> 8;
+        const int nu = e & 3, tnl = (e >> 2) & 15, ql = (e >> 6) & 3, j = (e >> 8) & 1, h = (e >> 9) & 1, xi = e >> 10;
         const int co = cb * 32 + h * 16 + tnl, ci = 2 * ql + j;
-        const int xi = p >> 2, nu = p & 3;
         const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         double u = 0;
         for (int ky = 0; ky < 3; ++ky)

@@ -128,7 +128,8 @@ class FFDNetEngine:
             for i in range(self.nb):
                 cin = self.cin0 if i == 0 else self.nc
                 cout = self.cout_last if i == self.nb - 1 else self.nc
-                self.packed_wino.append(ops.pack_conv3x3_wino(self.packed[i], cin, cout))
+                # (96-output-channel layers also get the slab layout of the persistent kernel, csrc/conv_winop.hip)
+                self.packed_wino.append(ops.pack_conv3x3_wino_both(self.packed[i], cin, cout))
 
     def adopt(self, packed_f32, packed_split=None):
         """Take over device-packed weights (the online finetune packs its updated master weights on the GPU,

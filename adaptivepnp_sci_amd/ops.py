@@ -333,10 +333,49 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
                torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32))
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
              (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
+    if isinstance(packed_wino, WinoPacked):
+        if packed_wino.p is not None and not (rows16 or shuffle) and persistent_wino_enabled():
+            _timed_call('conv3x3_c8p_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8p', _p(x, 'x'),
+                        _p(packed_wino.p, 'packed_winop'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'),
+                        n, cg * 8, Cout, h, w, flags, _stream())
+            return out
+        packed_wino = packed_wino.w
     _timed_call('conv3x3_c8w_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w', _p(x, 'x'),
                 _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
                 Cout, h, w, flags, _stream())
     return out
+
+
+class WinoPacked:
+    """Winograd-domain weights of one layer for conv3x3_c8w: `w` = the scipnp_pack_conv3x3_wino packing (every shape and
+    epilogue), `p` = the slab layout of the persistent kernel scipnp_conv3x3_c8p where the layer shape has one (96 output
+    channels), else None.  conv3x3_c8w picks the persistent form when it can (bit-identical results)."""
+    __slots__ = ('w', 'p', 'cin', 'cout')
+
+    def __init__(self, w, p, cin, cout):
+        self.w, self.p, self.cin, self.cout = w, p, cin, cout
+
+    def data_ptr(self):                                   # (C-entry callers pass the classic packing)
+        return self.w.data_ptr()
+
+
+def persistent_wino_enabled():
+    """SCIPNP_WINO_PERSISTENT=1 puts the 96-output-channel fp32 Winograd layers on the persistent kernel (csrc/conv_winop.hip).
+    Off by default: bit-identical to the classic kernel but measured 366-370 us against 334-336 us on the FFDNet body layer
+    (profiles/r03_winop_ablate.txt)."""
+    import os
+    return os.environ.get('SCIPNP_WINO_PERSISTENT', '0') == '1'
+
+
+def pack_conv3x3_wino_both(packed_f32, Cin, Cout):
+    """both Winograd packings of a layer from its fp32 direct packing (device buffers)"""
+    w = pack_conv3x3_wino(packed_f32, Cin, Cout)
+    p = None
+    lib = _lib.load()
+    if lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
+        p = torch.empty(lib.scipnp_conv3x3_winop_packed_floats(Cin, Cout), dtype=F32, device=packed_f32.device)
+        _call('scipnp_pack_conv3x3_winop', _p(packed_f32, 'packed_f32'), _p(p, 'packed_winop'), Cin, Cout, _stream())
+    return WinoPacked(w, p, Cin, Cout)
 
 
 def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_scale=None, bn_shift=None):

@@ -24,7 +24,7 @@ typedef struct {
     const char* out;          /* out_mosaic.bin */
     int f32;                  /* fp32 Winograd kernels instead of split-fp16 */
     int two_streams;          /* split-fp16: half of the frames of every network pass on the solve's own side stream */
-    float input_scale;        /* y is multiplied by this (1 = as given; 1e6 drives the activations out of fp16 range) */
+    float input_scale;        /* y is multiplied by this (1 = as given; 2e4 drives the first layers' activations past fp16's 65504) */
     int overflow;             /* result: the solve's own range-guard word after the last iteration */
     int H, W, B, tv_iters, iters;
 } pnp_solve_t;

@@ -351,6 +351,22 @@ int scipnp_pack_conv3x3_wino(const float* packed_f32, float* packed_wino, int Ci
 int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, const float* residual,
                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
+ * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
+ * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of
+ * 4-row x 32-column units with the channel-group pipeline running across unit boundaries.  Weights in their own slab layout:
+ * scipnp_pack_conv3x3_winop from the fp32 direct packing (scipnp_conv3x3_winop_packed_floats floats; 0 if unsupported).
+ * flags: bit0 ReLU, bit1 residual (fp32 c8, output shape), bit4 ReLU mask (mask_src), bit8 head tag; stride 1 only.
+ * scipnp_conv3x3_c8p_supported(Cin, Cout) = 1 for Cin % 8 == 0, Cout == 96. */
+int scipnp_conv3x3_c8p_supported(int Cin, int Cout);
+size_t scipnp_conv3x3_winop_packed_floats(int Cin, int Cout);
+int scipnp_pack_conv3x3_winop(const float* packed_f32, float* packed_winop, int Cin, int Cout, scipnp_stream_t s);
+int scipnp_conv3x3_c8p(const float* in, const float* packed_winop, float* out, const float* residual, const float* mask_src,
+                       int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+/* diagnostic: the same kernel with parts switched off (timing only, WRONG results) -- tools/probes/winop_ablate.py */
+int scipnp_conv3x3_c8p_diag(const float* in, const float* packed_winop, float* out, int n, int Cin, int Cout, int h, int w,
+                            int flags, int diag, scipnp_stream_t s);
+
 /* DIAGNOSTIC instantiation of scipnp_conv3x3_c8w (layers with more than 16 outputs, flags bit0 only): the same kernel
  * with six s_memtime stamps per workgroup; no product path calls it and the product kernel executes no stamp.
  * stamps: 80 words per workgroup (grid = ceil(w/32)*ceil(h/8)*n*ceil(Cout/32)), written by its first lane:
@@ -571,6 +587,10 @@ int scipnp_bench_mfma(float* out, int blocks, int iters, int mode, scipnp_stream
  * v_mfma_f32_16x16x4_f32, else v_mfma_f32_32x32x16_f16; 32 matrix-pipe cycles either way) nv (0, 1, 2, 4, 6, 8) independent
  * v_add_f32 of the same wave; cycles[blocks*4]: s_memtime ticks of each wave's loop of iters x 16 MFMAs. */
 int scipnp_bench_mfma_valu(float* out, unsigned long long* cycles, int blocks, int iters, int nv, int f32, scipnp_stream_t s);
+/* accumulation-chain issue patterns of v_mfma_f32_16x16x4_f32: second use of an accumulator `dist` MFMAs behind the first */
+int scipnp_bench_mfma_dep(float* out, unsigned long long* cycles, int blocks, int iters, int dist, scipnp_stream_t s);
+/* VGPR-bank placement of the A / B operands of v_mfma_f32_16x16x4_f32 (var 0..3, csrc/peaks.hip) */
+int scipnp_bench_mfma_bank(float* out, unsigned long long* cycles, int blocks, int iters, int var, scipnp_stream_t s);
 int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s);
 
 #ifdef __cplusplus

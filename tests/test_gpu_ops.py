@@ -1051,6 +1051,41 @@ def test_conv3x3_winograd_random_shapes(ops):
         assert rel_l2(ops.from_c8(got).cpu().numpy(), direct.numpy()) < 2e-6
 
 
+def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
+    """csrc/conv_winop.hip -- the persistent 96-output-channel form (input transform shared through LDS, 12-wave resident
+    workgroups, channel-group pipeline running across unit boundaries) -- computes the same products in the same order as
+    csrc/conv_wino.hip: BIT-IDENTICAL outputs for every epilogue, ragged sizes (units cut by the right / bottom border),
+    one and many channel groups, fewer units than CUs and many units per workgroup, several frames"""
+    g = torch.Generator().manual_seed(96)
+    shapes = [(1, 96, 4, 32), (2, 96, 20, 36), (3, 16, 13, 70), (1, 8, 1, 1), (2, 48, 37, 97), (8, 96, 128, 128),
+              (5, 96, 66, 250), (1, 24, 300, 33)]
+    for n, cin, h, w in shapes:
+        cout = 96
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        bias = torch.randn(cout, generator=g)
+        packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+        both = ops.pack_conv3x3_wino_both(packed, cin, cout)
+        assert both.p is not None
+        xc = ops.to_c8(x.cuda())
+        res = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        fwd = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        for kw in (dict(), dict(relu=True), dict(relu=True, residual=res), dict(mask_src=fwd), dict(mask_src=fwd, residual=res),
+                   dict(relu=True, head=True)):
+            monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '1')
+            got = ops.conv3x3_c8w(xc, both, cout, **kw)
+            monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '0')
+            want = ops.conv3x3_c8w(xc, both, cout, **kw)
+            assert torch.equal(got, want), (n, cin, h, w, sorted(kw), float((got - want).abs().max()))
+        if h * w <= 4096:
+            ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+            monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '1')
+            err = rel_l2(ops.from_c8(ops.conv3x3_c8w(xc, both, cout)).cpu().numpy(), ref.numpy())
+            assert err < 2e-6, (n, cin, h, w, err)
+    # shapes without a persistent form keep the classic kernel
+    assert ops.pack_conv3x3_wino_both(ops.pack_conv3x3(torch.zeros(64, 64, 3, 3), None, Cin=64, Cout=64, device='cuda'), 64, 64).p is None
+
+
 def test_tv_banded_kernel_random_shapes(ops):
     """seeded sweep of plane shapes and channel counts through the banded TV kernel against the tiled one: bit-identical
     `out` and stop iterations whatever the band / strip / wave seams and the iteration count"""

@@ -2,6 +2,7 @@
 """GPU box: FFDNet body layer (96 -> 96, 8 frames of 256 x 256): fp32 direct MFMA vs fp32 Winograd F(2x2,3x3) MFMA."""
 import os, sys
 import torch
+os.environ.setdefault('SCIPNP_WINO_PERSISTENT', '1')          # the WinoPacked variants below take the persistent kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import ops
 
@@ -14,16 +15,18 @@ b = torch.randn(c, generator=g)
 x8 = ops.to_c8(x)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pw = ops.pack_conv3x3_wino(pk, c, c)
-o8, o8w, o8v = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
+pb = ops.pack_conv3x3_wino_both(pk, c, c)
+o8, o8w, o8v, o8p = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
 variants = {'fp32 direct': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
             'fp32 winograd': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8w),
-            'fp32 wino 16row': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8v, rows16=True)}
+            'fp32 wino 16row': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8v, rows16=True),
+            'fp32 wino persist': lambda: ops.conv3x3_c8w(x8, pb, c, relu=True, out=o8p)}
 for f in variants.values():
     for _ in range(3):
         f()
 torch.cuda.synchronize()
 print('winograd vs direct rel-L2:', float((o8w - o8).norm() / o8.norm()), '16-row:', float((o8v - o8).norm() / o8.norm()),
-      'bitwise equal variants:', bool(torch.equal(o8w, o8v)))
+      'bitwise equal variants:', bool(torch.equal(o8w, o8v)), 'persistent == classic:', bool(torch.equal(o8w, o8p)))
 res = {k: [] for k in variants}
 for r in range(5):
     for k, f in variants.items():
