@@ -6,7 +6,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 T=r03a
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x --deselect tests/test_bench_launcher.py > gpurun_out/${T}_pytest.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -q --deselect tests/test_bench_launcher.py > gpurun_out/${T}_pytest.log 2>&1
 echo "pytest rc=$?"; tail -6 gpurun_out/${T}_pytest.log
 ls gpurun_out/fastdvd_grad_parity_*.txt 2>/dev/null && head -5 gpurun_out/fastdvd_grad_parity_f32.txt gpurun_out/fastdvd_grad_parity_f16x3.txt
 timeout -k 10 600 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
