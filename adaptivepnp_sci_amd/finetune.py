@@ -113,6 +113,8 @@ class _DeviceMean:
 # every online-finetune event, before the Adam step -- the quantity the reference holds in `.grad` after its first
 # total_loss.backward() (test_ffdnet_ipol.py:296, test_fastdvdnet.py:444).  None in production.
 GRAD_HOOK = None
+# diagnostic tap (tools/probes/fastdvd_grad_debug.py): callable(block name, layer index, gradient at that layer's (BN) output)
+TAP = None
 
 
 class _FFDNetTrainer:
@@ -553,8 +555,10 @@ class _FastDVDTrainer:
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         sp = self.split
         inv = 1.0 / self.gscale if sp else 1.0
-        gl = lambda i, x_in, dy, h, w: blk.grads_of_layer(  # noqa: E731
-            i, x_in, dy, B, h, w, self.ws, self.bws, _split_slabs(blk.spec[i][2]) if sp else self.NSLAB, inv)
+        def gl(i, x_in, dy, h, w):
+            if TAP is not None:
+                TAP(name, i, dy)
+            blk.grads_of_layer(i, x_in, dy, B, h, w, self.ws, self.bws, _split_slabs(blk.spec[i][2]) if sp else self.NSLAB, inv)
 
         def unshuffle(src, dst, cs, h, w):
             fn = lib.scipnp_pixel_shuffle_bwd_c8s if sp else lib.scipnp_pixel_shuffle_bwd_c8
