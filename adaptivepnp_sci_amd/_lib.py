@@ -105,6 +105,9 @@ SIGNATURES = {
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
+    'scipnp_admm_tv_flush': (_int, [_vp, C.POINTER(_int), _vp]),
+    'scipnp_pm_dual_project_fits': (_int, [_int, _int, _int]),
+    'scipnp_pm_dual_project': (_int, [_vp] * 9 + [_int, _int, _int, _int, _int, _flt, _flt, _vp]),
     'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
@@ -136,7 +139,8 @@ class AdmmTvArgs(C.Structure):
                 ('Phi', C.c_void_p), ('y', C.c_void_p), ('Phisum', C.c_void_p),
                 ('c0', C.c_double), ('c1', C.c_double), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
                 ('tv_workspace', C.c_void_p), ('tv_workspace_bytes', C.c_size_t),
-                ('orig', C.c_void_p), ('sse_part', C.c_void_p)]
+                ('orig', C.c_void_p), ('sse_part', C.c_void_p),
+                ('defer_state', C.POINTER(C.c_int)), ('sse_part_prev', C.c_void_p)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)

@@ -180,6 +180,105 @@ struct LdsAttrOnce {
 
 // tv.hip: can the banded one-launch Chambolle kernel take planes of M x N with n_iter iterations?
 bool tv_band_fits(int M, int N, int n_iter);
+// tv.hip: the CANDIDATE form of the banded kernel (one launch, nothing recomputed, no communication between bands): `out` of
+// every iteration and every band's partial energy sums go to the workspace; the consumer evaluates the stop test per channel
+// (tv_band_stop_test, by one full wave) and reads theta_raw = cand[(stop - 1) * C*M*N + i]
+struct TvCandidates {
+    const float* cand;      // [n_iter - 1][C][M][N]
+    const double* part;     // [C][nbands][n_iter][2]
+    int32_t* stop;          // [C] scratch for tv_stop_test_launch
+    int nbands, n_iter;
+    size_t MN;
+};
+bool tv_candidates_fit(int M, int N, int n_iter);
+void tv_candidate_ptrs(int M, int N, int C, int n_iter, void* workspace, TvCandidates* out);
+int tv_band_candidates(const float* x, const float* b, float coef, int M, int N, int C, float weight, float eps, int n_iter,
+                       void* workspace, size_t workspace_bytes, hipStream_t st);
+int tv_stop_test_launch(const TvCandidates& cd, int C, float weight, float eps, hipStream_t st);
+double tv_scalar_as_double(float f);     // weight / eps: the shortest decimal that round-trips the float (tv.hip as_double)
+
+// skimage's stop test of one channel from the partial sums of its bands (pc[band][it][2] = sum d^2, sum |grad|): executed by
+// ONE FULL WAVE (all 64 lanes call it); lane l sums bands l, l+64, ... in order, then a fixed shuffle tree -- the same sums in
+// the same order wherever it is evaluated -- and every lane returns the iteration whose `out` skimage keeps.
+// float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does.
+__device__ __forceinline__ int tv_band_stop_test(const double* __restrict__ pc, int nbands, int n_iter, size_t MN, double weight,
+                                                 double eps) {
+    constexpr int MAXIT = 4;                             // n_iter - 1 <= 4 (the banded kernels' halo)
+    const int lane = threadIdx.x & 63;
+    double s1[MAXIT], s2[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        s1[it] = 0.0;
+        s2[it] = 0.0;
+        if (it < n_iter - 1)
+            for (int k = lane; k < nbands; k += 64) {
+                s1[it] += pc[(size_t)k * 2 * n_iter + 2 * it];
+                s2[it] += pc[(size_t)k * 2 * n_iter + 2 * it + 1];
+            }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+        for (int off = 32; off > 0; off >>= 1) {
+            s1[it] += __shfl_down(s1[it], off, 64);
+            s2[it] += __shfl_down(s2[it], off, 64);
+        }
+    double E0 = 0.0, Eprev = 0.0;
+    int stop_at = n_iter - 1;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        if (it >= n_iter - 1 || stop_at != n_iter - 1) continue;
+        double E = (double)(float)s1[it];
+        E += weight * (double)(float)s2[it];
+        E /= (double)MN;
+        if (it == 0) { E0 = E; Eprev = E; }
+        else if (fabs(Eprev - E) < eps * E0) stop_at = it;
+        else Eprev = E;
+    }
+    return __shfl(stop_at, 0, 64);                       // (lane 0 holds the complete sums)
+}
+
+// The same test for EIGHT channels at once when a channel has at most 8 bands: lane = 8 * (channel of the wave) + band; `pc` is
+// the lane's channel (nullptr: none).  The shuffle tree inside the 8-lane segments adds exactly the terms the 64-lane tree of
+// tv_band_stop_test adds that are not zeros, in the same order -- bit-identical sums; lanes with band 0 return their channel's result.
+__device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc, int nbands, int n_iter, size_t MN, double weight,
+                                                  double eps) {
+    constexpr int MAXIT = 4;
+    const int k = threadIdx.x & 7;
+    double s1[MAXIT], s2[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const bool on = pc != nullptr && it < n_iter - 1 && k < nbands;
+        s1[it] = on ? pc[(size_t)k * 2 * n_iter + 2 * it] : 0.0;
+        s2[it] = on ? pc[(size_t)k * 2 * n_iter + 2 * it + 1] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+        for (int off = 4; off > 0; off >>= 1) {
+            s1[it] += __shfl_down(s1[it], off, 8);
+            s2[it] += __shfl_down(s2[it], off, 8);
+        }
+    double E0 = 0.0, Eprev = 0.0;
+    int stop_at = n_iter - 1;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        if (it >= n_iter - 1 || stop_at != n_iter - 1) continue;
+        double E = (double)(float)s1[it];
+        E += weight * (double)(float)s2[it];
+        E /= (double)MN;
+        if (it == 0) { E0 = E; Eprev = E; }
+        else if (fabs(Eprev - E) < eps * E0) stop_at = it;
+        else Eprev = E;
+    }
+    return stop_at;
+}
+// sci_ops.hip: scipnp_pm_dual_update with theta_raw selected per channel (sel != nullptr: theta_raw is the candidate base,
+// element i of channel c = i / MN comes from theta_raw[(sel[c] - 1) * img + i]) and scipnp_pm_dual_project doing the stop test
+// of the candidate form itself (cd != nullptr; weight / eps of the TV step as doubles)
+int pm_dual_update_sel(const float* theta_raw, const int32_t* sel, const float* x, float* theta, float* b, const float* orig,
+                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st);
+int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cd, double tv_weight, double tv_eps, float* x, float* theta,
+                        float* b, const float* Phi, const float* y, const float* Phisum, const float* orig, double* sse_part,
+                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st);
 // tv.hip: Chambolle TV + ADMM dual update of planes up to 128 x 128 in one launch (used by iterate.hip)
 bool tv_plane_dual_fits(int M, int N, int C, int nfill, bool want_sse);
 int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int N, int C, float weight, float eps,

@@ -53,32 +53,69 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
                    "null pointer in argument block");
     const int M = a->M, N = a->N, B = a->B;
     int rc;
-    float coef, sign;
-    if (a->two_stage) {
-        SCIPNP_REQUIRE(a->c0 > 0.0, "rho must be positive");
-        coef = (float)(1.0 / a->c0); sign = +1.0f;
-        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 0, coef, (float)(a->c1 * a->c0), s);                 // theta = TV(x + b/rho), b += x - theta
-    } else {
-        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, 1, (float)a->c0, (float)a->c1, s);
-        coef = -1.0f; sign = -1.0f;                         // theta = TV(x - b),     b -= x - theta
-    }
-    if (rc) return rc;
-    // planes up to 256 columns take the banded TV kernel (many workgroups per plane) followed by the dual update; narrower
-    // problems that leave the chip idle either way keep the one-launch whole-plane form with the dual update in its epilogue
+    // planes up to 256 columns take the banded TV kernel (many workgroups per plane, one launch) followed by the dual update;
+    // narrower problems that leave the chip idle either way keep the one-launch whole-plane form with the dual update in its epilogue
     int nstd = 0;
     scipnp_sse_partials(a->x, a->x, (size_t)4 * M * N * B, nullptr, &nstd, s);          // size query: pm_dual_update's grid
     const bool want_sse = a->sse_part && a->orig;
     const bool banded = tv_band_fits(M, N, a->tv_iters) && (long long)4 * B * ((M + 31) / 32) >= 128;
+    // deferred form: TV in its one-launch candidate form (no second launch, nothing recomputed; theta_raw is not written), the
+    // dual update -- which then also picks every channel's candidate -- fused into the next call's projection
+    const bool defer = banded && a->defer_state && scipnp_pm_dual_project_fits(M, N, B) && tv_candidates_fit(M, N, a->tv_iters);
+    TvCandidates cd = {};
+    if (defer) tv_candidate_ptrs(M, N, 4 * B, a->tv_iters, a->tv_workspace, &cd);
+    float coef, sign, pc0, pc1;
+    int mode;
+    if (a->two_stage) {
+        SCIPNP_REQUIRE(a->c0 > 0.0, "rho must be positive");
+        coef = (float)(1.0 / a->c0); sign = +1.0f;          // theta = TV(x + b/rho), b += x - theta
+        mode = 0; pc0 = coef; pc1 = (float)(a->c1 * a->c0);
+    } else {
+        coef = -1.0f; sign = -1.0f;                         // theta = TV(x - b),     b -= x - theta
+        mode = 1; pc0 = (float)a->c0; pc1 = (float)a->c1;
+    }
+    if (defer && *a->defer_state)       // the previous call's dual update and this call's projection in one launch
+        rc = pm_dual_project_sel(cd.cand, &cd, tv_scalar_as_double(a->tv_weight), tv_scalar_as_double(2e-4f), a->x, a->theta, a->b,
+                                 a->Phi, a->y, a->Phisum, a->orig, a->orig ? a->sse_part_prev : nullptr, nstd, M, N, B, mode, pc0,
+                                 pc1, (hipStream_t)s);
+    else
+        rc = scipnp_pm_project(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, mode, pc0, pc1, s);
+    if (rc) return rc;
+    if (a->defer_state) *a->defer_state = 0;
     if (!banded && tv_plane_dual_fits(M, N, 4 * B, nstd, want_sse)) {
         if (nblocks) *nblocks = nstd;
         return tv_plane_dual(a->x, a->b, coef, a->theta, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->orig,
                              want_sse ? a->sse_part : nullptr, a->two_stage ? 0 : 1, sign, nstd, (hipStream_t)s);
+    }
+    if (defer) {                        // this iteration's dual update rides at the head of the next call (or the flush)
+        rc = tv_band_candidates(a->x, a->b, coef, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->tv_workspace,
+                                a->tv_workspace_bytes, (hipStream_t)s);
+        if (rc) return rc;
+        *a->defer_state = 1;
+        if (nblocks) *nblocks = nstd;
+        return SCIPNP_OK;
     }
     rc = scipnp_tv_chambolle(a->x, a->b, coef, a->theta_raw, M, N, 4 * B, a->tv_weight, 2e-4f, a->tv_iters, a->tv_workspace,
                              a->tv_workspace_bytes, nullptr, s);
     if (rc) return rc;
     return scipnp_pm_dual_update(a->theta_raw, a->x, a->theta, a->b, a->orig, a->sse_part, a->two_stage ? 0 : 1, sign, M, N, B,
                                  nblocks, s);
+}
+
+int scipnp_admm_tv_flush(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(a, "null argument block");
+    SCIPNP_REQUIRE(a->struct_size == sizeof(scipnp_admm_tv_args),
+                   "scipnp_admm_tv_args.struct_size is %zu, this library's block has %zu bytes", a->struct_size,
+                   sizeof(scipnp_admm_tv_args));
+    if (!a->defer_state || !*a->defer_state) return SCIPNP_OK;
+    SCIPNP_REQUIRE(a->theta && a->b && a->x && a->theta_raw, "null pointer in argument block");
+    *a->defer_state = 0;
+    TvCandidates cd = {};
+    tv_candidate_ptrs(a->M, a->N, 4 * a->B, a->tv_iters, a->tv_workspace, &cd);
+    int rc = tv_stop_test_launch(cd, 4 * a->B, a->tv_weight, 2e-4f, (hipStream_t)s);      // (the rare path: an extra launch)
+    if (rc) return rc;
+    return pm_dual_update_sel(cd.cand, cd.stop, a->x, a->theta, a->b, a->orig, a->orig ? a->sse_part : nullptr,
+                              a->two_stage ? 0 : 1, a->two_stage ? +1.0f : -1.0f, a->M, a->N, a->B, nblocks, (hipStream_t)s);
 }
 
 }  // extern "C"

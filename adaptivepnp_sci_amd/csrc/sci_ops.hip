@@ -470,13 +470,151 @@ static int launch_pm_project(const float* theta, const float* b, const float* Ph
     hipLaunchKernelGGL((pm_project_kernel<VEC, MAXB, MODE>),                                         \
                        dim3((unsigned)((Q / VEC + threads - 1) / threads)), dim3(threads), 0, st,    \
                        theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1)
-    if (vec && B <= 8) SCIPNP_GO(4, 8);
-    else if (vec && B <= 16) SCIPNP_GO(4, 16);
-    else if (vec) SCIPNP_GO(2, 32);              // 17..32 frames: 2 pixels per thread keep p and Phi in 128 registers
+    // small states (a 256 x 256 mosaic is 64 workgroups of 4-pixel threads on 256 CUs): one pixel per thread -- the loads of
+    // a wave stay contiguous, the launch gets four times the workgroups (ADMM-TV 256x256x8: 6.7 -> see profiles/r03d_*)
+    const bool wide = Q / 4 >= 512LL * threads;
+    if (vec && wide && B <= 8) SCIPNP_GO(4, 8);
+    else if (vec && wide && B <= 16) SCIPNP_GO(4, 16);
+    else if (vec && wide) SCIPNP_GO(2, 32);      // 17..32 frames: 2 pixels per thread keep p and Phi in 128 registers
     else if (B <= 8) SCIPNP_GO(1, 8);
+    else if (B <= 16) SCIPNP_GO(1, 16);
     else SCIPNP_GO(1, 32);
 #undef SCIPNP_GO
     return launch_status("pm_project_kernel");
+}
+
+// ===================================================================== dual update of iteration k-1 + projection of iteration k
+// One launch for the tail of one ADMM iteration and the head of the next (round 3: the ADMM-TV iteration is launch-bound --
+// four launches of 3 - 8 us on a 2 MB state): per mosaic pixel and frame
+//     theta = clip(theta_raw, 0, 1);  b += / -= x - theta;  [squared error of the reported iterate]      (pm_dual_update_kernel)
+//     p = theta - c0 b  /  theta + b;  x = p + Phi^T((y - Phi p) / (c1 + Phisum))                        (pm_project_kernel)
+// with exactly the expressions of the two stand-alone kernels, so theta, b and x are bit-identical to running them one
+// after the other (x is updated in place: a thread owns its pixels in every frame).  Squared-error partials: one per
+// workgroup, entries [gridDim.x, nfill) zeroed, so a caller that sums the nfill partials of pm_dual_update's grid gets the
+// total (fp64 sums of exact fp32 squares; the association differs from the stand-alone kernel's in the last bit of the sum).
+template <int VEC, int MAXB, int MODE>
+__global__ void __launch_bounds__(256)
+pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates cd, int use_cd, double tv_weight, double tv_eps,
+                       float* xio, float* theta, float* bb,
+                       const float* __restrict__ Phi, const float* __restrict__ y, const float* __restrict__ Phisum,
+                       const float* __restrict__ orig, double* sse_part, int nfill, long long Q, int B, float c0, float c1, int CH) {
+    using V = typename VecT<VEC>::type;
+    __shared__ double red[16];
+    __shared__ int s_sel[4 * 32];                       // [plane of the workgroup's pixels - first one][frame]
+    const long long MN = Q >> 2;
+    // a workgroup owns CH consecutive chunks of blockDim.x * VEC pixels (CH > 1 only where one workgroup per chunk would be
+    // more squared-error partials than the caller's buffer holds)
+    const long long per = (long long)blockDim.x * VEC;
+    const long long qb = (long long)blockIdx.x * CH * per;                           // first pixel of the workgroup
+    const int ib_lo = (int)(qb / MN);
+    double acc = 0.0;
+    for (int ch = 0; ch < CH; ++ch) {
+        const long long q = qb + (long long)ch * per + (long long)threadIdx.x * VEC;
+        const bool live = q < Q;
+        // operands that do not depend on the stop test first: their latency covers it
+        float xr[MAXB][VEC], br[MAXB][VEC], ph[MAXB][VEC];
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < MAXB; ++t) {
+                if (t < B) {
+                    const size_t o = (size_t)t * Q + q;
+                    const V xv = *(const V*)(xio + o), bv = *(const V*)(bb + o), phv = *(const V*)(Phi + o);
+                    const float *xp = (const float*)&xv, *bp = (const float*)&bv, *php = (const float*)&phv;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { xr[t][v] = xp[v]; br[t][v] = bp[v]; ph[t][v] = php[v]; }
+                }
+            }
+        }
+        if (use_cd && ch == 0) {
+            // TV step in its candidate form: the stop test of every channel this workgroup touches, here (the same sums in the
+            // same order as tv_stop_kernel): channel (t, ib) kept the `out` of iteration s_sel -> candidate s_sel - 1
+            long long qe = qb + (long long)CH * per - 1;
+            if (qe > Q - 1) qe = Q - 1;
+            const int nib = qe >= qb ? (int)(qe / MN) - ib_lo + 1 : 0;
+            const int wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+            if (cd.nbands <= 8) {           // eight channels per wave
+                for (int j0 = wave * 8; j0 < nib * B; j0 += nw * 8) {
+                    const int j = j0 + ((threadIdx.x & 63) >> 3);
+                    const bool on = j < nib * B;
+                    const int t = on ? j % B : 0, ibl = on ? j / B : 0;
+                    const int c = t * 4 + ib_lo + ibl;
+                    const int st = tv_band_stop_test8(on ? cd.part + (size_t)c * cd.nbands * 2 * cd.n_iter : nullptr, cd.nbands,
+                                                      cd.n_iter, cd.MN, tv_weight, tv_eps);
+                    if (on && (threadIdx.x & 7) == 0) s_sel[ibl * 32 + t] = st;
+                }
+            } else {
+                for (int j = wave; j < nib * B; j += nw) {
+                    const int t = j % B, ibl = j / B;
+                    const int c = t * 4 + ib_lo + ibl;
+                    const int st = tv_band_stop_test(cd.part + (size_t)c * cd.nbands * 2 * cd.n_iter, cd.nbands, cd.n_iter, cd.MN,
+                                                     tv_weight, tv_eps);
+                    if ((threadIdx.x & 63) == 0) s_sel[ibl * 32 + t] = st;
+                }
+            }
+            __syncthreads();
+        }
+        if (live) {
+            float p[MAXB][VEC];
+#pragma unroll
+            for (int t = 0; t < MAXB; ++t) {
+                if (t < B) {
+                    const size_t o = (size_t)t * Q + q;
+                    // candidate form of the TV step: channel (t, plane of q) kept the `out` of iteration s_sel (Q/4 = plane size;
+                    // the VEC pixels of a thread lie in one plane: Q/4 % VEC == 0 on the vector paths)
+                    const size_t ro = use_cd ? (size_t)(s_sel[((int)(q / MN) - ib_lo) * 32 + t] - 1) * ((size_t)B * Q) + o : o;
+                    const V rv = *(const V*)(theta_raw + ro);
+                    const float *rp = (const float*)&rv, *xp = xr[t], *bp = br[t];
+                    V tho, bo;
+                    float *thp = (float*)&tho, *bop = (float*)&bo;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float th = fminf(fmaxf(rp[v], 0.f), 1.f);
+                        const float d = xp[v] - th;
+                        const float bn = (MODE == 0) ? (bp[v] + d) : (bp[v] - d);
+                        thp[v] = th;
+                        bop[v] = bn;
+                        p[t][v] = (MODE == 0) ? (th - c0 * bn) : (th + bn);
+                    }
+                    *(V*)(theta + o) = tho;
+                    *(V*)(bb + o) = bo;
+                    if (sse_part) {
+                        const V ov = *(const V*)(orig + o);
+                        const float* op = (const float*)&ov;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const float e = op[v] - (MODE == 0 ? thp[v] : xp[v]);
+                            acc += (double)(e * e);
+                        }
+                    }
+                }
+            }
+            const V yv = *(const V*)(y + q), sv = *(const V*)(Phisum + q);
+            const float *yp = (const float*)&yv, *sp = (const float*)&sv;
+            float r[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float yb = torch_contig_sum<MAXB>(B, [&](int i) { return p[i][v] * ph[i][v]; });
+                r[v] = (MODE == 0) ? (yp[v] - yb) / (c1 + sp[v]) : (yp[v] - yb) / (sp[v] + c1);
+            }
+#pragma unroll
+            for (int t = 0; t < MAXB; ++t) {
+                if (t < B) {
+                    V ov;
+                    float* op = (float*)&ov;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        op[v] = (MODE == 0) ? (p[t][v] + ph[t][v] * r[v]) : (p[t][v] + c0 * (r[v] * ph[t][v]));
+                    *(V*)(xio + (size_t)t * Q + q) = ov;
+                }
+            }
+        }
+    }
+    if (sse_part) {
+        const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+        if (threadIdx.x == 0) sse_part[blockIdx.x] = s;
+        if (blockIdx.x == 0)
+            for (int i = gridDim.x + threadIdx.x; i < nfill; i += blockDim.x) sse_part[i] = 0.0;
+    }
 }
 
 // ===================================================================== dual update (+ SSE partials)
@@ -484,7 +622,8 @@ constexpr int RED_THREADS = 256;
 constexpr int RED_PER_THREAD = 8;
 
 __global__ void __launch_bounds__(RED_THREADS)
-pm_dual_update_kernel(const float* __restrict__ theta_raw, const float* __restrict__ x,
+pm_dual_update_kernel(const float* __restrict__ theta_raw, const int32_t* __restrict__ sel, long long MN,
+                      const float* __restrict__ x,
                       float* theta, float* b, const float* __restrict__ orig, double* sse_part,
                       int which, float sign, long long total) {
     __shared__ double red[16];
@@ -494,7 +633,7 @@ pm_dual_update_kernel(const float* __restrict__ theta_raw, const float* __restri
     for (int k = 0; k < RED_PER_THREAD; ++k) {
         const long long i = base + (long long)k * RED_THREADS + threadIdx.x;
         if (i < total) {
-            const float raw = theta_raw[i];
+            const float raw = sel ? theta_raw[(long long)(sel[i / MN] - 1) * total + i] : theta_raw[i];
             const float xv = x[i];
             const float th = fminf(fmaxf(raw, 0.f), 1.f);
             const float d = xv - th;
@@ -642,16 +781,83 @@ int scipnp_pm_project(const float* theta, const float* b, const float* Phi, cons
 int scipnp_pm_dual_update(const float* theta_raw, const float* x, float* theta, float* b,
                           const float* orig, double* sse_part, int which, float sign, int M, int N, int B,
                           int* nblocks, scipnp_stream_t s) {
+    return pm_dual_update_sel(theta_raw, nullptr, x, theta, b, orig, sse_part, which, sign, M, N, B, nblocks, (hipStream_t)s);
+}
+
+}  // extern "C"
+
+namespace scipnp {
+int pm_dual_update_sel(const float* theta_raw, const int32_t* sel, const float* x, float* theta, float* b, const float* orig,
+                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st) {
     SCIPNP_REQUIRE(theta_raw && x && theta && b, "null pointer");
     SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
     const long long total = 4LL * M * N * B;
     const int per = RED_THREADS * RED_PER_THREAD;
     const unsigned blocks = (unsigned)((total + per - 1) / per);
     if (nblocks) *nblocks = (int)blocks;
-    hipLaunchKernelGGL(pm_dual_update_kernel, dim3(blocks), dim3(RED_THREADS), 0, (hipStream_t)s, theta_raw, x,
+    hipLaunchKernelGGL(pm_dual_update_kernel, dim3(blocks), dim3(RED_THREADS), 0, st, theta_raw, sel, (long long)M * N, x,
                        theta, b, orig, sse_part, which, sign, total);
     return launch_status("pm_dual_update_kernel");
 }
+}  // namespace scipnp
+
+extern "C" {
+
+int scipnp_pm_dual_project_fits(int M, int N, int B) { return M > 0 && N > 0 && B > 0 && B <= 32; }
+
+int scipnp_pm_dual_project(const float* theta_raw, float* x, float* theta, float* b, const float* Phi, const float* y,
+                           const float* Phisum, const float* orig, double* sse_part, int nfill, int M, int N, int B, int mode,
+                           float c0, float c1, scipnp_stream_t s) {
+    return pm_dual_project_sel(theta_raw, nullptr, 0.0, 0.0, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, M, N, B, mode, c0,
+                               c1, (hipStream_t)s);
+}
+
+}  // extern "C"
+
+namespace scipnp {
+int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double tv_weight, double tv_eps, float* x, float* theta,
+                        float* b, const float* Phi, const float* y, const float* Phisum, const float* orig, double* sse_part,
+                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st) {
+    SCIPNP_REQUIRE(theta_raw && x && theta && b && Phi && y && Phisum, "null pointer");
+    TvCandidates cd = {};
+    const int use_cd = cdp != nullptr;
+    if (use_cd) cd = *cdp;
+    SCIPNP_REQUIRE(!use_cd || cd.n_iter - 1 <= 4, "candidate form: at most 5 TV iterations");
+    SCIPNP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (two-stage) or 1 (one-stage)");
+    SCIPNP_REQUIRE(scipnp_pm_dual_project_fits(M, N, B), "fused dual update + projection: 1 <= B <= 32 (got %d)", B);
+    SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
+    const long long Q = 4LL * M * N;
+    // (vector paths: every thread's pixels in one Bayer plane and every candidate plane set 16-byte aligned)
+    const bool vec = ((long long)M * N % 4 == 0) && aligned16(Phi) && aligned16(y) && aligned16(x) && aligned16(theta) && aligned16(b) &&
+                     aligned16(Phisum) && aligned16(theta_raw) && (orig == nullptr || aligned16(orig));
+    const int threads = 256;
+    unsigned grid;
+#define SCIPNP_DP(VEC, MAXB)                                                                                     \
+    do {                                                                                                         \
+        const long long nchunks = (Q / VEC + threads - 1) / threads;                                             \
+        SCIPNP_REQUIRE(sse_part == nullptr || nfill > 0, "sse_part needs nfill > 0");                            \
+        const int CH = sse_part ? (int)((nchunks + nfill - 1) / nfill) : 1;                                      \
+        grid = (unsigned)((nchunks + CH - 1) / CH);                                                              \
+        if (mode == 0)                                                                                           \
+            hipLaunchKernelGGL((pm_dual_project_kernel<VEC, MAXB, 0>), dim3(grid), dim3(threads), 0, st, theta_raw, cd, use_cd, \
+                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, B, c0, c1, CH); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((pm_dual_project_kernel<VEC, MAXB, 1>), dim3(grid), dim3(threads), 0, st, theta_raw, cd, use_cd, \
+                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, B, c0, c1, CH); \
+    } while (0)
+    const bool wide = Q / 4 >= 512LL * threads;               // (as launch_pm_project: small states take one pixel per thread)
+    if (vec && wide && B <= 8) SCIPNP_DP(4, 8);
+    else if (vec && wide && B <= 16) SCIPNP_DP(4, 16);
+    else if (vec && wide) SCIPNP_DP(2, 32);
+    else if (B <= 8) SCIPNP_DP(1, 8);
+    else if (B <= 16) SCIPNP_DP(1, 16);
+    else SCIPNP_DP(1, 32);
+#undef SCIPNP_DP
+    return launch_status("pm_dual_project_kernel");
+}
+}  // namespace scipnp
+
+extern "C" {
 
 int scipnp_sse_partials(const float* a, const float* b, size_t n, double* part, int* nblocks,
                         scipnp_stream_t s) {

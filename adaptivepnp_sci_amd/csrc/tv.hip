@@ -46,7 +46,8 @@ static size_t tv_layout(int M, int N, int C, int n_iter, void* base, TvWorkspace
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return b ? b + o : nullptr; };
     float* p0 = (float*)take(2 * img * sizeof(float));
     float* p1 = (float*)take(2 * img * sizeof(float));
-    double* part = (double*)take((size_t)n_iter * C * nblk * 2 * sizeof(double));
+    const int nblk_part = nblk > (M + 7) / 8 ? nblk : (M + 7) / 8;                  // (the banded kernels: up to ceil(M/8) bands per channel)
+    double* part = (double*)take((size_t)n_iter * C * nblk_part * 2 * sizeof(double));
     double* en = (double*)take((size_t)n_iter * C * sizeof(double));
     int* st = (int*)take((size_t)n_iter * C * sizeof(int));
     if (ws) { ws->p[0] = p0; ws->p[1] = p1; ws->partial = part; ws->energy = en; ws->stopped = st; }
@@ -361,7 +362,8 @@ constexpr int TVB_HALO = 4;
 
 template <int COLS, int R, int STRIPS>
 __device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, float coef, float* th, int M, int N,
-                                            int n_iter, int a_lo, int a_hi, int ext_lo, float tau_over_w, double* part_out) {
+                                            int n_iter, int a_lo, int a_hi, int ext_lo, float tau_over_w, double* part_out,
+                                            float* cand = nullptr, size_t cand_stride = 0) {
     constexpr int WPS = COLS / 64;                       // waves per strip
     __shared__ float s_p0e[STRIPS + 1][COLS];            // [s+1]: p0 on the last row of strip s
     __shared__ float s_oe[STRIPS + 1][COLS];             // [s]:   out on the first row of strip s
@@ -400,6 +402,11 @@ __device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, fl
                 if (col > 0) d = d + left;
                 out[k] = v[k] + d;
                 if (own[k]) a1 += (double)(d * d);
+            }
+            if (cand) {         // candidate form: the band's own rows of EVERY iteration's `out` (the stop test picks one later)
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (own[k]) cand[(size_t)(it - 1) * cand_stride + (size_t)(r0 + k) * N + col] = out[k];
             }
         }
         if (it == n_iter - 1) break;          // only `out` of the last iteration is used (its energy decides nothing)
@@ -442,9 +449,11 @@ __device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, fl
             part_out[2 * it + 1] = s2;
         }
     }
+    if (th) {
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (own[k]) th[(size_t)(r0 + k) * N + col] = out[k];
+        for (int k = 0; k < R; ++k)
+            if (own[k]) th[(size_t)(r0 + k) * N + col] = out[k];
+    }
 }
 
 // kernel A (STAGE 0): all iterations + partials; kernel B (STAGE 1): stop test per channel, recomputation if it stopped early.
@@ -454,7 +463,7 @@ template <int COLS, int R, int STRIPS, int STAGE>
 __global__ void __launch_bounds__(COLS* STRIPS)
 tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta, int M, int N,
                int n_iter, int RB, int nbands, double weight, float tau_over_w, double eps, double* __restrict__ part,
-               int32_t* __restrict__ stop_iter) {
+               int32_t* __restrict__ stop_iter, size_t cand_stride) {
     const int c = blockIdx.x / nbands, band = blockIdx.x - c * nbands;
     const size_t chan = (size_t)c * M * N;
     const int a_lo = band * RB, a_hi = min(M, a_lo + RB);
@@ -466,43 +475,24 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
                                      part + ((size_t)c * nbands + band) * 2 * n_iter);
         return;
     }
-    // ---- stop test of the channel (every workgroup of the channel evaluates it identically): wave 0 sums the band partials
-    // of every iteration -- lane l takes bands l, l+64, ... in order, then a fixed shuffle tree; all loads are issued before
-    // the first sum -- and lane 0 walks skimage's test over the iterations
+    if (STAGE == 3) {
+        // CANDIDATE form -- ONE launch, nothing recomputed, no communication between the bands: every band stores its own rows
+        // of the `out` of every iteration 1 .. n_iter-1 (cand[it-1], `theta` here; plane stride cand_stride) beside its partial
+        // energy sums; whoever consumes the result evaluates the stop test per channel from the partials (tv_band_stop_test:
+        // tv_stop_kernel below, or the ADMM dual-update kernels on the fly) and reads cand[stop - 1].  Early stops are common
+        // in the ADMM loop (most planes of a converging reconstruction), so a form that recomputes stopped channels pays a
+        // second pass almost every time; and a "last band of the channel decides" scheme needs a device-scope fence per
+        // workgroup -- an L2 write-back across the XCDs -- that costs more than the launch it saves (measured: 82 us against
+        // 17 us for 32 planes of 128 x 128).
+        tv_band_run<COLS, R, STRIPS>(xc, bc, coef, nullptr, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
+                                     part + ((size_t)c * nbands + band) * 2 * n_iter, theta + chan, cand_stride);
+        return;
+    }
+    // ---- stop test of the channel (every workgroup of the channel evaluates it identically, tv_band_stop_test in common.hpp)
     __shared__ int s_stop_at;
     if (threadIdx.x < 64) {
-        const double* pc = part + (size_t)c * nbands * 2 * n_iter;
-        double s1[TVB_HALO], s2[TVB_HALO];
-#pragma unroll
-        for (int it = 0; it < TVB_HALO; ++it) {
-            s1[it] = 0.0;
-            s2[it] = 0.0;
-            if (it < n_iter - 1)
-                for (int k = threadIdx.x; k < nbands; k += 64) {
-                    s1[it] += pc[(size_t)k * 2 * n_iter + 2 * it];
-                    s2[it] += pc[(size_t)k * 2 * n_iter + 2 * it + 1];
-                }
-        }
-#pragma unroll
-        for (int it = 0; it < TVB_HALO; ++it)
-            for (int off = 32; off > 0; off >>= 1) {
-                s1[it] += __shfl_down(s1[it], off, 64);
-                s2[it] += __shfl_down(s2[it], off, 64);
-            }
+        const int stop_at = tv_band_stop_test(part + (size_t)c * nbands * 2 * n_iter, nbands, n_iter, (size_t)M * N, weight, eps);
         if (threadIdx.x == 0) {
-            double E0 = 0.0, Eprev = 0.0;
-            int stop_at = n_iter - 1;
-#pragma unroll
-            for (int it = 0; it < TVB_HALO; ++it) {
-                if (it >= n_iter - 1 || stop_at != n_iter - 1) continue;
-                // float32 array sums (held exactly: rounded once to float) then double arithmetic, as NumPy 1.x does
-                double E = (double)(float)s1[it];
-                E += weight * (double)(float)s2[it];
-                E /= (double)((size_t)M * N);
-                if (it == 0) { E0 = E; Eprev = E; }
-                else if (fabs(Eprev - E) < eps * E0) stop_at = it;
-                else Eprev = E;
-            }
             s_stop_at = stop_at;
             if (stop_iter && band == 0) stop_iter[c] = stop_at;
         }
@@ -516,29 +506,71 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
 // band height for N <= 256: 16-row bands when 32-row bands would leave the chip short of workgroups
 bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && n_iter - 1 <= TVB_HALO; }
 
-static int tv_band_launch(const float* x, const float* b, float coef, float* theta, int M, int N, int C, double weight_d,
-                          float tau_over_w, double eps_d, int n_iter, double* part, int32_t* stop_iter, hipStream_t st) {
+// experiment switch (SCIPNP_TV_TINY_BANDS=1): 8-row bands for problems that leave the chip short of workgroups even with 16-row
+// bands (twice the workgroups, 16 computed rows per 8 useful ones)
+static bool tv_tiny_bands() {
+    static const bool on = [] { const char* e = getenv("SCIPNP_TV_TINY_BANDS"); return e && e[0] == '1'; }();
+    return on;
+}
+
+// band geometry of the banded kernels for (M, C): rows per band, bands per channel
+static void tv_band_geometry(int M, int C, int* RB, int* nbands) {
     const bool small = (long long)C * ((M + 31) / 32) < 256;        // fewer than one workgroup per CU with 32-row bands
-    const int RB = small ? 16 : 32;
-    const int nbands = (M + RB - 1) / RB;
+    const bool tiny = tv_tiny_bands() && (long long)C * ((M + 15) / 16) <= 256;   // ... at most one per CU with 16-row bands
+    *RB = tiny ? 8 : small ? 16 : 32;
+    *nbands = (M + *RB - 1) / *RB;
+}
+
+// candidates != nullptr: the one-launch candidate form (STAGE 3) -- `out` of iteration it goes to candidates[(it - 1) * C*M*N ..],
+// the partial sums to `part`, nothing else.  Else kernel A + kernel B into theta.
+static int tv_band_launch(const float* x, const float* b, float coef, float* theta, int M, int N, int C, double weight_d,
+                          float tau_over_w, double eps_d, int n_iter, double* part, int32_t* stop_iter,
+                          float* candidates, hipStream_t st) {
+    int RB, nbands;
+    tv_band_geometry(M, C, &RB, &nbands);
+    const bool small = RB == 16, tiny = RB == 8;
     const dim3 grid((unsigned)(C * nbands));
+    const size_t img = (size_t)C * M * N;
 #define SCIPNP_TVB(COLS, R, STRIPS, RBV)                                                                                \
     do {                                                                                                                \
         static_assert(STRIPS * R >= RBV + 2 * TVB_HALO, "a workgroup's rows must cover its band + both halos");        \
-        hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
-                           n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
-        hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
-                           n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter);                           \
+        if (candidates) {                                                                                               \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 3>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, candidates, M, \
+                               N, n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);               \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+                               n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);                  \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+                               n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);                  \
+        }                                                                                                               \
     } while (0)
     if (N <= 64) {
-        if (small) SCIPNP_TVB(64, 3, 8, 16); else SCIPNP_TVB(64, 5, 8, 32);
+        if (tiny) SCIPNP_TVB(64, 2, 8, 8); else if (small) SCIPNP_TVB(64, 3, 8, 16); else SCIPNP_TVB(64, 5, 8, 32);
     } else if (N <= 128) {
-        if (small) SCIPNP_TVB(128, 6, 4, 16); else SCIPNP_TVB(128, 10, 4, 32);
+        if (tiny) SCIPNP_TVB(128, 4, 4, 8); else if (small) SCIPNP_TVB(128, 6, 4, 16); else SCIPNP_TVB(128, 10, 4, 32);
     } else {
-        if (small) SCIPNP_TVB(256, 6, 4, 16); else SCIPNP_TVB(256, 10, 4, 32);
+        if (tiny) SCIPNP_TVB(256, 4, 4, 8); else if (small) SCIPNP_TVB(256, 6, 4, 16); else SCIPNP_TVB(256, 10, 4, 32);
     }
 #undef SCIPNP_TVB
     return launch_status("tv_band_kernel");
+}
+
+// stop test of the candidate form as its own launch: one wave per channel, stop[c] = the iteration whose `out` skimage returns
+__global__ void __launch_bounds__(64)
+tv_stop_kernel(const double* __restrict__ part, int32_t* __restrict__ stop, int nbands, int n_iter, size_t MN, double weight,
+               double eps) {
+    const int c = blockIdx.x;
+    const int s = tv_band_stop_test(part + (size_t)c * nbands * 2 * n_iter, nbands, n_iter, MN, weight, eps);
+    if (threadIdx.x == 0) stop[c] = s;
+}
+
+// theta[i] = candidates[(stop[channel] - 1) * C*M*N + i]: the selection the fused ADMM kernel does on the fly
+__global__ void __launch_bounds__(256)
+tv_select_kernel(const float* __restrict__ cand, const int32_t* __restrict__ stop_iter, float* __restrict__ theta, size_t MN,
+                 size_t img) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= img) return;
+    theta[i] = cand[(size_t)(stop_iter[i / MN] - 1) * img + i];
 }
 
 // the shortest decimal that round-trips a float32: weight and eps are Python floats (doubles) in the reference and
@@ -592,6 +624,44 @@ int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int
                            nullptr, &d, st);
 }
 
+bool tv_candidates_fit(int M, int N, int n_iter) { return tv_band_fits(M, N, n_iter) && n_iter >= 2; }
+
+// where the candidate form keeps its results in a workspace laid out for (M, N, C, n_iter): `out` of iteration it at
+// cand[(it - 1) * C*M*N ..] (the tiled kernel's dual-field slots), the partial sums of channel c at part[c * nbands * 2 * n_iter ..],
+// a stop-iteration array of C ints for tv_stop_test_launch
+void tv_candidate_ptrs(int M, int N, int C, int n_iter, void* workspace, TvCandidates* out) {
+    TvWorkspace ws;
+    tv_layout(M, N, C, n_iter, workspace, &ws);
+    int RB;
+    tv_band_geometry(M, C, &RB, &out->nbands);
+    out->cand = ws.p[0];
+    out->part = ws.partial;
+    out->stop = (int32_t*)ws.stopped;
+    out->n_iter = n_iter;
+    out->MN = (size_t)M * N;
+}
+
+int tv_band_candidates(const float* x, const float* b, float coef, int M, int N, int C, float weight, float eps, int n_iter,
+                       void* workspace, size_t workspace_bytes, hipStream_t st) {
+    SCIPNP_REQUIRE(x && workspace && tv_candidates_fit(M, N, n_iter) && C > 0 && C <= 65535, "bad arguments");
+    SCIPNP_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
+    TvWorkspace ws;
+    const size_t need = tv_layout(M, N, C, n_iter, workspace, &ws);
+    if (workspace_bytes < need) return fail(SCIPNP_EWORKSPACE, "TV workspace too small: %zu < %zu", workspace_bytes, need);
+    const double weight_d = as_double(weight);
+    return tv_band_launch(x, b, coef, nullptr, M, N, C, weight_d, (float)(0.25 / weight_d), as_double(eps), n_iter, ws.partial,
+                          nullptr, ws.p[0], st);
+}
+
+// the stop test of a finished candidate launch as its own launch (the flush of a deferred ADMM-TV iteration): fills cd.stop
+int tv_stop_test_launch(const TvCandidates& cd, int C, float weight, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(tv_stop_kernel, dim3(C), dim3(64), 0, st, cd.part, cd.stop, cd.nbands, cd.n_iter, cd.MN, as_double(weight),
+                       as_double(eps));
+    return launch_status("tv_stop_kernel");
+}
+
+double tv_scalar_as_double(float f) { return as_double(f); }
+
 __global__ void tv_fill_stop_kernel(int32_t* stop_iter, int C, int last) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C && stop_iter[c] < 0) stop_iter[c] = last;
@@ -633,12 +703,29 @@ int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* th
     const float tau_over_w = (float)(0.25 / weight_d);
     const bool fits_plane = M <= TVP_MAX && N <= TVP_MAX;
     const bool fits_band = tv_band_fits(M, N, n_iter_max);
-    SCIPNP_REQUIRE(kernel >= 0 && kernel <= 3 && (kernel != 2 || fits_plane) && (kernel != 3 || fits_band),
+    SCIPNP_REQUIRE(kernel >= 0 && kernel <= 4 && (kernel != 2 || fits_plane) && ((kernel != 3 && kernel != 4) || fits_band),
                    "kernel=%d not available for %d x %d planes, %d iterations", kernel, M, N, n_iter_max);
+    SCIPNP_REQUIRE(kernel != 4 || (n_iter_max >= 2 && stop_iter), "kernel 4 (candidate form) needs n_iter_max >= 2 and stop_iter");
     if (kernel == 3 || (kernel == 0 && fits_band)) {
-        // banded one-launch form (+ the stop-test / recompute launch); its partials live in the tiled kernel's slot
-        // of the workspace (n_iter x C x ceil(M/16) x 2 doubles: at least as many as C x nbands x 2 x n_iter)
-        return tv_band_launch(x, b, coef, theta, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, ws.partial, stop_iter, st);
+        // banded form, kernel A + kernel B; the partials live in the tiled kernel's slot of the workspace
+        // (n_iter x C x ceil(M/16) x 2 doubles: at least as many as C x nbands x 2 x n_iter)
+        return tv_band_launch(x, b, coef, theta, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, ws.partial, stop_iter,
+                              nullptr, st);
+    }
+    if (kernel == 4) {
+        // candidate form (what scipnp_admm_tv_iterate uses with a deferred dual update) + the selection as its own launch:
+        // the candidates live in the tiled kernel's dual-field slots (4 x C x M x N floats >= n_iter_max - 1 planes sets)
+        int rc = tv_band_launch(x, b, coef, nullptr, M, N, C, weight_d, tau_over_w, eps_d, n_iter_max, ws.partial, stop_iter,
+                                ws.p[0], st);
+        if (rc) return rc;
+        const size_t img = (size_t)C * M * N;
+        int RB, nbands;
+        tv_band_geometry(M, C, &RB, &nbands);
+        hipLaunchKernelGGL(tv_stop_kernel, dim3(C), dim3(64), 0, st, ws.partial, stop_iter, nbands, n_iter_max, (size_t)M * N,
+                           weight_d, eps_d);
+        hipLaunchKernelGGL(tv_select_kernel, dim3((unsigned)((img + 255) / 256)), dim3(256), 0, st, ws.p[0], stop_iter, theta,
+                           (size_t)M * N, img);
+        return launch_status("tv_select_kernel");
     }
     if (fits_plane && kernel != 1) {
         // rows per thread: ceil(M / strips), strips = 1024 / columns

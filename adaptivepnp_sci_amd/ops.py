@@ -163,7 +163,8 @@ class TvPlan:
         self.M, self.N, self.C, self.n_iter_max = M, N, C_, n_iter_max
         nbytes = _lib.load().scipnp_tv_workspace_bytes(M, N, C_, n_iter_max)
         self.nbytes = nbytes
-        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        # zero once: the one-launch banded kernel counts finished bands per channel here (include/scipnp.h)
+        self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         off = (-self.ws.data_ptr()) % 256
         self.ptr = self.ws.data_ptr() + off
         self.stop_iter = torch.empty(C_, dtype=torch.int32, device=device)
@@ -172,7 +173,8 @@ class TvPlan:
 def tv_chambolle(x, b, coef, theta, plan, weight=0.1, eps=2e-4, kernel=0):
     """theta = TV(x + coef*b) channel by channel; x, b, theta: (C, M, N) views of plane-major state.
     kernel: 0 = the library's choice, 1 = tiled (a launch per iteration), 2 = whole plane (one launch, planes <= 128x128),
-    3 = banded (one launch of many workgroups per plane + the stop-test launch; <= 256 columns, <= 5 iterations)."""
+    3 = banded (one launch of many workgroups per plane + the stop-test launch; <= 256 columns, <= 5 iterations), 4 = banded
+    candidate form (one launch, nothing recomputed) + a selection launch (n_iter >= 2)."""
     _call('scipnp_tv_chambolle_ex', _p(x, 'x'), _p(b, 'b'), float(np.float32(coef)), _p(theta, 'theta'),
           plan.M, plan.N, plan.C, float(np.float32(weight)), float(np.float32(eps)), plan.n_iter_max,
           C.c_void_p(plan.ptr), plan.nbytes, _p(plan.stop_iter, 'stop_iter', torch.int32), int(kernel), _stream())

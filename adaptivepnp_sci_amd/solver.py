@@ -149,6 +149,13 @@ class AdmmRun:
                                             self.theta_raw.data_ptr(), self.Phi.data_ptr(), self.y.data_ptr(),
                                             self.Phisum.data_ptr(), float(c0), float(c1), 0.1, 5, self.plan.ptr,
                                             self.plan.nbytes, 0 if self.orig is None else self.orig.data_ptr(), 0)
+            # two launches per iteration: the dual update of an iteration rides in the launch that projects the next one
+            # (scipnp_admm_tv_args.defer_state); theta, b and the last squared-error row are brought up to date by flush(),
+            # which every reader of the state calls.  SCIPNP_TV_DEFER=0: three launches, nothing pending between steps.
+            self._tv_defer = C.c_int(0)
+            self._tv_prev_row = None
+            if os.environ.get('SCIPNP_TV_DEFER', '1') != '0':
+                self._tv_args.defer_state = C.pointer(self._tv_defer)
         else:
             self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
             self.w = torch.zeros_like(self.x_rgb) if two_stage else None
@@ -177,13 +184,17 @@ class AdmmRun:
         if self.denoiser == 'tv' and self.phi_events is None:
             part = self._new_sse(ops.sse_nblocks(self.x.numel())) if self.iqa else None
             self._tv_args.sse_part = 0 if part is None else part.data_ptr()
+            self._tv_args.sse_part_prev = 0 if self._tv_prev_row is None else self._tv_prev_row.data_ptr()
+            self._tv_prev_row = part
             _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(self._tv_args), None,
                                                           _lib.stream_ptr()),
                        'scipnp_admm_tv_iterate')
             if ITERATE_HOOK is not None:
+                self.flush()
                 ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
             self.k += 1
             return
+        self.flush()
         if self.phi_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
@@ -281,6 +292,17 @@ class AdmmRun:
         if self.ovf_word is not None and ops.split_overflow(word=self.ovf_word):
             raise _lib.ScipnpError(_OVERFLOW_MSG)
 
+    def flush(self):
+        """bring theta, b and the newest squared-error row up to date (the ADMM-TV path may leave the dual update of its last
+        step pending, see __init__); a no-op otherwise"""
+        if self.denoiser == 'tv' and self._tv_defer.value:
+            _lib.check(_lib.load().scipnp_admm_tv_flush(C.byref(self._tv_args), None, _lib.stream_ptr()), 'scipnp_admm_tv_flush')
+
+    @property
+    def log_lag(self):
+        """1 while the squared error of step k only exists after step k + 1 (or flush()) has been enqueued"""
+        return 1 if (self.denoiser == 'tv' and bool(self._tv_args.defer_state) and self.phi_events is None) else 0
+
     # ------------------------------------------------------------------ reporting
     def _new_sse(self, nblocks):
         if self._sse_fixed is not None:           # hipGraph replay: one fixed buffer, rows are collected on the device
@@ -293,6 +315,7 @@ class AdmmRun:
         """One read-back for all iterations: PSNR_k = 10 log10(1 / mean sq err) (skimage formula)."""
         if not self.sse_rows:
             return []
+        self.flush()
         n0 = self.sse_rows[0].numel()
         if all(r.numel() == n0 for r in self.sse_rows):            # one launch for the whole table
             sse = ops.sum_rows_f64(torch.stack(self.sse_rows)).cpu().numpy()
@@ -303,12 +326,14 @@ class AdmmRun:
 
     def result_mosaic(self):
         """(H,W,B) CUDA tensor of the reported iterate (theta two-stage, x one-stage; reference :312-315 / :538-541)."""
+        self.flush()
         return ops.state_to_mosaic(self.theta if self.two_stage else self.x)
 
     def final_report(self, mosaic_np=None):
         """per-frame PSNR / SSIM of the final reconstruction (reference :316-321 / :542-547), computed on the device"""
         if self.orig is None:
             return [], []
+        self.flush()
         return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
 
 
@@ -424,6 +449,9 @@ class GrayAdmmRun:
     psnr_all = AdmmRun.psnr_all
     check_overflow = AdmmRun.check_overflow
 
+    def flush(self):                                   # (nothing is ever left pending on this path)
+        pass
+
     def result_cube(self):
         return self._cube(self.x)
 
@@ -456,6 +484,7 @@ def _run_tv_graphed(run, total):
     256 x 256 x 8, 50 iterations, the whole call takes 5.0 ms with capture + instantiate + 49 replays against 4.1 ms for
     50 eager iterations -- one solve is too short to amortise the capture; it pays for schedules of several hundred
     iterations."""
+    run._tv_args.defer_state = None          # (a captured step must leave its squared-error row complete)
     run.step(0)
     n = total - 1
     table = kdev = None
@@ -560,13 +589,23 @@ def _run_schedule(run, sigma, iter_max, log=None):
             from .finetune import NoisePrefetch
             own_noise = run.noise_source = NoisePrefetch((run.B, 3, run.H, run.W), n_events)
     try:
+        held = None                              # (k, nsig) of a step whose squared-error row exists one step later
         for idx, nsig in enumerate(sigma):
             for _ in range(iter_max[idx]):
                 k = run.k
                 run.step(nsig, last=(run.k == total - 1))
                 if log is not None:
-                    log.after_step(k, nsig)
+                    if held is not None:
+                        log.after_step(*held)
+                        held = None
+                    if getattr(run, 'log_lag', 0):
+                        held = (k, nsig)
+                    else:
+                        log.after_step(k, nsig)
         if log is not None:
+            if held is not None:
+                run.flush()
+                log.after_step(*held)
             log.poll(block=True)
     finally:
         if own_noise is not None:

@@ -111,8 +111,12 @@ int scipnp_tv_chambolle(const float* x, const float* b, float coef, float* theta
  * banded form, 3; otherwise 2 where it fits, else 1); 1 = tiled, one launch of 16 x 256 tiles per iteration; 2 = whole
  * plane, all iterations in ONE launch, a workgroup per channel holding its plane in registers (planes up to 128 x 128);
  * 3 = banded, all iterations in one launch of many workgroups per channel (bands of 16 / 32 rows computed with a 4-row
- * halo) plus one launch for the stop test and the recomputation of channels that stopped early.  SCIPNP_EINVAL if the
- * named kernel does not fit the shape.  All four give bit-identical `theta` and stop iterations. */
+ * halo) plus one launch for the stop test and the recomputation of channels that stopped early; 4 = the banded CANDIDATE
+ * form (n_iter_max >= 2, stop_iter required): one launch stores the `out` of every iteration and every band's partial
+ * energy sums -- nothing is recomputed, the bands do not communicate -- followed here by the stop test per channel and the
+ * copy of every channel's selected candidate to theta as two small launches (scipnp_admm_tv_iterate with defer_state does
+ * both inside its dual-update launch instead).  SCIPNP_EINVAL if the named kernel does not fit the shape.  All five give bit-identical `theta` and stop
+ * iterations. */
 int scipnp_tv_chambolle_ex(const float* x, const float* b, float coef, float* theta,
                            int M, int N, int C, float weight, float eps, int n_iter_max,
                            void* workspace, size_t workspace_bytes, int32_t* stop_iter,
@@ -478,8 +482,8 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
 /* ADMM-TV iteration of either solver (dvp...:121-160, :265-271 two-stage; :385-407, :500-509 one-stage):
  * two_stage != 0: c0 = rho, c1 = alpha (theta = TV(x + b/rho), b += x - theta);
  * two_stage == 0: c0 = lambda, c1 = gamma (theta = TV(x - b), b -= x - theta).
- * Planes up to 256 columns with enough channels to fill the chip: four launches -- projection, the banded TV kernel (all
- * iterations, many workgroups per plane), its stop-test launch, dual update; small problems (fewer than 128 bands of 32 rows,
+ * Planes up to 256 columns with enough channels to fill the chip: three launches -- projection, the one-launch banded TV
+ * kernel, dual update -- or TWO with defer_state (below); small problems (fewer than 128 bands of 32 rows,
  * planes up to 128 x 128): two launches, the projection and one whole-plane kernel for all TV iterations plus the dual update
  * (theta_raw is then left untouched); wider planes: projection, a launch per TV iteration, dual update.
  * sse_part must hold the partials of scipnp_pm_dual_update's grid (size query: scipnp_sse_partials); all of them are
@@ -496,8 +500,26 @@ typedef struct {
     size_t tv_workspace_bytes;
     const float* orig;
     double* sse_part;
+    /* Deferred dual update (round 3; NULL: every call ends with theta, b and sse_part up to date).  defer_state points at a HOST
+     * int owned by the caller, 0 before the first call.  On the banded path (and B <= 32) a call then ends after the TV step
+     * and leaves ITS dual update pending (*defer_state = 1); the next call starts with ONE launch that performs the pending
+     * dual update -- writing the previous call's squared-error partials to sse_part_prev -- together with its own projection:
+     * an iteration is TWO launches (that launch + the banded TV kernel in its one-launch candidate form; theta_raw is then unused).  theta, b and sse_part are current again
+     * after scipnp_admm_tv_flush (same argument block; a no-op when nothing is pending).  Same results bit for bit. */
+    int* defer_state;
+    double* sse_part_prev;              /* sse_part of the PREVIOUS call (written during this one), or NULL */
 } scipnp_admm_tv_args;
 int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+int scipnp_admm_tv_flush(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+
+/* dual update of one ADMM iteration and projection of the next in ONE launch (csrc/sci_ops.hip; B <= 32:
+ * scipnp_pm_dual_project_fits): theta = clip(theta_raw), b +-= x - theta, then x = project(theta, b) in place -- the
+ * expressions of scipnp_pm_dual_update followed by scipnp_pm_project (mode, c0, c1 as there), bit-identical theta, b, x.
+ * sse_part (NULL: none) receives one partial per workgroup and zeros up to nfill entries. */
+int scipnp_pm_dual_project_fits(int M, int N, int B);
+int scipnp_pm_dual_project(const float* theta_raw, float* x, float* theta, float* b, const float* Phi, const float* y,
+                           const float* Phisum, const float* orig, double* sse_part, int nfill, int M, int N, int B, int mode,
+                           float c0, float c1, scipnp_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Layout steps of the stand-alone denoiser plug-ins (the solver fuses them into its pre/post kernels) -- csrc/plugin.hip

@@ -214,6 +214,15 @@ def test_tv_banded_kernel_equals_the_tiled_kernel(ops, shape, n_iter):
     o0 = torch.full_like(x, -3.0)
     ops.tv_chambolle(x, b, -1.0, o0, plan2, 0.1, kernel=0)      # the library's own choice
     assert torch.equal(o0, o1)
+    # kernel 4 = the CANDIDATE form (one launch stores every iteration's `out`, the last band of a channel does the stop test,
+    # nothing is recomputed; here followed by the selection launch); the per-channel band counters of the workspace are back
+    # at zero after every call, so a plan is reusable at once -- the same plan runs both banded forms, twice
+    if n_iter >= 2:
+        for kernel in (4, 3, 4, 4):
+            o4 = torch.full_like(x, -9.0)
+            plan2.stop_iter.fill_(-1)
+            ops.tv_chambolle(x, b, -1.0, o4, plan2, 0.1, kernel=kernel)
+            assert torch.equal(o4, o1) and torch.equal(plan1.stop_iter, plan2.stop_iter), kernel
 
 
 def test_tv_banded_kernel_early_stop_is_exercised(ops):

@@ -319,6 +319,41 @@ def test_fastdvdnet_online_finetune_matches_reference(solver, precision, monkeyp
     assert n_cmp > 100000 and n_floor < 0.5 * n_cmp, (n_cmp, n_floor)
 
 
+@pytest.mark.parametrize('two_stage', [False, True])
+def test_admm_tv_two_launch_iteration_equals_the_undeferred_one(solver, two_stage, monkeypatch):
+    """ADMM-TV with the dual update of an iteration riding in the launch that projects the next one (two launches per
+    iteration: scipnp_pm_dual_project + the one-launch banded TV kernel; scipnp_admm_tv_args.defer_state) against the same
+    solve with nothing deferred (SCIPNP_TV_DEFER=0): bit-identical mosaic, PSNR trace to 1e-9 dB (the squared-error partials
+    associate differently), the same log text -- and the state is complete whenever it is read in between (flush)"""
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    y, Phi, orig = synth.make_problem(256, 256, 8, seed=9)
+    fn = solver.twoStageAdmm_denoise_bayer if two_stage else solver.admm_denoise_bayer_demosaic_pre
+    outs = {}
+    for defer in ('1', '0'):
+        monkeypatch.setenv('SCIPNP_TV_DEFER', defer)
+        log = io.StringIO()
+        res = fn(y, Phi, 1, 0.01, 'tv', [11], False, [0], X_orig=orig, logf=log)
+        outs[defer] = (res[0], np.array(res[3]), log.getvalue())
+    assert np.array_equal(outs['1'][0], outs['0'][0])
+    assert len(outs['1'][1]) == 11 and np.abs(outs['1'][1] - outs['0'][1]).max() < 1e-9
+    assert outs['1'][2] == outs['0'][2] and outs['1'][2].count('PSNR') == 5
+    # stepping by hand: the reported iterate read after every step (flush) equals the undeferred run's, and the pending
+    # state is visible in between
+    monkeypatch.setenv('SCIPNP_TV_DEFER', '1')
+    a = AdmmRun(y, Phi, 'tv', two_stage, X_orig=orig)
+    monkeypatch.setenv('SCIPNP_TV_DEFER', '0')
+    b = AdmmRun(y, Phi, 'tv', two_stage, X_orig=orig)
+    assert a.log_lag == 1 and b.log_lag == 0
+    for k in range(5):
+        a.step(0)
+        b.step(0)
+        assert a._tv_defer.value == 1 and b._tv_defer.value == 0
+        if k in (1, 4):
+            assert torch.equal(a.result_mosaic(), b.result_mosaic()) and a._tv_defer.value == 0
+    assert np.abs(np.array(a.psnr_all()) - np.array(b.psnr_all())).max() < 1e-9
+
+
 class _MaskReLU(torch.nn.Module):
     """ReLU whose derivative is a GIVEN 0/1 mask: out = x * mask (call k of the module uses masks[order(k)])"""
 
@@ -610,6 +645,7 @@ def test_admm_tv_single_call_iteration_equals_the_launch_by_launch_path(solver, 
     for _ in range(6):
         fused.step(0)
         plain.step(0)
+    fused.flush()                              # (the banded path leaves the last dual update pending: two launches per step)
     assert torch.equal(fused.theta, plain.theta) and torch.equal(fused.b, plain.b) and torch.equal(fused.x, plain.x)
     assert np.abs(np.array(fused.psnr_all()) - np.array(plain.psnr_all())).max() < 1e-9
 

@@ -13,7 +13,7 @@ for (C_, M, N) in ((32, 128, 128), (64, 128, 128), (32, 64, 64), (32, 256, 256))
     b = torch.randn(C_, M, N, device=dev) * 0.1
     out = torch.empty_like(x)
     plan = ops.TvPlan(M, N, C_, 5, dev)
-    for kernel in ((1, 2, 3) if M <= 128 else (1, 3)):
+    for kernel in ((1, 2, 3, 4) if M <= 128 else (1, 3, 4)):
         for _ in range(5):
             ops.tv_chambolle(x, b, -1.0, out, plan, 0.1, kernel=kernel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,7 +24,8 @@ for (C_, M, N) in ((32, 128, 128), (64, 128, 128), (32, 64, 64), (32, 256, 256))
         print(f'TV 5 iterations, {C_} planes of {M}x{N}, kernel={kernel}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us')
 for (H, W, B) in ((256, 256, 8), (256, 256, 16), (128, 128, 8)):
     y, Phi, orig = synth.make_problem(H, W, B, 0)
-    for two in (False, True):
+    for two, defer in ((False, '1'), (False, '0'), (True, '1'), (True, '0')):
+        os.environ['SCIPNP_TV_DEFER'] = defer
         run = AdmmRun(y, Phi, 'tv', two, X_orig=orig)
         for _ in range(3):
             run.step(0)
@@ -33,8 +34,9 @@ for (H, W, B) in ((256, 256, 8), (256, 256, 16), (128, 128, 8)):
             run.step(0)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
-        print(f'ADMM-TV {"two" if two else "one"}-stage {H}x{W}x{B}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us/iteration '
+        print(f'ADMM-TV {"two" if two else "one"}-stage {H}x{W}x{B} defer={defer}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us/iteration '
               f'(host enqueue {(t1 - t0) / 50 * 1e6:.1f} us)')
+os.environ['SCIPNP_TV_DEFER'] = '1'
 y0, Phi0, orig0 = synth.make_problem(256, 256, 8, 0)
 for mode in ('1', '0'):
     os.environ['SCIPNP_HIPGRAPH'] = mode
