@@ -238,6 +238,11 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         transform(d, Va);
     }
 
+    // The LAST slot of a group is only loaded before the group's barrier; its four MFMAs are issued right behind the barrier,
+    // after the first U fragments of the next group have been requested from LDS (NH = 2): the matrix pipe has work while the
+    // wave waits for those operands -- the previous group's V lives in the other V buffer until slot 8 of the next group.
+    constexpr bool HOLD = NH == 2;
+    f32x4 u_held = {0.f, 0.f, 0.f, 0.f};
     // one channel group: MFMAs on (V, U_cig), transform of group cig+1 into Vn, staging of group cig+2 / U_{cig+1}
     auto group_step = [&](int cig, const f32x2 (&V)[4][4], f32x2 (&Vn)[4][4]) {
         const int cur = cig & 1;
@@ -262,6 +267,14 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         f32x4 af[3];                                            // U fragments of three consecutive fragments (rotating)
         af[0] = *(const f32x4*)(ucur + a_off + frag_vec(0) * 256);
         af[1] = *(const f32x4*)(ucur + a_off + frag_vec(STEP) * 256);
+        if (HOLD && cig > 0) {                                  // slot 15 of the previous group: (xi 3, h 1, j 1), V still in Vn
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                acc[12 + nu][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u_held[nu], Vn[3][nu][1], acc[12 + nu][NH - 1], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const bool has_frag = (p % STEP) == 0;
@@ -285,7 +298,9 @@ conv3x3_c8w_kernel(const WinoArgs a) {
                 // raw tile of group cig+2: its LDS buffer held group cig, whose transform finished before the last barrier
                 write_raw(raw_lds + cur * K::RAW, st_in);
             }
-            if (has_frag) {
+            if (HOLD && p == 15) {
+                u_held = af[fi % 3];                            // (issued behind the barrier, see above)
+            } else if (has_frag) {
                 const f32x4 u = af[fi % 3];
                 int xi, h, j;
                 if (NH == 2) { xi = p >> 2; h = p & 1; j = (p >> 1) & 1; }
@@ -320,6 +335,12 @@ conv3x3_c8w_kernel(const WinoArgs a) {
         group_step(cig + 1, Vb, Va);
     }
     if (cig < CG) group_step(cig, Va, Vb);
+    if (HOLD) {                                                 // slot 15 of the last group (its V: Va after an odd group count)
+        const f32x2 (&Vl)[4][4] = (CG & 1) ? Va : Vb;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+            acc[12 + nu][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u_held[nu], Vl[3][nu][1], acc[12 + nu][NH - 1], 0, 0, 0);
+    }
     if constexpr (STAMP) WINO_STAMP(ts3);
 
     // ---- output transform  Y = A^T M A, bias, epilogue; lane: tile (wv, tn), channels 32*split + 16*h + 4*q + r.
