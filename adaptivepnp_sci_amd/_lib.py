@@ -111,6 +111,10 @@ SIGNATURES = {
     'scipnp_conv3x3_wino_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_wino4_packed_floats': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_wino4': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w4': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
     'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),

@@ -336,6 +336,8 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
              (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
     if isinstance(packed_wino, WinoPacked):
+        if packed_wino.f4 is not None and not (rows16 or shuffle) and wino_f4_enabled():
+            return conv3x3_c8w4(x, packed_wino.f4, Cout, relu=relu, residual=residual, mask_src=mask_src, out=out, head=head)
         if packed_wino.p is not None and not (rows16 or shuffle) and persistent_wino_enabled():
             _timed_call('conv3x3_c8p_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8p', _p(x, 'x'),
                         _p(packed_wino.p, 'packed_winop'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'),
@@ -348,17 +350,52 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
     return out
 
 
+def pack_conv3x3_wino4(packed_f32, Cin, Cout, out=None):
+    """fp32 direct packing (device buffer) -> Winograd F(4x4,3x3) packing for conv3x3_c8w4 (U = G g G^T in double, on the device)"""
+    if out is None:
+        out = torch.empty(_lib.load().scipnp_conv3x3_wino4_packed_floats(Cin, Cout), dtype=F32, device=packed_f32.device)
+    _call('scipnp_pack_conv3x3_wino4', _p(packed_f32, 'packed_f32'), _p(out, 'packed_wino4'), Cin, Cout, _stream())
+    return out
+
+
+def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+    """stride-1 3x3 conv on c8 activations in fp32 Winograd F(4x4,3x3) arithmetic (csrc/conv_wino4.hip): 2.25 multiply-adds per
+    output on the matrix cores instead of 4 (conv3x3_c8w) or 9 (conv3x3_c8)."""
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
+             (0x100 if head else 0))
+    _timed_call('conv3x3_c8w4_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w4', _p(x, 'x'),
+                _p(packed_wino4, 'packed_wino4'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
+                Cout, h, w, flags, _stream())
+    return out
+
+
 class WinoPacked:
     """Winograd-domain weights of one layer for conv3x3_c8w: `w` = the scipnp_pack_conv3x3_wino packing (every shape and
-    epilogue), `p` = the slab layout of the persistent kernel scipnp_conv3x3_c8p where the layer shape has one (96 output
-    channels), else None.  conv3x3_c8w picks the persistent form when it can (bit-identical results)."""
-    __slots__ = ('w', 'p', 'cin', 'cout')
+    epilogue), `f4` = the F(4x4,3x3) packing of scipnp_conv3x3_c8w4 for the layer shapes that kernel is used for, else None,
+    `p` = the slab layout of the persistent F(2x2) kernel scipnp_conv3x3_c8p (96 output channels), else None."""
+    __slots__ = ('w', 'p', 'f4', 'cin', 'cout')
 
-    def __init__(self, w, p, cin, cout):
-        self.w, self.p, self.cin, self.cout = w, p, cin, cout
+    def __init__(self, w, p, cin, cout, f4=None):
+        self.w, self.p, self.f4, self.cin, self.cout = w, p, f4, cin, cout
 
     def data_ptr(self):                                   # (C-entry callers pass the classic packing)
         return self.w.data_ptr()
+
+
+def wino_f4_enabled():
+    """SCIPNP_WINO_F4=0 keeps every fp32 Winograd layer on the F(2x2,3x3) kernel; default: layers with at least 32 input and
+    output channels run as F(4x4,3x3) (csrc/conv_wino4.hip)."""
+    import os
+    return os.environ.get('SCIPNP_WINO_F4', '0') == '1'
+
+
+def wino_f4_shape(Cin, Cout):
+    """layer shapes the F(4x4,3x3) kernel is used for: its workgroup computes 32 output channels from K-steps of 4 input
+    channels -- narrower layers are padding or transform-bound there"""
+    return Cin >= 32 and Cout >= 32
 
 
 def persistent_wino_enabled():
@@ -370,14 +407,15 @@ def persistent_wino_enabled():
 
 
 def pack_conv3x3_wino_both(packed_f32, Cin, Cout):
-    """both Winograd packings of a layer from its fp32 direct packing (device buffers)"""
+    """the Winograd packings of a layer from its fp32 direct packing (device buffers)"""
     w = pack_conv3x3_wino(packed_f32, Cin, Cout)
     p = None
     lib = _lib.load()
-    if lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
+    if persistent_wino_enabled() and lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
         p = torch.empty(lib.scipnp_conv3x3_winop_packed_floats(Cin, Cout), dtype=F32, device=packed_f32.device)
         _call('scipnp_pack_conv3x3_winop', _p(packed_f32, 'packed_f32'), _p(p, 'packed_winop'), Cin, Cout, _stream())
-    return WinoPacked(w, p, Cin, Cout)
+    f4 = pack_conv3x3_wino4(packed_f32, Cin, Cout) if (wino_f4_enabled() and wino_f4_shape(Cin, Cout)) else None
+    return WinoPacked(w, p, Cin, Cout, f4)
 
 
 def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_scale=None, bn_shift=None):

@@ -355,6 +355,25 @@ int scipnp_pack_conv3x3_wino(const float* packed_f32, float* packed_wino, int Ci
 int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, const float* residual,
                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* ---- fp32 Winograd F(4x4,3x3) form (csrc/conv_wino4.hip, round 3): 36 exact fp32 products per 16 outputs and channel pair,
+ * 2.25 multiply-adds per output (F(2x2): 4, direct: 9), interpolation points 0, +-1, +-2, inf, fp32 accumulation on
+ * v_mfma_f32_16x16x4_f32; results equal to scipnp_conv3x3_c8 up to fp32 re-association and the transforms' rounding
+ * (<= 3e-6 relative L2 per layer in tests/test_gpu_ops.py; 3e-7 through the 12 FFDNet layers against float64).
+ * packed_wino4: scipnp_conv3x3_wino4_packed_floats(Cin, Cout) floats derived on the device from the fp32 direct packing
+ * (U = G g G^T in double), layout [2*Cin/8 k-steps][CoutP/32][xi half][9 vectors][lane][4], then bias[CoutP].
+ * flags: bit0 ReLU, bit1 add `residual`, bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag; stride 1, plain store.
+ * -- same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8w. */
+size_t scipnp_conv3x3_wino4_packed_floats(int Cin, int Cout);
+int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int Cin, int Cout, scipnp_stream_t s);
+int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, const float* residual,
+                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+
+/* diagnostic: the F(4x4) kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
+ * diag: bit0 no input transform, bit1 no raw-tile staging, bit2 no U LDS-DMA, bit3 no barriers in the K loop, bit4 no MFMAs,
+ * bit5 no output transform / stores */
+int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                             int flags, int diag, scipnp_stream_t s);
+
 /* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
  * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
  * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of

@@ -1065,6 +1065,8 @@ def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
     workgroups, channel-group pipeline running across unit boundaries) -- computes the same products in the same order as
     csrc/conv_wino.hip: BIT-IDENTICAL outputs for every epilogue, ragged sizes (units cut by the right / bottom border),
     one and many channel groups, fewer units than CUs and many units per workgroup, several frames"""
+    monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '1')         # (the persistent slab layout is only packed when the kernel is enabled)
+    monkeypatch.setenv('SCIPNP_WINO_F4', '0')
     g = torch.Generator().manual_seed(96)
     shapes = [(1, 96, 4, 32), (2, 96, 20, 36), (3, 16, 13, 70), (1, 8, 1, 1), (2, 48, 37, 97), (8, 96, 128, 128),
               (5, 96, 66, 250), (1, 24, 300, 33)]
