@@ -114,6 +114,7 @@ SIGNATURES = {
     'scipnp_conv3x3_wino4_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino4': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w4': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
     'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
@@ -132,6 +133,7 @@ SIGNATURES = {
     'scipnp_ffdnet_unpack_output': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     'scipnp_cube_sum3': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8w': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_ffdnet_forward_c8w4': (_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward_c8s_2s': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
@@ -163,7 +165,7 @@ class TwoStageFfdnetArgs(C.Structure):
                 ('sigma', C.c_float), ('first_iter', C.c_int),
                 ('packed_wino', C.c_void_p), ('net_in_c8', C.c_void_p),
                 ('overflow_word', C.c_void_p), ('side_stream', C.c_void_p),
-                ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p)]
+                ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p), ('packed_wino4', C.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(C.sizeof(type(self)), **kw)

@@ -34,7 +34,9 @@
 // One barrier per k-step (36 MFMAs per wave): a whole group's slab pair double-buffered (74 KiB) plus the tiles would not leave
 // room for two workgroups per CU.
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace scipnp {
 
@@ -67,6 +69,8 @@ struct Wino4Args {
     int H, W;
     int ntx, nty;
     int flags;
+    int stagger;             // first-generation workgroups 256..511 (the second workgroup slot of every CU) sleep this many x 64 x 127 cycles
+    unsigned long long* dbg; // STAMP instantiation (DIAG bit6) only: 128 words per workgroup, see scipnp_conv3x3_c8w4_stamped
 };
 
 // (host pass: only parsed -- the kernel body never runs there)
@@ -94,6 +98,35 @@ __host__ __device__ __forceinline__ f32x2 psub4(f32x2 a, f32x2 b) {
     return a - b;
 #endif
 }
+// c * x + y on a float2 as ONE v_pk_fma_f32, c an inline constant (the compiler scalarises a <2 x float> fma whose result is
+// only ever read element by element -- the MFMA operands -- into two v_fma_f32, and every vector instruction is matrix time)
+#define W4_PK_FMA_CONST(NAME, LIT)                                                                     \
+    __host__ __device__ __forceinline__ f32x2 NAME(f32x2 x, f32x2 y) {                                 \
+        f32x2 r = x * (float)(LIT) + y;                                                                \
+        W4_DEVICE_ASM("v_pk_fma_f32 %0, %1, " #LIT ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y)); \
+        return r;                                                                                      \
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W4_DEVICE_ASM(...) asm(__VA_ARGS__)
+#else
+#define W4_DEVICE_ASM(...) (void)0
+#endif
+W4_PK_FMA_CONST(fma_p4, 4.0)
+W4_PK_FMA_CONST(fma_m4, -4.0)
+W4_PK_FMA_CONST(fma_p2, 2.0)
+W4_PK_FMA_CONST(fma_m2, -2.0)
+// k * x + y with k (both halves the same value) in a scalar register pair: -5 is not an inline constant
+__host__ __device__ __forceinline__ f32x2 fma_k(f32x2 x, f32x2 y, f32x2 k) {
+    f32x2 r = x * k + y;
+    W4_DEVICE_ASM("v_pk_fma_f32 %0, %1, %3, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y), "s"(k));
+    return r;
+}
+__host__ __device__ __forceinline__ f32x2 padd(f32x2 a, f32x2 b) {
+    f32x2 r = a + b;
+    W4_DEVICE_ASM("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // a - b on a float4 as two v_pk_add_f32
 __host__ __device__ __forceinline__ f32x4 psub4(f32x4 a, f32x4 b) {
     const f32x2 lo = psub4(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = psub4(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
@@ -107,26 +140,55 @@ __host__ __device__ __forceinline__ f32x2 splat<f32x2>(float v) { return f32x2{v
 template <>
 __host__ __device__ __forceinline__ f32x4 splat<f32x4>(float v) { return f32x4{v, v, v, v}; }
 
-// rows 0..2 of B^T x for x = (x0 .. x4)  (x5 does not enter):  4x0 - 5x2 + x4 | -4x1 - 4x2 + x3 + x4 | 4x1 - 4x2 - x3 + x4
-__host__ __device__ __forceinline__ void bt_lo(const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, f32x2& o0,
-                                      f32x2& o1, f32x2& o2) {
-    const f32x2 c4 = splat<f32x2>(4.f), m4 = splat<f32x2>(-4.f), m5 = splat<f32x2>(-5.f);
-    o0 = pk_fma(c4, x0, pk_fma(m5, x2, x4));
-    const f32x2 a = pk_fma(m4, x2, x4), b = pk_fma(m4, x1, x3);
-    o1 = a + b;
-    o2 = psub4(a, b);
+// one clock stamp of wave 0, written with a SCALAR store (no vmcnt traffic: the K loop's waits count vector memory operations)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W4_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if constexpr ((DIAG & 64) != 0) {                                                                           \
+            if (wvu == 0) {                                                                                         \
+                unsigned long long t_;                                                                              \
+                const unsigned long long* p_ = stamp_base + (slot);                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t_) : "s"(p_) : "memory"); \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#else
+#define W4_STAMP(slot) (void)0
+#endif
+
+template <int... I, typename F>
+__host__ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
 }
-// rows 3..5 of B^T x for x = (x1 .. x5)  (x0 does not enter):  -2x1 - x2 + 2x3 + x4 | 2x1 - x2 - 2x3 + x4 | 4x1 - 5x3 + x5
-__host__ __device__ __forceinline__ void bt_hi(const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 x5, f32x2& o3,
-                                      f32x2& o4, f32x2& o5) {
-    const f32x2 c4 = splat<f32x2>(4.f), c2 = splat<f32x2>(2.f), m2 = splat<f32x2>(-2.f), m5 = splat<f32x2>(-5.f);
-    const f32x2 c = psub4(x4, x2), e = psub4(x3, x1);
-    o3 = pk_fma(c2, e, c);
-    o4 = pk_fma(m2, e, c);
-    o5 = pk_fma(c4, x1, pk_fma(m5, x3, x5));
+template <int N, typename F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// TAG only changes the symbol name (1 = first / last layer of a network) so profiler statistics of the body layers stay clean
+// ONE packed operation (K = 0..5) of half a 1-D input transform: LO: rows 0..2 of B^T x from (x0..x4) = i0..i4; else rows 3..5
+// from (x1..x5) = i0..i4.  ta, tb carry the two intermediates between the operations of one half.
+template <bool LO, int K>
+__host__ __device__ __forceinline__ void half_op(const f32x2 i0, const f32x2 i1, const f32x2 i2, const f32x2 i3, const f32x2 i4,
+                                                 f32x2& o0, f32x2& o1, f32x2& o2, f32x2& ta, f32x2& tb, const f32x2 m5) {
+    if constexpr (LO) {                 // 4x0 - 5x2 + x4 | (x4 - 4x2) + (x3 - 4x1) | (x4 - 4x2) - (x3 - 4x1)
+        if constexpr (K == 0) ta = fma_k(i2, i4, m5);
+        if constexpr (K == 1) o0 = fma_p4(i0, ta);
+        if constexpr (K == 2) ta = fma_m4(i2, i4);
+        if constexpr (K == 3) tb = fma_m4(i1, i3);
+        if constexpr (K == 4) o1 = padd(ta, tb);
+        if constexpr (K == 5) o2 = psub4(ta, tb);
+    } else {                            // (x4 - x2) + 2(x3 - x1) | (x4 - x2) - 2(x3 - x1) | 4x1 - 5x3 + x5
+        if constexpr (K == 0) ta = psub4(i3, i1);
+        if constexpr (K == 1) tb = psub4(i2, i0);
+        if constexpr (K == 2) o0 = fma_p2(tb, ta);
+        if constexpr (K == 3) o1 = fma_m2(tb, ta);
+        if constexpr (K == 4) ta = fma_k(i2, i4, m5);
+        if constexpr (K == 5) o2 = fma_p4(i0, ta);
+    }
+}
+
 // DIAG (timing experiments only, wrong results): bit0 no transform, 1 no raw staging, 2 no U DMA, 3 no barriers, 4 no MFMAs, 5 no epilogue
 template <int TAG, int DIAG = 0>
 __global__ void __launch_bounds__(W4_THREADS, 2)
@@ -138,6 +200,17 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long* const stamp_base = (DIAG & 64) ? a.dbg + (size_t)blockIdx.x * 128 : nullptr;
+    (void)stamp_base;
+    W4_STAMP(0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // De-synchronise the two workgroups of a CU: all workgroups live equally long, so the pair that starts together would also
+    // load its first tiles together and transform / store its outputs together, for every generation of the grid, with the matrix
+    // pipes idle meanwhile.  The workgroups that fill the second slot of the CUs start late by a part of a workgroup life once,
+    // in the first generation; the offset then carries through the launch.
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int tg = wvu >> 1, xh = wvu & 1;             // tile row of the workgroup, half of the transformed rows
     const int tn = lane & 15, q = lane >> 4;           // tile along x, channel pair
     const int H = a.H, W = a.W;
@@ -210,13 +283,7 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         if (!last) w_g += w_step;
     };
 
-    f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]
-#pragma unroll
-    for (int x = 0; x < 3; ++x)
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[x][nu][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]; zeroed behind the first requests
 
     // per-lane LDS offsets (floats): patch of tile (tg, tn), channel pair q (half-pixel plane q >> 1, 8 bytes (q & 1) of the
     // unit); U vectors of half xh
@@ -225,88 +292,178 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     const int a_off = xh * (9 * 256) + lane * 4;                                             // + v * 256
 
     const int CG = a.CGin;
-    f32x2 V[3][6];                                      // own three rows of B^T d B, x the channel pair
-    if constexpr (DIAG != 0) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-#pragma unroll
-            for (int nu = 0; nu < 6; ++nu) V[x][nu] = f32x2{(float)lane, 1.f};
-    }
-    // B^T d B, own rows: column pass one patch column at a time (five 8-byte reads), then the row pass in place
-    auto transform_half = [&](const float* rawp, auto LO) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int bo = (c < 4 ? b_off0 : b_off1) + c * 4;
-            f32x2 x[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) x[r] = *(const f32x2*)(rawp + bo + r * (W4_RSL * 4));
-            if constexpr (decltype(LO)::value) bt_lo(x[0], x[1], x[2], x[3], x[4], V[0][c], V[1][c], V[2][c]);
-            else bt_hi(x[0], x[1], x[2], x[3], x[4], V[0][c], V[1][c], V[2][c]);
+    // one vector of the k-step slab, stored by the packer in the order the k-step walks its accumulators (see pack_wino4_kernel)
+    auto u_vec = [&](const float* ucur, int pos) { return *(const f32x4*)(ucur + a_off + pos * 256); };
+    // the four MFMAs of one U vector -- positions (x, 2np), (x, 2np+1) x the two output-channel halves, k-step J -- and the four
+    // packed vector operations of the input transform that go with it (ops(P, i), P = the vector's number in the k-step).
+    // W4_VBLK = how the vector operations are placed: 1 = one behind each MFMA, 4 = four behind each vector's MFMAs, 12 = twelve
+    // behind every third vector.  Two waves on a SIMD interleave best 1 : 1 (1.7 cycles of the matrix pipe per packed operation
+    // against 3.2 in blocks of eight, tools/probes/mfma_valu_coissue.py), but a wave's own vector instruction waits for its own
+    // MFMA to finish (46 cycles per MFMA + operation for a wave alone on its SIMD), and the arbiter serves the OLDER wave first:
+    // the older workgroup of a CU runs like a lone one and the younger fills the gaps (tools/probes/wino4_stamps.py), so what
+    // counts is the lone wave's pace -- fewer, larger blocks.
+#ifndef W4_VBLK
+#define W4_VBLK 1
+#endif
+    auto quad = [&](const f32x4 u, const f32x2 (&Vr)[6], f32x4 (&ac)[6][2], auto NP, auto J, auto P, auto&& ops) {
+        constexpr int np = decltype(NP)::value, j = decltype(J)::value, pos = decltype(P)::value;
+        const float b0 = Vr[2 * np][j], b1 = Vr[2 * np + 1][j];
+        auto op = [&](auto Q, auto I) { ops(Q, I); };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+        if (!(DIAG & 16)) ac[2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b0, ac[2 * np][0], 0, 0, 0);
+        if constexpr (W4_VBLK == 1) op(P, C0{});
+        if (!(DIAG & 16)) ac[2 * np + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], b1, ac[2 * np + 1][0], 0, 0, 0);
+        if constexpr (W4_VBLK == 1) op(P, C1{});
+        if (!(DIAG & 16)) ac[2 * np][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], b0, ac[2 * np][1], 0, 0, 0);
+        if constexpr (W4_VBLK == 1) op(P, C2{});
+        if (!(DIAG & 16)) ac[2 * np + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], b1, ac[2 * np + 1][1], 0, 0, 0);
+        if constexpr (W4_VBLK == 1) op(P, C3{});
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if constexpr (W4_VBLK == 4) { op(P, C0{}); op(P, C1{}); op(P, C2{}); op(P, C3{}); }
+        if constexpr (W4_VBLK == 12 && pos % 3 == 2) {
+            static_for<3>([&](auto QQ) {
+                using Q = std::integral_constant<int, pos - 2 + decltype(QQ)::value>;
+                op(Q{}, C0{}); op(Q{}, C1{}); op(Q{}, C2{}); op(Q{}, C3{});
+            });
         }
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            f32x2 o[6];
-            bt_lo(V[x][0], V[x][1], V[x][2], V[x][3], V[x][4], o[0], o[1], o[2]);
-            bt_hi(V[x][1], V[x][2], V[x][3], V[x][4], V[x][5], o[3], o[4], o[5]);
-#pragma unroll
-            for (int nu = 0; nu < 6; ++nu) V[x][nu] = o[nu];
-        }
-    };
-    auto transform = [&](const float* rawp) {
-        if (DIAG & 1) return;
-        if (xh == 0) transform_half(rawp, std::true_type{});
-        else transform_half(rawp, std::false_type{});
-    };
-    // the 36 MFMAs of one k-step: nine U vectors, each the four fragments (nu = 2np, 2np+1) x (half 0, 1) of one own row
-    auto mfma_step = [&](const float* ucur, int j) {
-        if (DIAG & 16) return;
-        f32x4 af[3];
-        af[0] = *(const f32x4*)(ucur + a_off);
-        af[1] = *(const f32x4*)(ucur + a_off + 256);
-#pragma unroll
-        for (int v = 0; v < 9; ++v) {
-            if (v + 2 < 9) af[(v + 2) % 3] = *(const f32x4*)(ucur + a_off + (v + 2) * 256);
-            const f32x4 u = af[v % 3];
-            const int x = v / 3, np = v % 3;
-            const float b0 = j ? V[x][2 * np][1] : V[x][2 * np][0], b1 = j ? V[x][2 * np + 1][1] : V[x][2 * np + 1][0];
-            acc[x][2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b0, acc[x][2 * np][0], 0, 0, 0);
-            acc[x][2 * np + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], b1, acc[x][2 * np + 1][0], 0, 0, 0);
-            acc[x][2 * np][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], b0, acc[x][2 * np][1], 0, 0, 0);
-            acc[x][2 * np + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], b1, acc[x][2 * np + 1][1], 0, 0, 0);
-        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (W4_VBLK != 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     };
 
-    {   // prologue: raw tile of group 0, U of k-step 0
-        issue_raw(raw_lds, CG <= 1);
-        issue_u(u_lds, false);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    for (int g = 0; g < CG; ++g) {
-        float* const rcur = raw_lds + (g & 1) * W4_RAW;
-        float* const rnext = raw_lds + ((g & 1) ^ 1) * W4_RAW;
-        // ---- k-step (g, 0).  Behind the last barrier every wave has finished k-step 2g-1 and the transform of group g-1:
-        // U of k-step 2g+1 -> its buffer, raw tile of group g+1 -> the other tile buffer (two k-steps ahead of its use)
-        issue_u(u_lds + W4_SLAB, 2 * g + 2 >= 2 * CG);
-        issue_raw(rnext, g + 2 >= CG);
-        transform(rcur);
+    // The K loop for one transform flavour (LO: this wave owns the rows 0..2 of the transformed patch, else the rows 3..5).
+    //   T  = own rows of the column pass B^T d of the NEXT group's patch, formed during k-step (g, 1), one patch-column pair per
+    //        third of its MFMAs (the k-step walks its accumulators column-pair by column-pair, so the V entries it has finished
+    //        with make room);
+    //   V  = own rows of B^T d B, formed from T by the row pass during k-step (g, 0), one row per third of its MFMAs (that k-step
+    //        walks row by row; only the first row's pass runs ahead of the MFMAs).
+    auto k_loop = [&](auto LO) {
+        constexpr bool lo = decltype(LO)::value;
+        f32x2 T[3][6], V[3][6];
+        f32x2 ta = {0.f, 0.f}, tb = {0.f, 0.f};
+        const f32x2 m5 = {-5.f, -5.f};
+        if constexpr (DIAG != 0) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) T[x][nu] = V[x][nu] = f32x2{(float)lane, 1.f};
+        }
+        // own five rows of patch column c of the tile in rawp
+        auto load_col = [&](const float* rawp, int c, f32x2 (&x)[5]) {
+            const int bo = (c < 4 ? b_off0 : b_off1) + c * 4;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) x[r] = *(const f32x2*)(rawp + bo + r * (W4_RSL * 4));
+        };
+        // operation K (0..5) of the column pass of one patch column: x = own five patch rows -> own three rows of B^T d
+        auto col_op = [&](const f32x2 (&x)[5], f32x2& o0, f32x2& o1, f32x2& o2, auto K) {
+            if (DIAG & 1) return;
+            half_op<lo, decltype(K)::value>(x[0], x[1], x[2], x[3], x[4], o0, o1, o2, ta, tb, m5);
+        };
+        // operation K (0..11) of the row pass of own row r: T[r][0..5] -> V[r][0..5]
+        auto row_op = [&](auto R, auto K) {
+            if (DIAG & 1) return;
+            constexpr int r = decltype(R)::value, k = decltype(K)::value;
+            if constexpr (k < 6) half_op<true, k>(T[r][0], T[r][1], T[r][2], T[r][3], T[r][4], V[r][0], V[r][1], V[r][2], ta, tb, m5);
+            else half_op<false, k - 6>(T[r][1], T[r][2], T[r][3], T[r][4], T[r][5], V[r][3], V[r][4], V[r][5], ta, tb, m5);
+        };
+
+        {   // prologue: raw tiles of groups 0 and 1, U of k-step 0; column pass of group 0
+            issue_raw(raw_lds, CG <= 1);
+            issue_u(u_lds, false);
+            issue_raw(raw_lds + W4_RAW, CG <= 2);
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-        mfma_step(u_lds, 0);
-        // bare s_barrier: __syncthreads() is a fence too and would wait for the raw tile's LDS-DMA issued above.  What must have
-        // landed is U of k-step 2g+1 (every wave's own pieces; the raw pieces were issued behind them); own LDS reads are done.
-        if (DIAG & 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W4_IN_ITERS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W4_IN_ITERS) : "memory");
-        // ---- k-step (g, 1): U of k-step 2g+2 -> the buffer of k-step 2g
-        issue_u(u_lds, 2 * g + 3 >= 2 * CG);
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[x][nu][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-        mfma_step(u_lds + W4_SLAB, 1);
-        if (DIAG & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // raw tile of group g+1, U of k-step 2g+2
-    }
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W4_IN_ITERS) : "memory");
+            W4_STAMP(1);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                f32x2 x[5];
+                load_col(raw_lds, c, x);
+                static_for<6>([&](auto K) { col_op(x, T[0][c], T[1][c], T[2][c], K); });
+            }
+            W4_STAMP(2);
+        }
+        for (int g = 0; g < CG; ++g) {
+            float* const rcur = raw_lds + (g & 1) * W4_RAW;          // held group g (its column pass is done): free behind the next barrier
+            float* const rnext = raw_lds + ((g & 1) ^ 1) * W4_RAW;   // group g+1, requested one k-step ago
+            // ---- k-step (g, 0), row by row.  Behind the last barrier every wave has finished k-step 2g-1: U of k-step 2g+1 -> its buffer
+            issue_u(u_lds + W4_SLAB, 2 * g + 2 >= 2 * CG);
+            f32x4 af[3];
+            af[0] = u_vec(u_lds, 0);
+            af[1] = u_vec(u_lds, 1);
+            static_for<12>([&](auto K) { row_op(std::integral_constant<int, 0>{}, K); });
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            static_for<9>([&](auto P) {
+                constexpr int pos = decltype(P)::value, x = pos / 3, np = pos % 3;
+                if constexpr (pos + 2 < 9) af[(pos + 2) % 3] = u_vec(u_lds, pos + 2);
+                quad(af[pos % 3], V[x], acc[x], std::integral_constant<int, np>{}, std::integral_constant<int, 0>{}, P, [&](auto Q, auto I) {
+                    // vector Q = 3 x' + np' of the k-step carries the operations 4 np' .. 4 np' + 3 of the row pass of row x' + 1
+                    constexpr int qx = decltype(Q)::value / 3, qn = decltype(Q)::value % 3;
+                    if constexpr (qx < 2) row_op(std::integral_constant<int, qx + 1>{}, std::integral_constant<int, 4 * qn + decltype(I)::value>{});
+                });
+            });
+            // bare s_barrier (__syncthreads() is a fence too and would wait for every LDS-DMA in flight, whatever the count).  Landed
+            // by now: the raw tile of group g+1 and U of k-step 2g+1 (every wave's own pieces); own LDS reads are done.
+            if (g < 24) W4_STAMP(8 + 4 * g);
+            if (DIAG & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g < 24) W4_STAMP(9 + 4 * g);
+            // ---- k-step (g, 1), column pair by column pair, with the column pass of group g+1: U of k-step 2g+2 -> the buffer of
+            // k-step 2g, raw tile of group g+2 -> the buffer of group g (two k-steps ahead of its use)
+            issue_u(u_lds, 2 * g + 3 >= 2 * CG);
+            issue_raw(rcur, g + 3 >= CG);
+            const float* const ub = u_lds + W4_SLAB;
+            af[0] = u_vec(ub, 0);
+            af[1] = u_vec(ub, 1);
+            f32x2 xa[5], xb[5];                                      // own rows of the even / odd patch column of the current pair
+            load_col(rnext, 0, xa);
+            load_col(rnext, 1, xb);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            // 36 column-pass operations (column c: operations 6c .. 6c+5, even columns from xa, odd ones from xb), four under each U
+            // vector from the SECOND vector on -- the first vector's MFMAs cover the latency of the first patch reads -- and the last
+            // four behind the last vector.  T is free since the row passes of k-step (g, 0).
+            auto col_ops4 = [&](auto Q, auto I) {                                          // operation 4Q + I of the 36
+                constexpr int k = 4 * decltype(Q)::value + decltype(I)::value, c = k / 6;
+                if constexpr (c % 2 == 0) col_op(xa, T[0][c], T[1][c], T[2][c], std::integral_constant<int, k % 6>{});
+                else col_op(xb, T[0][c], T[1][c], T[2][c], std::integral_constant<int, k % 6>{});
+                // the next pair's patch values: xa is free after operation 6c+5 of an even column, xb after that of an odd one
+                if constexpr (k % 6 == 5 && c + 2 < 6) load_col(rnext, c + 2, c % 2 == 0 ? xa : xb);
+            };
+            static_for<9>([&](auto P) {
+                constexpr int pos = decltype(P)::value, np = pos / 3, x = pos % 3;
+                if constexpr (pos + 2 < 9) af[(pos + 2) % 3] = u_vec(ub, pos + 2);
+                quad(af[pos % 3], V[x], acc[x], std::integral_constant<int, np>{}, std::integral_constant<int, 1>{}, P, [&](auto Q, auto I) {
+                    if constexpr (W4_VBLK == 12) col_ops4(Q, I);                            // (whole column pairs behind their third of the MFMAs)
+                    else if constexpr (decltype(Q)::value > 0) col_ops4(std::integral_constant<int, decltype(Q)::value - 1>{}, I);
+                });
+            });
+            if constexpr (W4_VBLK != 12) static_for<4>([&](auto I) { col_ops4(std::integral_constant<int, 8>{}, I); });
+            if (g < 24) W4_STAMP(10 + 4 * g);
+            if (DIAG & 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W4_IN_ITERS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W4_IN_ITERS) : "memory");   // U of k-step 2g+2
+            if (g < 24) W4_STAMP(11 + 4 * g);
+        }
+    };
+    if (xh == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    W4_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetched last slab must not land in the exchange buffer)
     __syncthreads();
 
@@ -351,6 +508,7 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         else finish(std::false_type{});
     }
     __syncthreads();
+    W4_STAMP(4);
     const float* bias = a.wpk + (size_t)2 * a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
     (void)relu; (void)add_res; (void)mask; (void)bias;
@@ -410,6 +568,16 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[il][j]), r_out, off[il][j], 0, 0);
 #endif
     }
+    W4_STAMP(5);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((DIAG & 64) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_STAMP(6);                                       // stores acknowledged
+        if (tid == 0) a.dbg[(size_t)blockIdx.x * 128 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                                                           (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));      // XCC_ID, HW_ID
+        asm volatile("s_dcache_wb" ::: "memory");
+    }
+#endif
 }
 
 // U = G g G^T from the fp32 direct packing [cig][tap][CoutP][8]; one thread per slab element
@@ -419,13 +587,16 @@ __global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restric
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
         // slab element index: [xh 2][v 9][lane 64 = q*16 + tn][e 4] -> U_p[co = 32 cb + 16 (e >> 1) + tn][ci = 2 q + j],
-        // p = (xi = 3 xh + v / 3, nu = 2 (v % 3) + (e & 1)); slab index = (2 cig + j) * NCB + cb
+        // p = (xi = 3 xh + own row, nu = 2 np + (e & 1)), (own row, np) = (v / 3, v % 3) for j = 0 and (v % 3, v / 3) for j = 1;
+        // slab index = (2 cig + j) * NCB + cb
         const int el = (int)(i % W4_SLAB);
         const size_t sl = i / W4_SLAB;
         const int cb = (int)(sl % NCB), ks = (int)(sl / NCB);
         const int cig = ks >> 1, j = ks & 1;
         const int e = el & 3, tnl = (el >> 2) & 15, ql = (el >> 6) & 3, vv = (el >> 8) % 9, xhh = (el >> 8) / 9;
-        const int xi = 3 * xhh + vv / 3, nu = 2 * (vv % 3) + (e & 1), h = e >> 1;
+        // vector order = the order the k-step walks its accumulators: j = 0 row by row, j = 1 column pair by column pair
+        const int xl = j ? vv % 3 : vv / 3, npp = j ? vv / 3 : vv % 3;
+        const int xi = 3 * xhh + xl, nu = 2 * npp + (e & 1), h = e >> 1;
         const int co = cb * 32 + h * 16 + tnl, ci = 2 * ql + j;
         const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
@@ -439,6 +610,15 @@ __global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restric
 }
 
 static inline int round_up_w4(int v, int m) { return (v + m - 1) / m * m; }
+
+// SCIPNP_W4_STAGGER: start offset of the second workgroup slot in units of 8128 cycles (s_sleep 127); tuning knob
+static int wino4_stagger() {
+    static const int v = [] {
+        const char* e = getenv("SCIPNP_W4_STAGGER");
+        return e ? atoi(e) : 4;
+    }();
+    return v;
+}
 
 }  // namespace scipnp
 
@@ -476,13 +656,14 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     SCIPNP_REQUIRE(!(flags & 2) || residual, "flag bit1 needs residual");
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
     Wino4Args a;
-    a.in = in; a.wpk = packed_wino4; a.out = out; a.residual = residual; a.mask_src = mask_src;
+    a.in = in; a.wpk = packed_wino4; a.out = out; a.residual = residual; a.mask_src = mask_src; a.dbg = nullptr;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
     a.H = h; a.W = w;
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
     a.flags = flags;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.stagger = total >= 1024 ? wino4_stagger() : 0;
     const int tag = (flags & 0x100) ? 1 : 0;
     const void* fns[2] = {(const void*)conv3x3_c8w4_kernel<0>, (const void*)conv3x3_c8w4_kernel<1>};
     static LdsAttrOnce attr[2];
@@ -491,6 +672,66 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     if (tag) hipLaunchKernelGGL((conv3x3_c8w4_kernel<1>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
     else hipLaunchKernelGGL((conv3x3_c8w4_kernel<0>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
     return launch_status("conv3x3_c8w4_kernel");
+}
+
+/* The whole FFDNet pass with the layers that have an F(4x4,3x3) packing (packed_wino4[l] != NULL; NULL array: none) on
+ * scipnp_conv3x3_c8w4 and the others on scipnp_conv3x3_c8w. */
+int scipnp_ffdnet_forward_c8w4(const float* in_c8, float* out_c8, const float* const* packed_wino, const float* const* packed_wino4,
+                               int nb, int nc, float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8 && packed_wino && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
+    float* buf[2] = {scratch0, scratch1};
+    auto layer = [&](int l, const float* in, float* out, int cin, int cout, int flags) {
+        if (packed_wino4 && packed_wino4[l])
+            return scipnp_conv3x3_c8w4(in, packed_wino4[l], out, nullptr, nullptr, B, cin, cout, M, N, flags, s);
+        return scipnp_conv3x3_c8w(in, packed_wino[l], out, nullptr, nullptr, B, cin, cout, M, N, flags, s);
+    };
+    int rc = layer(0, in_c8, buf[0], 16, nc, 1 | 0x100);
+    if (rc) return rc;
+    int cur = 0;
+    for (int l = 1; l < nb - 1; ++l) {
+        rc = layer(l, buf[cur], buf[cur ^ 1], nc, nc, 1);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return layer(nb - 1, buf[cur], out_c8, nc, 16, 0x100);
+}
+
+/* DIAGNOSTIC instantiation with s_memtime stamps of wave 0 of every workgroup (128 words per workgroup; tools/probes/wino4_stamps.py):
+ * [0] entry, [1] first tiles / slab in LDS, [2] first column pass done, [8 + 4g + {0, 1, 2, 3}] k-step (g, 0) MFMAs issued | its
+ * barrier passed | k-step (g, 1) MFMAs issued | its barrier passed (g < 24), [3] loop left, [4] partial tiles exchanged,
+ * [5] stores issued, [6] stores acknowledged, [7] XCC_ID << 32 | HW_ID.  Results are the product kernel's. */
+int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                                int flags, unsigned long long* stamps, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in && packed_wino4 && out && stamps, "null pointer");
+    SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
+    SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
+    Wino4Args a;
+    a.in = in; a.wpk = packed_wino4; a.out = out; a.residual = nullptr; a.mask_src = nullptr; a.dbg = stamps;
+    a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
+    a.H = h; a.W = w;
+    a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
+    a.flags = flags & 1;
+    const long long total = (long long)a.ntx * a.nty * n * a.NCB;
+    SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.stagger = total >= 1024 ? wino4_stagger() : 0;
+    const dim3 grid((unsigned)total), block(W4_THREADS);
+    // flags bits 12.. select a stamped build with parts switched off (diag bits 0..2 of scipnp_conv3x3_c8w4_diag; wrong results)
+#define W4_STAMP_CASE(D)                                                                                                     \
+    case D: {                                                                                                                \
+        static LdsAttrOnce attr;                                                                                             \
+        if (int rc = attr.ensure((const void*)conv3x3_c8w4_kernel<0, 64 | D>, (size_t)160 * 1024, "conv3x3_c8w4 stamped")) return rc; \
+        hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 64 | D>), grid, block, lds_req, (hipStream_t)s, a);                       \
+        break;                                                                                                               \
+    }
+    // (experiment: SCIPNP_W4_ONE_PER_CU=1 asks for the whole LDS, i.e. a single resident workgroup per CU)
+    const size_t lds_req = getenv("SCIPNP_W4_ONE_PER_CU") ? (size_t)160 * 1024 : W4_LDS_BYTES;
+    switch ((flags >> 12) & 7) {
+        W4_STAMP_CASE(0) W4_STAMP_CASE(1) W4_STAMP_CASE(2) W4_STAMP_CASE(4) W4_STAMP_CASE(6) W4_STAMP_CASE(7)
+        default: SCIPNP_REQUIRE(false, "no stamped build for that mask");
+    }
+#undef W4_STAMP_CASE
+    return launch_status("conv3x3_c8w4_kernel<stamped>");
 }
 
 /* diagnostic: the same kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
@@ -502,13 +743,14 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "bad shape");
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
     Wino4Args a;
-    a.in = in; a.wpk = packed_wino4; a.out = out; a.residual = nullptr; a.mask_src = nullptr;
+    a.in = in; a.wpk = packed_wino4; a.out = out; a.residual = nullptr; a.mask_src = nullptr; a.dbg = nullptr;
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
     a.H = h; a.W = w;
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.stagger = total >= 1024 ? wino4_stagger() : 0;
     const dim3 grid((unsigned)total), block(W4_THREADS);
 #define W4_DIAG_CASE(D)                                                                                                    \
     case D: {                                                                                                              \

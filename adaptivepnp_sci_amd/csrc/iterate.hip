@@ -30,8 +30,8 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
                                   f32 ? nullptr : a->net_in_c8s, M, N, B, inv_rho, inv_tau, a->sigma, s);
     if (rc) return rc;
     if (f32) {
-        rc = scipnp_ffdnet_forward_c8w(a->net_in_c8, a->net_out_c8, a->packed_wino, a->nb, a->nc, (float*)a->scratch0,
-                                       (float*)a->scratch1, B, M, N, s);
+        rc = scipnp_ffdnet_forward_c8w4(a->net_in_c8, a->net_out_c8, a->packed_wino, a->packed_wino4, a->nb, a->nc,
+                                        (float*)a->scratch0, (float*)a->scratch1, B, M, N, s);
     } else {
         // the solve's own range-guard word for the launches of this call; the thread's binding is restored afterwards
         OverflowScope scope(a->overflow_word);

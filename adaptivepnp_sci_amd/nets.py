@@ -212,13 +212,15 @@ class FFDNetEngine:
         out_c8 = self.out_c8 if out_c8 is None else out_c8
         lib = _lib.load()
         _lib.require_gpu()
-        if self.packed_wino is not None:                  # the engine's own form: F(2x2,3x3) layers, one C call
+        if self.packed_wino is not None:                  # the engine's own form: Winograd layers, one C call
             ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed_wino])
-            rc = lib.scipnp_ffdnet_forward_c8w(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, self.nb,
-                                               self.nc, C.c_void_p(self.scratch[0].data_ptr()),
-                                               C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
-                                               _lib.stream_ptr())
-            _lib.check(rc, 'scipnp_ffdnet_forward_c8w')
+            p4 = (C.c_void_p * self.nb)(*[(p.f4.data_ptr() if (p.f4 is not None and ops.wino_f4_enabled()) else None)
+                                         for p in self.packed_wino])
+            rc = lib.scipnp_ffdnet_forward_c8w4(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, p4, self.nb,
+                                                self.nc, C.c_void_p(self.scratch[0].data_ptr()),
+                                                C.c_void_p(self.scratch[1].data_ptr()), self.B, self.M, self.N,
+                                                _lib.stream_ptr())
+            _lib.check(rc, 'scipnp_ffdnet_forward_c8w4')
             return out_c8
         rc = lib.scipnp_ffdnet_forward(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), self._ptrs,
                                        self.nb, self.nc, C.c_void_p(self.scratch[0].data_ptr()),

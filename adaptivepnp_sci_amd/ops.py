@@ -389,7 +389,7 @@ def wino_f4_enabled():
     """SCIPNP_WINO_F4=0 keeps every fp32 Winograd layer on the F(2x2,3x3) kernel; default: layers with at least 32 input and
     output channels run as F(4x4,3x3) (csrc/conv_wino4.hip)."""
     import os
-    return os.environ.get('SCIPNP_WINO_F4', '0') == '1'
+    return os.environ.get('SCIPNP_WINO_F4', '1') != '0'
 
 
 def wino_f4_shape(Cin, Cout):

@@ -318,6 +318,7 @@ def executed_flop(family, n, cin, cout, h, w, flags):
       conv3x3_c8_kernel  (direct fp32, v_mfma_f32_32x32x2_f32): 2*9*Cin*CoutP FLOP per output pixel, CoutP = Cout rounded to 32;
       conv3x3_c8w_kernel (fp32 Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32): 2*16*Cin*CoutP per 2x2 output tile (CoutP = 16
                          for layers of <= 16 output channels, which multiply one half of the 32-channel block);
+      conv3x3_c8w4_kernel (fp32 Winograd F(4x4,3x3), same instruction): 2*36*Cin*CoutP per 4x4 output tile;
       conv3x3_c8s_kernel (split-fp16, v_mfma_f32_32x32x16_f16): 14 MFMAs of 32768 FLOP per (8 in-ch x 9 taps x 32 out-ch x
                          32 pixels) = 56 FLOP per (in-ch, out-ch, output pixel)."""
     stride2 = bool(flags & 4)
@@ -327,6 +328,8 @@ def executed_flop(family, n, cin, cout, h, w, flags):
         if cout <= 16:
             coutp = 16
         return 2.0 * 16 * cin * coutp * ((ho + 1) // 2) * ((wo + 1) // 2) * n, ho * wo
+    if family == 'conv3x3_c8w4_kernel':
+        return 2.0 * 36 * cin * coutp * ((ho + 3) // 4) * ((wo + 3) // 4) * n, ho * wo
     if family == 'conv3x3_c8s_kernel':
         return 56.0 * cin * coutp * ho * wo * n, ho * wo
     return 2.0 * 9 * cin * coutp * ho * wo * n, ho * wo
@@ -384,19 +387,23 @@ def time_precision(prec, args, ctx):
     from adaptivepnp_sci_amd import shard
     from adaptivepnp_sci_amd.solver import AdmmRun
     dist, rank, world, dev, cdev = ctx['dist'], ctx['rank'], ctx['world'], ctx['dev'], ctx['coll_dev']
-    direct = prec == 'f32_direct'
-    old_form = os.environ.get('SCIPNP_F32_CONV')
-    if direct:                                   # the fp32 pass in direct form (csrc/conv.hip) instead of Winograd
-        os.environ['SCIPNP_F32_CONV'] = 'direct'
+    direct, f2 = prec == 'f32_direct', prec == 'f32_f2'
+    # the fp32 pass in direct form (csrc/conv.hip), or with its body layers as Winograd F(2x2,3x3) instead of F(4x4,3x3)
+    override = {'SCIPNP_F32_CONV': 'direct'} if direct else {'SCIPNP_WINO_F4': '0'} if f2 else {}
+    saved = {k: os.environ.get(k) for k in override}
+    os.environ.update(override)
     try:
         run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'],
-                      model=ctx['net'], conv_precision='f32' if direct else prec)
+                      model=ctx['net'], conv_precision='f32' if (direct or f2) else prec)
+        if f2:                                   # (the kernel choice is read at launch time: keep it for this run's launches)
+            for pw in run.eng.packed_wino:
+                pw.f4 = None
     finally:
-        if direct:
-            if old_form is None:
-                os.environ.pop('SCIPNP_F32_CONV', None)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
             else:
-                os.environ['SCIPNP_F32_CONV'] = old_form
+                os.environ[k] = v
 
     def barrier():
         if dist is not None:
@@ -455,11 +462,18 @@ def time_precision(prec, args, ctx):
     return rec, run, mosaic, psnr
 
 
+def roofline_form(f32_form):
+    """the fp32 form the FFDNet BODY layers run in: 'winograd' splits into F(4x4,3x3) (default) and F(2x2,3x3) (SCIPNP_WINO_F4=0)"""
+    from adaptivepnp_sci_amd import ops
+    return 'winograd_f4' if (f32_form == 'winograd' and ops.wino_f4_enabled()) else f32_form
+
+
 def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_form='winograd'):
     """Roofline of the dominant kernel.  `achieved` / `frac` count the multiply-adds of the algorithm the kernel RUNS, per
     launch, over the event-timed launch duration -- for the Winograd kernel the 16 products per 2x2 tile and channel pair of
     F(2x2,3x3) (= 1/2.25 of the direct form's), so `frac` is the matrix pipes' own duty and can never exceed 1; the
-    direct-form-equivalent rate is kept under `direct_form_equivalent_TFLOPs`.  For the split-fp16 kernel, which EXECUTES
+    direct-form-equivalent rate is kept under `direct_form_equivalent_TFLOPs`; F(4x4,3x3) (the default fp32 form of the
+    body layers, csrc/conv_wino4.hip) runs 36 products per 4x4 tile = 1/4 of the direct form's.  For the split-fp16 kernel, which EXECUTES
     3.11x the fp32 convolution's products as fp16 products, `frac` counts the fp32 convolution's FLOPs (the smaller figure)
     and the pipes' duty rides in `matrix_pipe_frac_of_peak`."""
     direct_rate = BODY_FLOP_PER_LAUNCH / body_launch_s
@@ -469,10 +483,17 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
                  'split-fp16: 3 exact fp16 products per fp32 product on v_mfma_f32_32x32x16_f16, fp32 accumulate)')
         peak_meas = measured.get('mfma_f16_32x32x16_2wave_per_simd_TFLOPs')
         tr = _pick(traffic, 'conv3x3_c8s_kernel<3, 0')
+    elif f32_form == 'winograd_f4':
+        # F(4x4,3x3): 36 products per 4x4 output tile and channel pair instead of 144 -- the matrix pipes execute 1/4 of the
+        # direct form's multiply-adds, every one an exact fp32 product on v_mfma_f32_16x16x4_f32
+        peak, exec_ratio = PEAK_FP32_MFMA, 1.0 / 4.0
+        kname = ('conv3x3_c8w4_kernel<TAG=0> (FFDNet body layer 96->96, 8 frames of 256x256; fp32 Winograd F(4x4,3x3), '
+                 'v_mfma_f32_16x16x4_f32, input/output transforms fused into the kernel, tiles and weight slabs by LDS-DMA)')
+        peak_meas = measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
+        tr = _pick(traffic, 'conv3x3_c8w4_kernel<0, 0')
     elif f32_form == 'winograd':
         # F(2x2,3x3): 16 products per 2x2 output tile and channel pair instead of 36 -- the matrix pipes execute 1/2.25 of
-        # the ALGORITHMIC (direct-form) multiply-adds, every one an exact fp32 product on v_mfma_f32_16x16x4_f32; `achieved`
-        # counts algorithmic FLOPs as the contract asks, so `frac` can exceed 1 -- the pipes' own duty is matrix_pipe_frac_of_peak
+        # the direct form's multiply-adds, every one an exact fp32 product on v_mfma_f32_16x16x4_f32
         peak, exec_ratio = PEAK_FP32_MFMA, 1.0 / 2.25
         kname = ('conv3x3_c8w_kernel<TAG=0,NW=4> (FFDNet body layer 96->96, 8 frames of 256x256; fp32 Winograd F(2x2,3x3), '
                  'v_mfma_f32_16x16x4_f32, input/output transforms fused into the kernel)')
@@ -487,7 +508,8 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
     if tr is None:                                   # no live PMC pass: the committed profile, named
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):
-            key = 'f32_direct' if (prec == 'f32' and f32_form == 'direct') else prec
+            key = ('f32_direct' if (prec == 'f32' and f32_form == 'direct') else
+                   'f32_winograd_f4' if (prec == 'f32' and f32_form == 'winograd_f4') else prec)
             tr = json.load(open(tpath)).get(key, {}).get('hbm_bytes_per_launch')
             src = f'committed profile profiles/pmc_traffic.json (live PMC pass unavailable: {traffic_src})'
     flop = BODY_FLOP_PER_LAUNCH * min(1.0, exec_ratio)       # the algorithm run: never more than the pipes execute
@@ -498,7 +520,7 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
             'flop_per_launch': flop, 'avg_launch_ms': body_launch_s * 1e3,
             'direct_form_flop_per_launch': BODY_FLOP_PER_LAUNCH, 'direct_form_equivalent_TFLOPs': direct_rate / 1e12,
             'denoiser_direct_form_flop_per_iter': FFDNET_FLOP_PER_ITER,
-            # executed matrix FLOPs over the direct form's: 1/2.25 (Winograd), 1 (direct), 3.11 (split-fp16 products)
+            # executed matrix FLOPs over the direct form's: 1/4 (Winograd F(4x4)), 1/2.25 (F(2x2)), 1 (direct), 3.11 (split-fp16)
             'mfma_flop_executed_over_direct_form': exec_ratio,
             'matrix_pipe_frac_of_peak': direct_rate * exec_ratio / peak,
             # the ceiling MEASURED in this invocation with a register-resident MFMA loop on random operands (no memory traffic)
@@ -864,7 +886,7 @@ def fixed_total_mode(args, ctx, net, wdesc):
         'denoiser_direct_form_TFLOPs': flop_px * px * args.steps / dt / 1e12,
         'roofline': None if body_s is None else roofline_record('f32', body_s * (H // 2) * (W // 2) * B /
                                                                  ((ushape[0] // 2) * (ushape[1] // 2) * ushape[2]),
-                                                                 None, 'not collected in this mode', {}, ctx['f32_form']),
+                                                                 None, 'not collected in this mode', {}, roofline_form(ctx['f32_form'])),
         'cpu_baseline': None, 'cpu_baseline_note': 'reported by the default mode (python bench.py), N = 1',
     }
     if tiled:
@@ -981,6 +1003,9 @@ def main():
     passes = list(PRECISIONS[:1] if args.no_fast_path else PRECISIONS)
     if f32_form == 'winograd' and not args.no_fast_path:
         passes.append('f32_direct')
+        from adaptivepnp_sci_amd import ops as _o
+        if _o.wino_f4_enabled():
+            passes.append('f32_f2')
     for prec in passes:
         rec, run, mosaic, psnr = time_precision(prec, args, ctx)
         recs[prec] = rec
@@ -1011,7 +1036,7 @@ def main():
             # of a whole solver call with the reference driver's 25-iteration schedule) is filled in below at N = 1
             'frame_iterations_per_s': head['frame_iterations_per_s'],
             'frames_per_s': None,
-            'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured, f32_form),
+            'roofline': roofline_record('f32', head['body_launch_s'], traffic, traffic_src, measured, roofline_form(f32_form)),
             'phi_step': phi_record(last_run, head['phi_s'], traffic, traffic_src, measured, dev),
             'measured_peaks': measured,
             'preheat': f'{args.preheat} untimed denoiser passes before the warm-up steps (clock ramp after the TV phase)',
@@ -1039,6 +1064,16 @@ def main():
                 'roofline': roofline_record('f32', fd['body_launch_s'], traffic, traffic_src, measured, 'direct'),
                 'parity_vs_headline': {'rel_l2_final_iterate': rel_l2(gpu_out['f32_direct'][0], gpu_out['f32'][0]),
                                        'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_out['f32_direct'][1]) -
+                                                                                   np.array(gpu_out['f32'][1]))))}}
+        if 'f32_f2' in recs:
+            f2 = recs['f32_f2']
+            line['f32_winograd_f2x2'] = {
+                'dtype': 'f32', 'note': 'the same fp32 pass with the body layers as Winograd F(2x2,3x3) (SCIPNP_WINO_F4=0; the '
+                                        'headline form until round 3): 4 instead of 2.25 multiply-adds per output',
+                'value': f2['value'], 'unit': 'ADMM iterations/s', 'ms_per_step': f2['ms_per_step'],
+                'roofline': roofline_record('f32', f2['body_launch_s'], traffic, traffic_src, measured, 'winograd'),
+                'parity_vs_headline': {'rel_l2_final_iterate': rel_l2(gpu_out['f32_f2'][0], gpu_out['f32'][0]),
+                                       'max_abs_psnr_diff_db': float(np.max(np.abs(np.array(gpu_out['f32_f2'][1]) -
                                                                                    np.array(gpu_out['f32'][1]))))}}
         if world == 1:
             # SURVEY 8(d)'s other reading of the metric: whole solver calls with the reference driver's schedule

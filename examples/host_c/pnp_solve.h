@@ -72,6 +72,7 @@ static void pnp_solve(pnp_solve_t* job) {
     /* ---- FFDNet weights: pack on the host, upload (fp32 form: the Winograd-domain weights are derived on the device) */
     const void** packed = malloc(nb * sizeof(void*));
     const float** packed_w = malloc(nb * sizeof(float*));
+    const float** packed_w4 = calloc(nb, sizeof(float*));      /* F(4x4,3x3) packings of the body layers (NULL: F(2x2,3x3)) */
     for (int l = 0; l < nb; ++l) {
         int32_t dims[2];
         rd(dims, sizeof dims, f);
@@ -87,6 +88,11 @@ static void pnp_solve(pnp_solve_t* job) {
             float* pw = dmalloc(scipnp_conv3x3_wino_packed_floats(Cin, Cout) * 4);
             SCICHK(scipnp_pack_conv3x3_wino(pd, pw, Cin, Cout, st));
             packed_w[l] = pw;
+            if (Cin >= 32 && Cout >= 32) {               /* the 96 -> 96 layers: 2.25 multiply-adds per output instead of 4 */
+                float* p4 = dmalloc(scipnp_conv3x3_wino4_packed_floats(Cin, Cout) * 4);
+                SCICHK(scipnp_pack_conv3x3_wino4(pd, p4, Cin, Cout, st));
+                packed_w4[l] = p4;
+            }
             packed[l] = NULL;
             free(ph);
         } else {
@@ -113,7 +119,7 @@ static void pnp_solve(pnp_solve_t* job) {
     a.theta = theta; a.b = b; a.x = x; a.Phi = Phi; a.y = y; a.Phisum = Phisum;
     a.w = dmalloc(RGB * 4); a.x_rgb = dmalloc(RGB * 4); a.out_rgb = NULL;
     a.net_out_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4);
-    if (f32) { a.net_in_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4); a.packed_wino = packed_w; }
+    if (f32) { a.net_in_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4); a.packed_wino = packed_w; a.packed_wino4 = packed_w4; }
     else { a.net_in_c8s = dmalloc((size_t)B * 2 * 2 * M * N * 8 * 2); a.packed_split = packed; }
     a.nb = nb; a.nc = nc;
     a.scratch0 = dmalloc((size_t)B * nc * M * N * 4); a.scratch1 = dmalloc((size_t)B * nc * M * N * 4);

@@ -368,6 +368,19 @@ int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int 
 int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, const float* residual,
                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* The whole FFDNet-colour pass as ONE call with mixed Winograd forms: layer l runs on scipnp_conv3x3_c8w4 when
+ * packed_wino4 != NULL and packed_wino4[l] != NULL (the 96 -> 96 body layers, packed by scipnp_pack_conv3x3_wino4), else on
+ * scipnp_conv3x3_c8w with packed_wino[l]; other arguments as scipnp_ffdnet_forward_c8w. */
+int scipnp_ffdnet_forward_c8w4(const float* in_c8, float* out_c8, const float* const* packed_wino, const float* const* packed_wino4,
+                               int nb, int nc, float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
+
+/* DIAGNOSTIC instantiation of scipnp_conv3x3_c8w4 with s_memtime stamps of wave 0 of every workgroup, written by scalar stores
+ * (128 words per workgroup, grid = ceil(w/64)*ceil(h/8)*n*ceil(Cout/32); tools/probes/wino4_stamps.py): [0] entry, [1] first
+ * tiles / slab in LDS, [2] first column pass done, [8 + 4g + {0,1,2,3}] k-step (g,0) MFMAs issued | its barrier passed | k-step
+ * (g,1) MFMAs issued | its barrier passed (g < 24), [3] loop left, [4] partial tiles exchanged, [5] stores issued, [6] stores
+ * acknowledged, [7] XCC_ID << 32 | HW_ID.  No product path calls it; the product kernel executes no stamp. */
+int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                                int flags, unsigned long long* stamps, scipnp_stream_t s);
 /* diagnostic: the F(4x4) kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
  * diag: bit0 no input transform, bit1 no raw-tile staging, bit2 no U LDS-DMA, bit3 no barriers in the K loop, bit4 no MFMAs,
  * bit5 no output transform / stores */
@@ -495,6 +508,9 @@ typedef struct {
     int* overflow_word;                 /* range-guard word of THIS solve (device int, zeroed by the caller) */
     scipnp_stream_t side_stream;        /* the caller's second stream for half of the frames of the network pass ... */
     void *side_fork_event, *side_join_event;   /* ... and its two hipEvent_t (as scipnp_ffdnet_forward_c8s_2s) */
+    /* fp32 path only (NULL: every layer on the F(2x2,3x3) kernel): per-layer F(4x4,3x3) packings, NULL entries for the layers
+     * that keep packed_wino[l] (scipnp_ffdnet_forward_c8w4) */
+    const float* const* packed_wino4;
 } scipnp_twostage_ffdnet_args;
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
 

@@ -1060,6 +1060,67 @@ def test_conv3x3_winograd_random_shapes(ops):
         assert rel_l2(ops.from_c8(got).cpu().numpy(), direct.numpy()) < 2e-6
 
 
+def test_conv3x3_winograd_f4_random_shapes(ops):
+    """csrc/conv_wino4.hip -- fp32 Winograd F(4x4,3x3): seeded sweep of small / ragged / thin shapes (tiles cut by every border,
+    one and many channel groups, co-blocks with padding channels, several frames) and every epilogue against float64 and the
+    direct fp32-MFMA kernel.  Measured 0.7e-6 .. 1.7e-6 relative L2 per layer on zero-mean random data (the transforms' 4, 5, 8
+    multipliers; F(2x2): 1e-7 .. 2.6e-7), 7.7e-7 on the final iterate of the 28-iteration headline run against the oracle."""
+    rng = np.random.default_rng(44)
+    g = torch.Generator().manual_seed(44)
+    shapes = [(1, 8, 32, 8, 64), (2, 96, 96, 20, 70), (1, 16, 96, 37, 129), (3, 64, 24, 5, 7), (1, 40, 72, 64, 64), (1, 8, 8, 1, 1),
+              (2, 32, 32, 9, 65), (1, 96, 96, 66, 130)]
+    for _ in range(24):
+        shapes.append((int(rng.integers(1, 4)), 8 * int(rng.integers(1, 13)), 8 * int(rng.integers(1, 14)),
+                       int(rng.integers(1, 41)), int(rng.integers(1, 150))))
+    for n, cin, cout, h, w in shapes:
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        bias = torch.randn(cout, generator=g)
+        res, fwd = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+        p4 = ops.pack_conv3x3_wino4(packed, cin, cout)
+        xc, rc, fc = ops.to_c8(x.cuda()), ops.to_c8(res.cuda()), ops.to_c8(fwd.cuda())
+        got = ops.from_c8(ops.conv3x3_c8w4(xc, p4, cout)).cpu()
+        err = rel_l2(got.numpy(), ref.numpy())
+        assert err < 4e-6, (n, cin, cout, h, w, err)
+        direct = ops.from_c8(ops.conv3x3_c8(xc, packed, cout)).cpu()
+        assert rel_l2(got.numpy(), direct.numpy()) < 4e-6
+        got = ops.from_c8(ops.conv3x3_c8w4(xc, p4, cout, relu=True, residual=rc, head=True)).cpu()
+        assert rel_l2(got.numpy(), torch.relu(ref + res.double()).numpy()) < 4e-6, (n, cin, cout, h, w)
+        got = ops.from_c8(ops.conv3x3_c8w4(xc, p4, cout, mask_src=fc, residual=rc)).cpu()
+        want = torch.where(fwd > 0, ref + res.double(), torch.zeros_like(ref))
+        assert rel_l2(got.numpy(), want.numpy()) < 4e-6, (n, cin, cout, h, w)
+
+
+def test_conv3x3_winograd_f4_is_what_the_engines_run(ops, monkeypatch):
+    """conv3x3_c8w takes the F(4x4,3x3) kernel for a layer packed by pack_conv3x3_wino_both when the shape has one (at least
+    32 input and output channels, plain store); SCIPNP_WINO_F4=0 at pack or launch time keeps the F(2x2,3x3) kernel; the FFDNet
+    engine's C entry (scipnp_ffdnet_forward_c8w4) runs the same launches as its Python layer loop"""
+    g = torch.Generator().manual_seed(45)
+    x = ops.to_c8(torch.randn(2, 96, 24, 40, generator=g).cuda())
+    packed = ops.pack_conv3x3(torch.randn(96, 96, 3, 3, generator=g) * 0.05, torch.randn(96, generator=g), Cin=96, Cout=96, device='cuda')
+    monkeypatch.setenv('SCIPNP_WINO_F4', '1')
+    both = ops.pack_conv3x3_wino_both(packed, 96, 96)
+    assert both.f4 is not None
+    ops.LAUNCH_LOG = log = []
+    try:
+        a = ops.conv3x3_c8w(x, both, 96, relu=True)
+        monkeypatch.setenv('SCIPNP_WINO_F4', '0')
+        b = ops.conv3x3_c8w(x, both, 96, relu=True)
+    finally:
+        ops.LAUNCH_LOG = None
+    assert [e[0] for e in log] == ['conv3x3_c8w4_kernel', 'conv3x3_c8w_kernel']
+    assert torch.equal(a, ops.conv3x3_c8w4(x, both.f4, 96, relu=True)) and torch.equal(b, ops.conv3x3_c8w(x, both.w, 96, relu=True))
+    assert 0 < rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 4e-6
+    assert ops.pack_conv3x3_wino_both(packed, 96, 96).f4 is None                 # (not packed while switched off)
+    monkeypatch.setenv('SCIPNP_WINO_F4', '1')
+    for cin, cout in ((16, 96), (96, 16), (24, 64)):                             # narrow layers keep F(2x2,3x3)
+        pk = ops.pack_conv3x3(torch.zeros(cout, cin, 3, 3), None, Cin=cin, Cout=cout, device='cuda')
+        assert ops.pack_conv3x3_wino_both(pk, cin, cout).f4 is None
+    assert ops.conv3x3_c8w(x, both, 96, shuffle=True).shape == (2, 3, 48, 80, 8)   # PixelShuffle store: the F(2x2) kernel's epilogue
+
+
 def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
     """csrc/conv_winop.hip -- the persistent 96-output-channel form (input transform shared through LDS, 12-wave resident
     workgroups, channel-group pipeline running across unit boundaries) -- computes the same products in the same order as
@@ -1076,8 +1137,9 @@ def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
         wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
         bias = torch.randn(cout, generator=g)
         packed = ops.pack_conv3x3(wt, bias, Cin=cin, Cout=cout, device='cuda')
+        monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '1')
         both = ops.pack_conv3x3_wino_both(packed, cin, cout)
-        assert both.p is not None
+        assert both.p is not None and both.f4 is None
         xc = ops.to_c8(x.cuda())
         res = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
         fwd = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
@@ -1094,6 +1156,7 @@ def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
             err = rel_l2(ops.from_c8(ops.conv3x3_c8w(xc, both, cout)).cpu().numpy(), ref.numpy())
             assert err < 2e-6, (n, cin, h, w, err)
     # shapes without a persistent form keep the classic kernel
+    monkeypatch.setenv('SCIPNP_WINO_PERSISTENT', '1')
     assert ops.pack_conv3x3_wino_both(ops.pack_conv3x3(torch.zeros(64, 64, 3, 3), None, Cin=64, Cout=64, device='cuda'), 64, 64).p is None
 
 

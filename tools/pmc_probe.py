@@ -26,6 +26,7 @@ xs = ops.c8_to_c8s(x8)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pks = ops.pack_conv3x3_split(wt, b, Cin=c, Cout=c, device='cuda')
 pkw = ops.pack_conv3x3_wino(pk, c, c)
+pkw4 = ops.pack_conv3x3_wino4(pk, c, c)
 o8, os_ = torch.empty_like(x8), torch.empty_like(xs)
 B, M, N = 8, 256, 256
 th = torch.rand(B, 4, M, N, device='cuda')
@@ -35,6 +36,7 @@ xo = torch.empty_like(th)
 for _ in range(4):
     ops.conv3x3_c8(x8, pk, c, relu=True, out=o8)
     ops.conv3x3_c8w(x8, pkw, c, relu=True, out=o8)
+    ops.conv3x3_c8w4(x8, pkw4, c, relu=True, out=o8)
     ops.conv3x3_c8s(xs, pks, c, relu=True, out=os_)
     ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo)
 torch.cuda.synchronize()
