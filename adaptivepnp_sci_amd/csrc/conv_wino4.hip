@@ -254,33 +254,41 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
 
     // `last`: no further group / k-step exists -- the pointer stays and the same data is fetched again (unused), so that
     // every step issues the same number of memory operations and the vmcnt waits below are constants
-    auto issue_raw = [&](float* dst, bool last) {
+    // one 1 KiB LDS-DMA piece of the raw tile / of the U slab.  A wave's buffer_load ... lds takes some 40 cycles of its issue
+    // time (tools/probes/wino4_stamps.py, one workgroup per CU: a k-step with its eleven requests in a row at its head is 450
+    // cycles longer), so inside the K loop the pieces go out one at a time behind the first MFMA of a U vector.
+    auto issue_raw_piece = [&](float* dst, int k) {
         if (DIAG & 2) return;
 #if defined(__HIP_DEVICE_COMPILE__)
         auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, plane_bytes, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < W4_IN_ITERS; ++k) {
-            int pc = wvu + 4 * k;
-            if (pc >= W4_RAW_PIECES) pc -= 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)((char*)dst + 1024 * pc), 16,
-                                                     in_off[k], 0, 0, 0);
-        }
+        int pc = wvu + 4 * k;
+        if (pc >= W4_RAW_PIECES) pc -= 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)((char*)dst + 1024 * pc), 16, in_off[k], 0, 0, 0);
 #endif
-        if (!last) in_g += HW * 8;
     };
-    auto issue_u = [&](float* dst, bool last) {
+    auto issue_u_piece = [&](float* dst, int k) {
         if (DIAG & 4) return;
 #if defined(__HIP_DEVICE_COMPILE__)
         auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, W4_SLAB * 4, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < W4_DMA_ITERS; ++k) {
-            int pc = wvu + 4 * k;
-            if (pc >= W4_PIECES) pc -= 4;                                       // (waves 2, 3: their fifth piece is their fourth again)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)((char*)dst + 1024 * pc), 16,
-                                                     (unsigned)(1024 * pc + 16 * lane), 0, 0, 0);
-        }
+        int pc = wvu + 4 * k;
+        if (pc >= W4_PIECES) pc -= 4;                                           // (waves 2, 3: their fifth piece is their fourth again)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)((char*)dst + 1024 * pc), 16,
+                                                 (unsigned)(1024 * pc + 16 * lane), 0, 0, 0);
 #endif
-        if (!last) w_g += w_step;
+    };
+    // `last`: no further group / k-step exists -- the pointer stays and the same data is fetched again (unused), so that
+    // every step issues the same number of memory operations and the vmcnt waits below are constants
+    auto raw_done = [&](bool last) { if (!last) in_g += HW * 8; };
+    auto u_done = [&](bool last) { if (!last) w_g += w_step; };
+    auto issue_raw = [&](float* dst, bool last) {
+#pragma unroll
+        for (int k = 0; k < W4_IN_ITERS; ++k) issue_raw_piece(dst, k);
+        raw_done(last);
+    };
+    auto issue_u = [&](float* dst, bool last) {
+#pragma unroll
+        for (int k = 0; k < W4_DMA_ITERS; ++k) issue_u_piece(dst, k);
+        u_done(last);
     };
 
     f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]; zeroed behind the first requests
@@ -305,13 +313,14 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
 #ifndef W4_VBLK
 #define W4_VBLK 1
 #endif
-    auto quad = [&](const f32x4 u, const f32x2 (&Vr)[6], f32x4 (&ac)[6][2], auto NP, auto J, auto P, auto&& ops) {
+    auto quad = [&](const f32x4 u, const f32x2 (&Vr)[6], f32x4 (&ac)[6][2], auto NP, auto J, auto P, auto&& ops, auto&& dma) {
         constexpr int np = decltype(NP)::value, j = decltype(J)::value, pos = decltype(P)::value;
         const float b0 = Vr[2 * np][j], b1 = Vr[2 * np + 1][j];
         auto op = [&](auto Q, auto I) { ops(Q, I); };
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
         using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
         if (!(DIAG & 16)) ac[2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b0, ac[2 * np][0], 0, 0, 0);
+        dma(P);                                            // (this vector's share of the k-step's LDS-DMA requests)
         if constexpr (W4_VBLK == 1) op(P, C0{});
         if (!(DIAG & 16)) ac[2 * np + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], b1, ac[2 * np + 1][0], 0, 0, 0);
         if constexpr (W4_VBLK == 1) op(P, C1{});
@@ -400,7 +409,6 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             float* const rcur = raw_lds + (g & 1) * W4_RAW;          // held group g (its column pass is done): free behind the next barrier
             float* const rnext = raw_lds + ((g & 1) ^ 1) * W4_RAW;   // group g+1, requested one k-step ago
             // ---- k-step (g, 0), row by row.  Behind the last barrier every wave has finished k-step 2g-1: U of k-step 2g+1 -> its buffer
-            issue_u(u_lds + W4_SLAB, 2 * g + 2 >= 2 * CG);
             f32x4 af[3];
             af[0] = u_vec(u_lds, 0);
             af[1] = u_vec(u_lds, 1);
@@ -415,8 +423,11 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                     // vector Q = 3 x' + np' of the k-step carries the operations 4 np' .. 4 np' + 3 of the row pass of row x' + 1
                     constexpr int qx = decltype(Q)::value / 3, qn = decltype(Q)::value % 3;
                     if constexpr (qx < 2) row_op(std::integral_constant<int, qx + 1>{}, std::integral_constant<int, 4 * qn + decltype(I)::value>{});
+                }, [&](auto Q) {
+                    if constexpr (decltype(Q)::value < W4_DMA_ITERS) issue_u_piece(u_lds + W4_SLAB, decltype(Q)::value);
                 });
             });
+            u_done(2 * g + 2 >= 2 * CG);
             // bare s_barrier (__syncthreads() is a fence too and would wait for every LDS-DMA in flight, whatever the count).  Landed
             // by now: the raw tile of group g+1 and U of k-step 2g+1 (every wave's own pieces); own LDS reads are done.
             if (g < 24) W4_STAMP(8 + 4 * g);
@@ -425,8 +436,6 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             if (g < 24) W4_STAMP(9 + 4 * g);
             // ---- k-step (g, 1), column pair by column pair, with the column pass of group g+1: U of k-step 2g+2 -> the buffer of
             // k-step 2g, raw tile of group g+2 -> the buffer of group g (two k-steps ahead of its use)
-            issue_u(u_lds, 2 * g + 3 >= 2 * CG);
-            issue_raw(rcur, g + 3 >= CG);
             const float* const ub = u_lds + W4_SLAB;
             af[0] = u_vec(ub, 0);
             af[1] = u_vec(ub, 1);
@@ -452,8 +461,18 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                 quad(af[pos % 3], V[x], acc[x], std::integral_constant<int, np>{}, std::integral_constant<int, 1>{}, P, [&](auto Q, auto I) {
                     if constexpr (W4_VBLK == 12) col_ops4(Q, I);                            // (whole column pairs behind their third of the MFMAs)
                     else if constexpr (decltype(Q)::value > 0) col_ops4(std::integral_constant<int, decltype(Q)::value - 1>{}, I);
+                }, [&](auto Q) {
+                    // the U pieces first (two per vector), then the raw pieces: the wait at the end of the k-step counts on that order
+                    constexpr int qq = decltype(Q)::value;
+                    if constexpr (2 * qq < W4_DMA_ITERS) issue_u_piece(u_lds, 2 * qq);
+                    if constexpr (2 * qq + 1 < W4_DMA_ITERS) issue_u_piece(u_lds, 2 * qq + 1);
+                    constexpr int r0 = (W4_DMA_ITERS + 1) / 2;                              // first vector that carries a raw piece
+                    if constexpr (qq >= r0 && qq - r0 < W4_IN_ITERS) issue_raw_piece(rcur, qq - r0);
                 });
             });
+            static_assert((W4_DMA_ITERS + 1) / 2 + W4_IN_ITERS <= 9, "a k-step has nine U vectors to hang its requests on");
+            u_done(2 * g + 3 >= 2 * CG);
+            raw_done(g + 3 >= CG);
             if constexpr (W4_VBLK != 12) static_for<4>([&](auto I) { col_ops4(std::integral_constant<int, 8>{}, I); });
             if (g < 24) W4_STAMP(10 + 4 * g);
             if (DIAG & 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W4_IN_ITERS) : "memory");
