@@ -69,7 +69,6 @@ struct Wino4Args {
     int H, W;
     int ntx, nty;
     int flags;
-    int stagger;             // first-generation workgroups 256..511 (the second workgroup slot of every CU) sleep this many x 64 x 127 cycles
     unsigned long long* dbg; // STAMP instantiation (DIAG bit6) only: 128 words per workgroup, see scipnp_conv3x3_c8w4_stamped
 };
 
@@ -203,14 +202,6 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     const unsigned long long* const stamp_base = (DIAG & 64) ? a.dbg + (size_t)blockIdx.x * 128 : nullptr;
     (void)stamp_base;
     W4_STAMP(0);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // De-synchronise the two workgroups of a CU: all workgroups live equally long, so the pair that starts together would also
-    // load its first tiles together and transform / store its outputs together, for every generation of the grid, with the matrix
-    // pipes idle meanwhile.  The workgroups that fill the second slot of the CUs start late by a part of a workgroup life once,
-    // in the first generation; the offset then carries through the launch.
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const int tg = wvu >> 1, xh = wvu & 1;             // tile row of the workgroup, half of the transformed rows
     const int tn = lane & 15, q = lane >> 4;           // tile along x, channel pair
     const int H = a.H, W = a.W;
@@ -630,15 +621,6 @@ __global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restric
 
 static inline int round_up_w4(int v, int m) { return (v + m - 1) / m * m; }
 
-// SCIPNP_W4_STAGGER: start offset of the second workgroup slot in units of 8128 cycles (s_sleep 127); tuning knob
-static int wino4_stagger() {
-    static const int v = [] {
-        const char* e = getenv("SCIPNP_W4_STAGGER");
-        return e ? atoi(e) : 4;
-    }();
-    return v;
-}
-
 }  // namespace scipnp
 
 using namespace scipnp;
@@ -682,7 +664,6 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     a.flags = flags;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
-    a.stagger = total >= 1024 ? wino4_stagger() : 0;
     const int tag = (flags & 0x100) ? 1 : 0;
     const void* fns[2] = {(const void*)conv3x3_c8w4_kernel<0>, (const void*)conv3x3_c8w4_kernel<1>};
     static LdsAttrOnce attr[2];
@@ -733,7 +714,6 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
-    a.stagger = total >= 1024 ? wino4_stagger() : 0;
     const dim3 grid((unsigned)total), block(W4_THREADS);
     // flags bits 12.. select a stamped build with parts switched off (diag bits 0..2 of scipnp_conv3x3_c8w4_diag; wrong results)
 #define W4_STAMP_CASE(D)                                                                                                     \
@@ -769,7 +749,6 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
-    a.stagger = total >= 1024 ? wino4_stagger() : 0;
     const dim3 grid((unsigned)total), block(W4_THREADS);
 #define W4_DIAG_CASE(D)                                                                                                    \
     case D: {                                                                                                              \

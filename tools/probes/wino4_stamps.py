@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: s_memtime stamps of the F(4x4,3x3) Winograd kernel (scipnp_conv3x3_c8w4_stamped) on the FFDNet body layer:
-where a workgroup's life goes -- prologue, the two k-steps of a channel group (MFMA issue phase | wait + barrier), epilogue."""
+where a workgroup's life goes -- prologue, the two k-steps of a channel group (MFMA issue phase | wait + barrier), epilogue.
+All figures are in units of 100 shader-clock cycles (s_memtime); W4_STAMP_OFF = parts switched off (timing only), SCIPNP_W4_ONE_PER_CU=1 = a
+single resident workgroup per CU (a lone wave's pace), W4_STAMP_DETAIL=1 = every k-step of four consecutive workgroups of one CU."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -29,11 +31,10 @@ ops.conv3x3_c8w4(x8, p4, c, relu=True, out=ref)
 print('stamped launch', round(e0.elapsed_time(e1) * 1e3, 1), 'us; equals the product kernel:', bool(torch.equal(out, ref)))
 s = st.cpu().numpy().reshape(nwg, 128).astype(np.float64)
 CG = c // 8
-t0 = s[:, 0].min()
+t0 = s[:, 0][s[:, 0] > 0].min()
 life = s[:, 6] - s[:, 0]
-clk = 100e6          # s_memtime counts at 100 MHz on gfx9 (constant clock)
-us = lambda d: d / clk * 1e6  # noqa: E731
-print(f'workgroups {nwg}; launch span {us(s[:, 6].max() - t0):.1f} us; workgroup life mean {us(life.mean()):.2f} us (min {us(life.min()):.2f}, max {us(life.max()):.2f})')
+us = lambda d: d / 100.0     # noqa: E731  -- s_memtime counts shader clocks here: print HUNDREDS OF CYCLES
+print(f'workgroups {nwg}; workgroup life mean {us(life.mean()):.1f} (min {us(life.min()):.1f}, max {us(life.max()):.1f})   [x 100 cycles]')
 print(f'  entry -> tiles/slab landed {us((s[:, 1] - s[:, 0]).mean()):.2f} | first column pass {us((s[:, 2] - s[:, 1]).mean()):.2f} | '
       f'loop {us((s[:, 3] - s[:, 2]).mean()):.2f} | drain + exchange {us((s[:, 4] - s[:, 3]).mean()):.2f} | output transform + stores issued '
       f'{us((s[:, 5] - s[:, 4]).mean()):.2f} | stores acknowledged {us((s[:, 6] - s[:, 5]).mean()):.2f}')
@@ -41,14 +42,14 @@ G = s[:, 8:8 + 4 * CG].reshape(nwg, CG, 4)
 prev = np.concatenate([s[:, 2:3], G[:, :-1, 3]], axis=1)          # start of each group
 a_issue, a_wait = G[:, :, 0] - prev, G[:, :, 1] - G[:, :, 0]
 b_issue, b_wait = G[:, :, 2] - G[:, :, 1], G[:, :, 3] - G[:, :, 2]
-print('per channel group (mean over workgroups and groups), us:')
+print('per channel group (mean over workgroups and groups), x 100 cycles:')
 print(f'  k-step 0: row pass + 36 MFMAs issued {us(a_issue.mean()):.3f} | wait (U, raw) + barrier {us(a_wait.mean()):.3f}')
 print(f'  k-step 1: 36 MFMAs + column pass     {us(b_issue.mean()):.3f} | wait (U) + barrier      {us(b_wait.mean()):.3f}')
-print(f'  group total {us((a_issue + a_wait + b_issue + b_wait).mean()):.3f}   (36 MFMAs alone on a SIMD: {36 * 32 / 2.4e3:.3f} us at 2.4 GHz)')
+print(f'  group total {us((a_issue + a_wait + b_issue + b_wait).mean()):.3f}   (72 MFMAs alone on a SIMD: 23.04; two waves sharing it: 46.08)')
 for name, arr in (('k-step 0 issue', a_issue), ('k-step 0 wait', a_wait), ('k-step 1 issue', b_issue), ('k-step 1 wait', b_wait)):
     q = np.percentile(us(arr), [10, 50, 90, 99])
     print(f'  {name:15s} p10 {q[0]:.3f}  p50 {q[1]:.3f}  p90 {q[2]:.3f}  p99 {q[3]:.3f}')
-print('  by group index (mean us): ' + ' '.join(f'{us((a_issue + a_wait + b_issue + b_wait)[:, k].mean()):.2f}' for k in range(CG)))
+print('  by group index (mean, x 100 cycles): ' + ' '.join(f'{us((a_issue + a_wait + b_issue + b_wait)[:, k].mean()):.2f}' for k in range(CG)))
 # ---- one CU's workgroups in start order (cycles from the launch's first entry)
 hw = st.cpu().numpy().reshape(nwg, 128)[:, 7]
 xcc, hwid = (hw >> 32) & 0xf, hw & 0xffffffff
