@@ -427,6 +427,8 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             if (g < 24) W4_STAMP(9 + 4 * g);
             // ---- k-step (g, 1), column pair by column pair, with the column pass of group g+1: U of k-step 2g+2 -> the buffer of
             // k-step 2g, raw tile of group g+2 -> the buffer of group g (two k-steps ahead of its use)
+            // (the last groups request nothing past the end: a re-fetched tile would only be waited for before the output transform)
+            const bool more_u = g + 1 < CG, more_raw = g + 2 < CG;
             const float* const ub = u_lds + W4_SLAB;
             af[0] = u_vec(ub, 0);
             af[1] = u_vec(ub, 1);
@@ -455,15 +457,17 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                 }, [&](auto Q) {
                     // the U pieces first (two per vector), then the raw pieces: the wait at the end of the k-step counts on that order
                     constexpr int qq = decltype(Q)::value;
-                    if constexpr (2 * qq < W4_DMA_ITERS) issue_u_piece(u_lds, 2 * qq);
-                    if constexpr (2 * qq + 1 < W4_DMA_ITERS) issue_u_piece(u_lds, 2 * qq + 1);
+                    if constexpr (2 * qq < W4_DMA_ITERS) { if (more_u) issue_u_piece(u_lds, 2 * qq); }
+                    if constexpr (2 * qq + 1 < W4_DMA_ITERS) { if (more_u) issue_u_piece(u_lds, 2 * qq + 1); }
                     constexpr int r0 = (W4_DMA_ITERS + 1) / 2;                              // first vector that carries a raw piece
-                    if constexpr (qq >= r0 && qq - r0 < W4_IN_ITERS) issue_raw_piece(rcur, qq - r0);
+                    if constexpr (qq >= r0 && qq - r0 < W4_IN_ITERS) { if (more_raw) issue_raw_piece(rcur, qq - r0); }
                 });
             });
             static_assert((W4_DMA_ITERS + 1) / 2 + W4_IN_ITERS <= 9, "a k-step has nine U vectors to hang its requests on");
             u_done(2 * g + 3 >= 2 * CG);
             raw_done(g + 3 >= CG);
+            // (no raw requests behind the U pieces in the last two groups: the U pieces are then the youngest requests)
+            if (!more_raw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (W4_VBLK != 12) static_for<4>([&](auto I) { col_ops4(std::integral_constant<int, 8>{}, I); });
             if (g < 24) W4_STAMP(10 + 4 * g);
             if (DIAG & 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W4_IN_ITERS) : "memory");
