@@ -189,7 +189,7 @@ __host__ __device__ __forceinline__ void half_op(const f32x2 i0, const f32x2 i1,
 }
 
 // DIAG (timing experiments only, wrong results): bit0 no transform, 1 no raw staging, 2 no U DMA, 3 no barriers, 4 no MFMAs, 5 no epilogue
-template <int TAG, int DIAG = 0>
+template <int TAG, int DIAG = 0, bool SHUF = false>
 __global__ void __launch_bounds__(W4_THREADS, 2)
 conv3x3_c8w4_kernel(const Wino4Args a) {
 
@@ -526,6 +526,73 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     const float* bias = a.wpk + (size_t)2 * a.CGin * w_step;
     const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
     (void)relu; (void)add_res; (void)mask; (void)bias;
+    if constexpr (SHUF) {
+        // PixelShuffle(2) folded into the store (flags bit3, as scipnp_conv3x3_c8w): conv channel 4c + 2dy + dx -> channel c of pixel
+        // (2y + dy, 2x + dx); the 32 conv channels of this workgroup are the 8 channels of output group `split`, and a lane's four
+        // values are the 2x2 sub-pixels of ONE output channel c = 4h + q.  The shuffled 16 x 128-pixel tile is assembled in LDS (the
+        // exchange area is free once every wave has read its partner's rows) and leaves in whole 128-byte lines: one thread = four
+        // consecutive pixels x 8 channels, skip tensor (same layout) added there.  out = relu?(conv + bias + res).
+        constexpr int ROW = 128 * 8 + 32 * 4;               // floats per shuffled row: 4 floats of padding per 4 pixels
+        static_assert(16 * ROW * 4 <= W4_LDS_BYTES, "shuffled tile");
+        float* const tile = smem_w4;
+        f32x4 v[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 bs = *(const f32x4*)(bias + (split * 4 + h * 2 + (q >> 1)) * 8 + 4 * (q & 1));
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[h][il][j] = (keep[il][j][h] + *(const f32x4*)(xbuf + (((wvu ^ 1) * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4)) + bs;
+        }
+        __syncthreads();                                    // partner rows read: the area becomes the shuffled tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int yl = 2 * (4 * tg + 2 * xh + il) + (e >> 1), xl = 2 * (4 * tn + j) + (e & 1);
+                        tile[yl * ROW + xl * 8 + (xl >> 2) * 4 + 4 * h + q] = v[h][il][j][e];
+                    }
+        __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int H2 = 2 * H, W2 = 2 * W;
+        const size_t plane = ((size_t)n * a.NCB + split) * (size_t)H2 * W2 * 8;               // floats; NCB = Cout/32 output groups
+        const unsigned pbytes = (unsigned)((size_t)H2 * W2 * 32);
+        auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, pbytes, 0x00020000);
+        auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)((add_res ? a.residual : a.out) + plane), 0, pbytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                    // 16 rows x 32 groups of 4 pixels = 512 items, two per thread
+            const int item = tid + it * W4_THREADS, yl = item >> 5, xg = item & 31;
+            const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg;
+            const float* src = tile + yl * ROW + xg * 36;
+            f32x4 px[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) px[k] = *(const f32x4*)(src + 4 * k);
+            unsigned off[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) off[k] = (y2 < H2 && x2 + k < W2) ? (unsigned)(((size_t)y2 * W2 + x2 + k) * 32) : 0x80000000u;
+            if (add_res) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    px[k] = px[k] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[k >> 1] + 16 * (k & 1), 0, 0));
+            }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) px[k][e] = fmaxf(px[k][e], 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[k]), r_out, off[k >> 1] + 16 * (k & 1), 0, 0);
+        }
+#endif
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)
@@ -656,7 +723,9 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     SCIPNP_ALIGNED(in); SCIPNP_ALIGNED(packed_wino4); SCIPNP_ALIGNED(out);
     if (residual) SCIPNP_ALIGNED(residual);
     if (mask_src) SCIPNP_ALIGNED(mask_src);
-    SCIPNP_REQUIRE(!(flags & (4 | 8 | 0x200)), "the F(4x4,3x3) kernel is stride 1, plain store, 8-row workgroups");
+    SCIPNP_REQUIRE(!(flags & (4 | 0x200)), "the F(4x4,3x3) kernel is stride 1, 8-row workgroups");
+    SCIPNP_REQUIRE(!(flags & 8) || (Cout % 32 == 0 && !(flags & 16)), "PixelShuffle store: Cout must be a multiple of 32, no ReLU-mask epilogue");
+    SCIPNP_REQUIRE(!(flags & 8) || (long long)h * w * 4 * 32 < (1ll << 30), "shuffled plane too large for 32-bit buffer offsets");
     SCIPNP_REQUIRE(!(flags & 16) || mask_src, "flag bit4 needs mask_src");
     SCIPNP_REQUIRE(!(flags & 2) || residual, "flag bit1 needs residual");
     SCIPNP_REQUIRE((long long)h * w * 32 < (1ll << 30), "image too large for 32-bit buffer offsets (h*w < 2^25)");
@@ -673,6 +742,12 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     static LdsAttrOnce attr[2];
     if (int rc = attr[tag].ensure(fns[tag], W4_LDS_BYTES, "conv3x3_c8w4")) return rc;
     const dim3 grid((unsigned)total), block(W4_THREADS);
+    if (flags & 8) {                                            // PixelShuffle(2) store (UpBlocks of FastDVDnet / DDnet)
+        static LdsAttrOnce shuf_attr;
+        if (int rc = shuf_attr.ensure((const void*)conv3x3_c8w4_kernel<0, 0, true>, W4_LDS_BYTES, "conv3x3_c8w4 shuffle")) return rc;
+        hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 0, true>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
+        return launch_status("conv3x3_c8w4_kernel<shuffle>");
+    }
     if (tag) hipLaunchKernelGGL((conv3x3_c8w4_kernel<1>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
     else hipLaunchKernelGGL((conv3x3_c8w4_kernel<0>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
     return launch_status("conv3x3_c8w4_kernel");

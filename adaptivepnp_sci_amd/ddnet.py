@@ -136,8 +136,7 @@ def wino_packs(packed, ch_each_frame):
         if i < len(_LAYERS):
             _k, cin, cout, _r, s2, shuf = _LAYERS[i]
             cin = _p8(3 * ch_each_frame) if cin is None else cin
-            out.append(None if (s2 or (shuf and cout % 32)) else
-                       (ops.pack_conv3x3_wino(pk, cin, cout) if shuf else ops.pack_conv3x3_wino_both(pk, cin, cout)))
+            out.append(None if (s2 or (shuf and cout % 32)) else ops.pack_conv3x3_wino_both(pk, cin, cout))
         else:
             out.append(ops.pack_conv3x3_wino(pk, 8, 8))
     return out

@@ -336,8 +336,9 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
              (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
     if isinstance(packed_wino, WinoPacked):
-        if packed_wino.f4 is not None and not (rows16 or shuffle) and wino_f4_enabled():
-            return conv3x3_c8w4(x, packed_wino.f4, Cout, relu=relu, residual=residual, mask_src=mask_src, out=out, head=head)
+        if packed_wino.f4 is not None and not rows16 and wino_f4_enabled():
+            return conv3x3_c8w4(x, packed_wino.f4, Cout, relu=relu, residual=residual, mask_src=mask_src, out=out, head=head,
+                                shuffle=shuffle)
         if packed_wino.p is not None and not (rows16 or shuffle) and persistent_wino_enabled():
             _timed_call('conv3x3_c8p_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8p', _p(x, 'x'),
                         _p(packed_wino.p, 'packed_winop'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'),
@@ -358,14 +359,16 @@ def pack_conv3x3_wino4(packed_f32, Cin, Cout, out=None):
     return out
 
 
-def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False, shuffle=False):
     """stride-1 3x3 conv on c8 activations in fp32 Winograd F(4x4,3x3) arithmetic (csrc/conv_wino4.hip): 2.25 multiply-adds per
-    output on the matrix cores instead of 4 (conv3x3_c8w) or 9 (conv3x3_c8)."""
+    output on the matrix cores instead of 4 (conv3x3_c8w) or 9 (conv3x3_c8).
+    shuffle: PixelShuffle(2) folded into the store, out [n][Cout/32][2h][2w][8] (residual, if any, in that layout)."""
     n, cg, h, w, _ = x.shape
     if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+        out = (torch.empty(n, Cout // 32, 2 * h, 2 * w, 8, device=x.device, dtype=F32) if shuffle else
+               torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32))
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
-             (0x100 if head else 0))
+             (0x100 if head else 0) | (8 if shuffle else 0))
     _timed_call('conv3x3_c8w4_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w4', _p(x, 'x'),
                 _p(packed_wino4, 'packed_wino4'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
                 Cout, h, w, flags, _stream())

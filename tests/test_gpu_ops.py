@@ -1093,6 +1093,31 @@ def test_conv3x3_winograd_f4_random_shapes(ops):
         assert rel_l2(got.numpy(), want.numpy()) < 4e-6, (n, cin, cout, h, w)
 
 
+def test_conv3x3_winograd_f4_pixel_shuffle_store(ops):
+    """PixelShuffle(2) folded into the F(4x4,3x3) kernel's store (flags bit3: the UpBlocks of FastDVDnet / DDnet in fp32), with and
+    without the skip tensor and ReLU, against float64 conv + pixel_shuffle and against the F(2x2,3x3) kernel's shuffle epilogue;
+    ragged heights / widths, several images, 96 / 128 / 160 / 256 conv channels"""
+    g = torch.Generator().manual_seed(22)
+    for n, cin, cout, h, w in ((2, 64, 128, 16, 32), (1, 128, 256, 9, 21), (3, 40, 160, 5, 7), (2, 32, 96, 13, 70), (1, 64, 128, 64, 64)):
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(cout, generator=g) * 0.1
+        res = torch.randn(n, cout // 4, 2 * h, 2 * w, generator=g)
+        pk = ops.pack_conv3x3(wt, b, Cin=cin, Cout=cout, device='cuda')
+        p4, p2 = ops.pack_conv3x3_wino4(pk, cin, cout), ops.pack_conv3x3_wino(pk, cin, cout)
+        xc, rc = ops.to_c8(x.cuda()), ops.to_c8(res.cuda())
+        ref = torch.nn.functional.pixel_shuffle(torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=1), 2)
+        for residual, relu in ((None, False), (rc, False), (rc, True)):
+            want = ref + (res.double() if residual is not None else 0)
+            want = torch.relu(want) if relu else want
+            got = ops.conv3x3_c8w4(xc, p4, cout, relu=relu, residual=residual, shuffle=True)
+            assert got.shape == (n, cout // 32, 2 * h, 2 * w, 8)
+            err = rel_l2(ops.from_c8(got)[:, :cout // 4].cpu().numpy(), want.numpy())
+            assert err < 4e-6, (n, cin, cout, h, w, relu, err)
+            f2 = ops.conv3x3_c8w(xc, p2, cout, relu=relu, residual=residual, shuffle=True)
+            assert rel_l2(got.cpu().numpy(), f2.cpu().numpy()) < 4e-6
+
+
 def test_conv3x3_winograd_f4_is_what_the_engines_run(ops, monkeypatch):
     """conv3x3_c8w takes the F(4x4,3x3) kernel for a layer packed by pack_conv3x3_wino_both when the shape has one (at least
     32 input and output channels, plain store); SCIPNP_WINO_F4=0 at pack or launch time keeps the F(2x2,3x3) kernel; the FFDNet
@@ -1118,7 +1143,7 @@ def test_conv3x3_winograd_f4_is_what_the_engines_run(ops, monkeypatch):
     for cin, cout in ((16, 96), (96, 16), (24, 64)):                             # narrow layers keep F(2x2,3x3)
         pk = ops.pack_conv3x3(torch.zeros(cout, cin, 3, 3), None, Cin=cin, Cout=cout, device='cuda')
         assert ops.pack_conv3x3_wino_both(pk, cin, cout).f4 is None
-    assert ops.conv3x3_c8w(x, both, 96, shuffle=True).shape == (2, 3, 48, 80, 8)   # PixelShuffle store: the F(2x2) kernel's epilogue
+    assert ops.conv3x3_c8w(x, both, 96, shuffle=True).shape == (2, 3, 48, 80, 8)   # (the PixelShuffle store is an epilogue of both kernels)
 
 
 def test_conv3x3_winograd_persistent_equals_classic_kernel(ops, monkeypatch):
