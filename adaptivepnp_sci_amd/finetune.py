@@ -99,6 +99,13 @@ def _carve(flat, like):
     return out
 
 
+def _repack_wino(packed_f32, wp):
+    """Winograd-domain weights of a trainer layer (ops.WinoPacked with preallocated buffers) from its fp32 direct packing"""
+    ops.pack_conv3x3_wino(packed_f32, wp.cin, wp.cout, out=wp.w)
+    if wp.f4 is not None:
+        ops.pack_conv3x3_wino4(packed_f32, wp.cin, wp.cout, out=wp.f4)
+
+
 class _DeviceMean:
     """a sum left on the device by scipnp_sum_rows_f64 and its divisor: `.item()` reads it back (the only sync of a step)"""
 
@@ -151,10 +158,13 @@ class _FFDNetTrainer:
         # operator with transposed / flipped weights) run on csrc/conv_wino.hip too; weight gradients stay on the direct MFMA kernel
         self.wino = (not self.split) and getattr(eng, 'packed_wino', None) is not None
         if self.wino:
-            self.fwd_w = [torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev)
-                          for ci, co in zip(self.cin, self.cout)]
-            self.bwd_w = [None] + [torch.empty(lib.scipnp_conv3x3_wino_packed_floats(co, ci), dtype=F32, device=dev)
-                                   for ci, co in list(zip(self.cin, self.cout))[1:]]
+            # (the 96 -> 96 layers in both directions also as F(4x4,3x3), csrc/conv_wino4.hip: conv3x3_c8w prefers that packing)
+            def wp(ci, co):
+                f4 = (torch.empty(lib.scipnp_conv3x3_wino4_packed_floats(ci, co), dtype=F32, device=dev)
+                      if (ops.wino_f4_enabled() and ops.wino_f4_shape(ci, co)) else None)
+                return ops.WinoPacked(torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev), None, ci, co, f4)
+            self.fwd_w = [wp(ci, co) for ci, co in zip(self.cin, self.cout)]
+            self.bwd_w = [None] + [wp(co, ci) for ci, co in list(zip(self.cin, self.cout))[1:]]
         self.acts = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(self.nb - 1)]
         self.dz = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(2)]
         self.gout = torch.empty(B, 2, M, N, 8, dtype=F32, device=dev)
@@ -211,9 +221,9 @@ class _FFDNetTrainer:
                 _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), None, _ptr(self.bwd[l]), ci_r, co_r,
                                                                self.cin[l], self.cout[l], 1, _s()), 'pack bwd')
             if self.wino:
-                ops.pack_conv3x3_wino(self.fwd[l], self.cin[l], self.cout[l], out=self.fwd_w[l])
+                _repack_wino(self.fwd[l], self.fwd_w[l])
                 if l > 0 and not final:
-                    ops.pack_conv3x3_wino(self.bwd[l], self.cout[l], self.cin[l], out=self.bwd_w[l])
+                    _repack_wino(self.bwd[l], self.bwd_w[l])
 
     def forward_keep(self):
         eng = self.eng
