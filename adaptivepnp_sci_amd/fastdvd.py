@@ -152,7 +152,7 @@ def wino_packs(packed):
     """Winograd-domain weights (csrc/conv_wino.hip) of the stride-1 layers of one DenBlock (the PixelShuffle layers
     included: the shuffle is an epilogue of that kernel too), None for the stride-2 ones; derived on the device from the
     fp32 direct packing"""
-    # (layers of at least 32 input and output channels also get the F(4x4,3x3) packing of csrc/conv_wino4.hip, which conv3x3_c8w
+    # (layers of at least 16 input and 32 output channels also get the F(4x4,3x3) packing of csrc/conv_wino4.hip, which conv3x3_c8w
     # then prefers -- the PixelShuffle store is an epilogue of both kernels)
     return [None if s2 else ops.pack_conv3x3_wino_both(packed[i], cin, cout)
             for i, (_k, _bn, cin, cout, _relu, s2, _shuf) in enumerate(_LAYERS)]

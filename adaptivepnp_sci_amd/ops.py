@@ -389,20 +389,21 @@ class WinoPacked:
 
 
 def wino_f4_enabled():
-    """SCIPNP_WINO_F4=0 keeps every fp32 Winograd layer on the F(2x2,3x3) kernel; default: layers with at least 32 input and
+    """SCIPNP_WINO_F4=0 keeps every fp32 Winograd layer on the F(2x2,3x3) kernel; default: layers with at least 16 input and 32
     output channels run as F(4x4,3x3) (csrc/conv_wino4.hip)."""
     import os
     return os.environ.get('SCIPNP_WINO_F4', '1') != '0'
 
 
 def wino_f4_shape(Cin, Cout):
-    """layer shapes the F(4x4,3x3) kernel is used for: its workgroup computes 32 output channels from K-steps of 4 input
-    channels -- narrower layers are padding or transform-bound there"""
-    return Cin >= 32 and Cout >= 32
+    """layer shapes the F(4x4,3x3) kernel is used for: its workgroup computes 32 output channels -- a narrower output is padding
+    there (96 -> 16: 89 against 81 us) -- and needs at least two 8-channel groups to get its pipeline going (16 -> 96: 86 against
+    107 us, profiles/r03f_wino4_check.txt)"""
+    return Cin >= 16 and Cout >= 32
 
 
 def persistent_wino_enabled():
-    """SCIPNP_WINO_PERSISTENT=1 puts the 96-output-channel fp32 Winograd layers on the persistent kernel (csrc/conv_winop.hip).
+    """SCIPNP_WINO_PERSISTENT=1 puts the 96-output-channel fp32 F(2x2,3x3) layers on the persistent kernel (csrc/conv_winop.hip).
     Off by default: bit-identical to the classic kernel but measured 366-370 us against 334-336 us on the FFDNet body layer
     (profiles/r03_winop_ablate.txt)."""
     import os

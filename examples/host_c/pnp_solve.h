@@ -88,7 +88,7 @@ static void pnp_solve(pnp_solve_t* job) {
             float* pw = dmalloc(scipnp_conv3x3_wino_packed_floats(Cin, Cout) * 4);
             SCICHK(scipnp_pack_conv3x3_wino(pd, pw, Cin, Cout, st));
             packed_w[l] = pw;
-            if (Cin >= 32 && Cout >= 32) {               /* the 96 -> 96 layers: 2.25 multiply-adds per output instead of 4 */
+            if (Cin >= 16 && Cout >= 32) {               /* head and body layers: 2.25 multiply-adds per output instead of 4 */
                 float* p4 = dmalloc(scipnp_conv3x3_wino4_packed_floats(Cin, Cout) * 4);
                 SCICHK(scipnp_pack_conv3x3_wino4(pd, p4, Cin, Cout, st));
                 packed_w4[l] = p4;

@@ -26,7 +26,9 @@ for n, cin, cout, h, w in ((1, 8, 32, 8, 64), (1, 32, 32, 8, 64), (2, 96, 96, 20
 
 for name, n, cin, cout, h, w in (('FFDNet body', 8, 96, 96, 256, 256), ('FastDVDnet 64->64', 8, 64, 64, 256, 256),
                                  ('FastDVDnet 128->128', 8, 128, 128, 128, 128), ('FastDVDnet 96->32', 8, 96, 32, 512, 512),
-                                 ('FastDVDnet 32->32', 8, 32, 32, 512, 512), ('tile body', 16, 96, 96, 128, 128)):
+                                 ('FastDVDnet 32->32', 8, 32, 32, 512, 512), ('tile body', 16, 96, 96, 128, 128),
+                                 ('FFDNet head 16->96', 8, 16, 96, 256, 256), ('FFDNet tail 96->16', 8, 96, 16, 256, 256),
+                                 ('FastDVDnet inc 16->96', 8, 16, 96, 512, 512), ('FastDVDnet out 32->8', 8, 32, 8, 512, 512)):
     x8 = ops.to_c8(torch.randn(n, cin, h, w, generator=g).cuda())
     wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
     pk = ops.pack_conv3x3(wt, torch.randn(cout, generator=g), Cin=cin, Cout=cout, device='cuda')
