@@ -361,7 +361,10 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
  * (<= 3e-6 relative L2 per layer in tests/test_gpu_ops.py; 3e-7 through the 12 FFDNet layers against float64).
  * packed_wino4: scipnp_conv3x3_wino4_packed_floats(Cin, Cout) floats derived on the device from the fp32 direct packing
  * (U = G g G^T in double), layout [2*Cin/8 k-steps][CoutP/32][xi half][9 vectors][lane][4], then bias[CoutP].
- * flags: bit0 ReLU, bit1 add `residual`, bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag; stride 1, plain store.
+ * flags: bit0 ReLU, bit1 add `residual`, bit3 PixelShuffle(2) folded into the store (out and residual [n][Cout/32][2h][2w][8], Cout a
+ *        multiple of 32, no mask; as scipnp_conv3x3_c8w), bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag; stride 1.
+ * The engines use it for layers of at least 16 input and 32 output channels (a narrower output is padding in its 32-channel
+ * workgroups); SCIPNP_WINO_F4=0 keeps them on scipnp_conv3x3_c8w.
  * -- same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8w. */
 size_t scipnp_conv3x3_wino4_packed_floats(int Cin, int Cout);
 int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int Cin, int Cout, scipnp_stream_t s);

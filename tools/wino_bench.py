@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: FFDNet body layer (96 -> 96, 8 frames of 256 x 256): fp32 direct MFMA vs fp32 Winograd F(2x2,3x3) MFMA."""
+"""GPU box: FFDNet body layer (96 -> 96, 8 frames of 256 x 256): fp32 direct MFMA vs fp32 Winograd F(2x2,3x3) / F(4x4,3x3) MFMA."""
 import os, sys
 import torch
 os.environ.setdefault('SCIPNP_WINO_PERSISTENT', '1')          # the WinoPacked variants below take the persistent kernel
@@ -16,17 +16,21 @@ x8 = ops.to_c8(x)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pw = ops.pack_conv3x3_wino(pk, c, c)
 pb = ops.pack_conv3x3_wino_both(pk, c, c)
+p4 = ops.pack_conv3x3_wino4(pk, c, c)
+o84 = torch.empty_like(x8)
 o8, o8w, o8v, o8p = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
 variants = {'fp32 direct': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
             'fp32 winograd': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8w),
             'fp32 wino 16row': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8v, rows16=True),
-            'fp32 wino persist': lambda: ops.conv3x3_c8w(x8, pb, c, relu=True, out=o8p)}
+            'fp32 wino persist': lambda: ops.conv3x3_c8w(x8, ops.WinoPacked(pb.w, pb.p, c, c), c, relu=True, out=o8p),
+            'fp32 wino F(4x4)': lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=o84)}
 for f in variants.values():
     for _ in range(3):
         f()
 torch.cuda.synchronize()
 print('winograd vs direct rel-L2:', float((o8w - o8).norm() / o8.norm()), '16-row:', float((o8v - o8).norm() / o8.norm()),
-      'bitwise equal variants:', bool(torch.equal(o8w, o8v)), 'persistent == classic:', bool(torch.equal(o8w, o8p)))
+      'bitwise equal variants:', bool(torch.equal(o8w, o8v)), 'persistent == classic:', bool(torch.equal(o8w, o8p)),
+      'F(4x4) vs direct rel-L2:', float((o84 - o8).norm() / o8.norm()))
 res = {k: [] for k in variants}
 for r in range(5):
     for k, f in variants.items():
