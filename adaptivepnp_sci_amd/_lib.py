@@ -98,11 +98,6 @@ SIGNATURES = {
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_host_legacy_normal': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_double), C.c_double, C.c_double,
                                         _vp, _sz]),
-    'scipnp_bench_mfma': (_int, [_vp, _int, _int, _int, _vp]),
-    'scipnp_bench_mfma_valu': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
-    'scipnp_bench_mfma_dep': (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    'scipnp_bench_mfma_bank': (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_flush': (_int, [_vp, C.POINTER(_int), _vp]),
@@ -114,14 +109,6 @@ SIGNATURES = {
     'scipnp_conv3x3_wino4_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino4': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w4': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
-    'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
-    'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8w_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_negate': (_int, [_vp, _vp, _sz, _vp]),
     'scipnp_fastdvd_noisy_input': (_int, [_vp, _vp, _vp, _sz, _vp]),
     'scipnp_sum_rows_f64': (_int, [_vp, _vp, _int, _int, _vp]),

@@ -7,32 +7,15 @@
 #include <cstdint>
 #include "../../include/scipnp.h"
 
+#include "host_common.hpp"
+
 namespace scipnp {
-
-void set_error(const char* fmt, ...);
-
-inline int fail(int code, const char* fmt, ...) {
-    char buf[256];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    set_error("%s", buf);
-    return code;
-}
 
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SCIPNP_EHIP, "%s: %s", what, hipGetErrorString(e));
     return SCIPNP_OK;
 }
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-#define SCIPNP_REQUIRE(cond, ...) \
-    do { if (!(cond)) return ::scipnp::fail(SCIPNP_EINVAL, __VA_ARGS__); } while (0)
-#define SCIPNP_ALIGNED(p) \
-    do { if (!::scipnp::aligned16(p)) return ::scipnp::fail(SCIPNP_EALIGN, #p " is not 16-byte aligned"); } while (0)
 
 constexpr int WAVE = 64;
 

@@ -267,34 +267,7 @@ using namespace scipnp;
 
 extern "C" {
 
-size_t scipnp_conv3x3_packed_floats(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
-    const int CoutP = round_up(Cout, 32);
-    return (size_t)(Cin / 8) * 9 * CoutP * 8 + CoutP;
-}
-
-int scipnp_pack_conv3x3_weights(const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
-                                int Cin_real, int Cout_real, int Cin, int Cout, float* packed) {
-    SCIPNP_REQUIRE(w && packed, "null pointer");
-    SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
-                   "bad channel counts Cin_real=%d Cout_real=%d Cin=%d Cout=%d", Cin_real, Cout_real, Cin, Cout);
-    const int CoutP = round_up(Cout, 32);
-    const size_t nw = (size_t)(Cin / 8) * 9 * CoutP * 8;
-    for (size_t i = 0; i < nw + CoutP; ++i) packed[i] = 0.f;
-    for (int co = 0; co < Cout_real; ++co) {
-        const float sc = bn_scale ? bn_scale[co] : 1.f;
-        for (int ci = 0; ci < Cin_real; ++ci)
-            for (int tap = 0; tap < 9; ++tap) {
-                const float v = w[((size_t)co * Cin_real + ci) * 9 + tap];
-                packed[(((size_t)(ci / 8) * 9 + tap) * CoutP + co) * 8 + (ci % 8)] = bn_scale ? v * sc : v;
-            }
-        float bv = bias ? bias[co] : 0.f;
-        if (bn_scale) bv = bv * sc;
-        if (bn_shift) bv = bv + bn_shift[co];
-        packed[nw + co] = bv;
-    }
-    return SCIPNP_OK;
-}
+/* scipnp_conv3x3_packed_floats / scipnp_pack_conv3x3_weights (host functions): csrc/host_pack.hip */
 
 int scipnp_conv3x3_c8_ex(const float* in, const float* packed_w, float* out, const float* residual,
                          const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s) {

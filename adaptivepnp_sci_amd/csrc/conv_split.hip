@@ -647,13 +647,6 @@ static int dispatch_split(SplitArgs& a, int n, hipStream_t st) {
 
 static inline int round_up_s(int v, int m) { return (v + m - 1) / m * m; }
 
-// fp32 -> (hi, lo') halves on the host (round-to-nearest-even through _Float16)
-static inline void split_host(float v, _Float16* hi, _Float16* lo) {
-    const _Float16 h = (_Float16)v;
-    *hi = h;
-    *lo = (_Float16)((v - (float)h) * CS_LO_SCALE);
-}
-
 // fp32 c8 (+ optional c8s residual) -> c8s
 __global__ void __launch_bounds__(256)
 c8_to_c8s_kernel(const float* __restrict__ in, const char* __restrict__ res, char* __restrict__ out, size_t HW,
@@ -777,49 +770,7 @@ int scipnp_ffdnet_forward_c8s_2s(const void* in_c8s, float* out_c8, const void* 
                                  void* scratch0, void* scratch1, int B, int M, int N, scipnp_stream_t s,
                                  scipnp_stream_t side_stream, void* fork_event, void* join_event);
 
-size_t scipnp_conv3x3_split_packed_bytes(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
-    const int CoutP = round_up_s(Cout, 32);
-    return (size_t)(Cin / 8) * 9 * 2 * CoutP * 16 + (size_t)CoutP * 4;
-}
-
-int scipnp_pack_conv3x3_split_bn(const float* w, const float* bias, const float* bn_scale, const float* bn_shift,
-                                 int Cin_real, int Cout_real, int Cin, int Cout, void* packed) {
-    SCIPNP_REQUIRE(w && packed, "null pointer");
-    SCIPNP_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout,
-                   "bad channel counts");
-    const int CoutP = round_up_s(Cout, 32);
-    const size_t nw_bytes = (size_t)(Cin / 8) * 9 * 2 * CoutP * 16;
-    memset(packed, 0, nw_bytes + (size_t)CoutP * 4);
-    _Float16* p = (_Float16*)packed;
-    for (int co = 0; co < Cout_real; ++co) {
-        const float sc = bn_scale ? bn_scale[co] : 1.f;
-        for (int ci = 0; ci < Cin_real; ++ci)
-            for (int tap = 0; tap < 9; ++tap) {
-                _Float16 hi, lo;
-                float wv_ = w[((size_t)co * Cin_real + ci) * 9 + tap];
-                if (bn_scale) wv_ = wv_ * sc;
-                if (!(fabsf(wv_) < 31.9f)) return fail(SCIPNP_EINVAL, "split-fp16 conv needs |w| < 31.9 (got %g)", (double)wv_);
-                split_host(wv_, &hi, &lo);
-                const size_t base = ((size_t)(ci / 8) * 9 + tap) * 2;
-                p[((base + 0) * CoutP + co) * 8 + (ci % 8)] = hi;
-                p[((base + 1) * CoutP + co) * 8 + (ci % 8)] = lo;
-            }
-    }
-    float* b = (float*)((char*)packed + nw_bytes);
-    for (int co = 0; co < Cout_real; ++co) {
-        float bv = bias ? bias[co] : 0.f;
-        if (bn_scale) bv = bv * bn_scale[co];
-        if (bn_shift) bv = bv + bn_shift[co];
-        b[co] = bv;
-    }
-    return SCIPNP_OK;
-}
-
-int scipnp_pack_conv3x3_split(const float* w, const float* bias, int Cin_real, int Cout_real, int Cin, int Cout,
-                              void* packed) {
-    return scipnp_pack_conv3x3_split_bn(w, bias, nullptr, nullptr, Cin_real, Cout_real, Cin, Cout, packed);
-}
+/* scipnp_conv3x3_split_packed_bytes / scipnp_pack_conv3x3_split[_bn] (host functions): csrc/host_pack.hip */
 
 int scipnp_conv3x3_c8s(const void* in_c8s, const void* packed_split, void* out, int n, int Cin, int Cout, int h, int w,
                        int flags, scipnp_stream_t s) {

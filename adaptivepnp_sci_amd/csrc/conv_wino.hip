@@ -27,6 +27,9 @@
 //     ds_read_b128 per lane feeds four MFMAs on the four accumulators (xi, nu = 0..3) of one half and k-step) by LDS-DMA
 //     (buffer_load_dwordx4 ... lds), no staging registers.
 #include "common.hpp"
+#ifdef SCIPNP_DIAG_BUILD
+#include "../../include/scipnp_diag.h"
+#endif
 
 namespace scipnp {
 
@@ -523,6 +526,8 @@ using namespace scipnp;
 
 extern "C" {
 
+#ifndef SCIPNP_DIAG_BUILD   /* ---- product entries (libscipnp.so) */
+
 size_t scipnp_conv3x3_wino_packed_floats(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
     const int CoutP = round_up_w(Cout, 32);
@@ -594,6 +599,24 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
     return launch_status("conv3x3_c8w_kernel");
 }
 
+int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,
+                              float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(in_c8 && out_c8 && packed_wino && scratch0 && scratch1, "null pointer");
+    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
+    float* buf[2] = {scratch0, scratch1};
+    int rc = scipnp_conv3x3_c8w(in_c8, packed_wino[0], buf[0], nullptr, nullptr, B, 16, nc, M, N, 1 | 0x100, s);
+    if (rc) return rc;
+    int cur = 0;
+    for (int l = 1; l < nb - 1; ++l) {
+        rc = scipnp_conv3x3_c8w(buf[cur], packed_wino[l], buf[cur ^ 1], nullptr, nullptr, B, nc, nc, M, N, 1, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return scipnp_conv3x3_c8w(buf[cur], packed_wino[nb - 1], out_c8, nullptr, nullptr, B, nc, 16, M, N, 0x100, s);
+}
+
+#else   /* ---- SCIPNP_DIAG_BUILD: the stamped instantiation lives in libscipnp_diag.so only (include/scipnp_diag.h) */
+
 int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float* out, int n, int Cin, int Cout, int h, int w,
                                int flags, unsigned long long* stamps, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && packed_wino && out && stamps, "null pointer");
@@ -614,20 +637,6 @@ int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float*
     return launch_status("conv3x3_c8w_kernel<stamped>");
 }
 
-int scipnp_ffdnet_forward_c8w(const float* in_c8, float* out_c8, const float* const* packed_wino, int nb, int nc,
-                              float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s) {
-    SCIPNP_REQUIRE(in_c8 && out_c8 && packed_wino && scratch0 && scratch1, "null pointer");
-    SCIPNP_REQUIRE(nb >= 2 && nc % 8 == 0 && nc > 0, "bad network shape nb=%d nc=%d", nb, nc);
-    float* buf[2] = {scratch0, scratch1};
-    int rc = scipnp_conv3x3_c8w(in_c8, packed_wino[0], buf[0], nullptr, nullptr, B, 16, nc, M, N, 1 | 0x100, s);
-    if (rc) return rc;
-    int cur = 0;
-    for (int l = 1; l < nb - 1; ++l) {
-        rc = scipnp_conv3x3_c8w(buf[cur], packed_wino[l], buf[cur ^ 1], nullptr, nullptr, B, nc, nc, M, N, 1, s);
-        if (rc) return rc;
-        cur ^= 1;
-    }
-    return scipnp_conv3x3_c8w(buf[cur], packed_wino[nb - 1], out_c8, nullptr, nullptr, B, nc, 16, M, N, 0x100, s);
-}
+#endif  /* SCIPNP_DIAG_BUILD */
 
 }  // extern "C"

@@ -34,6 +34,9 @@
 // One barrier per k-step (36 MFMAs per wave): a whole group's slab pair double-buffered (74 KiB) plus the tiles would not leave
 // room for two workgroups per CU.
 #include "common.hpp"
+#ifdef SCIPNP_DIAG_BUILD
+#include "../../include/scipnp_diag.h"
+#endif
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -698,6 +701,8 @@ using namespace scipnp;
 
 extern "C" {
 
+#ifndef SCIPNP_DIAG_BUILD   /* ---- product entries (libscipnp.so) */
+
 size_t scipnp_conv3x3_wino4_packed_floats(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
     const int CoutP = round_up_w4(Cout, 32);
@@ -776,6 +781,8 @@ int scipnp_ffdnet_forward_c8w4(const float* in_c8, float* out_c8, const float* c
     return layer(nb - 1, buf[cur], out_c8, nc, 16, 0x100);
 }
 
+#else   /* ---- SCIPNP_DIAG_BUILD: the laboratory entries (libscipnp_diag.so, include/scipnp_diag.h); the product library holds none */
+
 /* DIAGNOSTIC instantiation with s_memtime stamps of wave 0 of every workgroup (128 words per workgroup; tools/probes/wino4_stamps.py):
  * [0] entry, [1] first tiles / slab in LDS, [2] first column pass done, [8 + 4g + {0, 1, 2, 3}] k-step (g, 0) MFMAs issued | its
  * barrier passed | k-step (g, 1) MFMAs issued | its barrier passed (g < 24), [3] loop left, [4] partial tiles exchanged,
@@ -845,5 +852,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
 #undef W4_DIAG_CASE
     return launch_status("conv3x3_c8w4_kernel<diag>");
 }
+
+#endif  /* SCIPNP_DIAG_BUILD */
 
 }  // extern "C"

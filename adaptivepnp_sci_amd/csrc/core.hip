@@ -1,5 +1,5 @@
 // Library identity and the thread-local error string of the C ABI.
-#include "common.hpp"
+#include "host_common.hpp"
 #include <cstring>
 
 namespace scipnp {
@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace scipnp
 
 extern "C" {
-const char* scipnp_version(void) { return "scipnp 0.3.0 (round 3)"; }
+const char* scipnp_version(void) { return "scipnp 0.4.0 (round 4)"; }
 const char* scipnp_last_error(void) { return scipnp::g_err; }
 const char* scipnp_arch(void) { return "gfx950"; }
 }

@@ -11,7 +11,7 @@
 #include <cstddef>
 #include <cstdint>
 
-#include "../../include/scipnp.h"
+#include "host_common.hpp"
 
 namespace {
 
@@ -55,7 +55,8 @@ struct Mt {
 
 extern "C" int scipnp_host_legacy_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, double loc,
                                          double scale, double* out, size_t n) {
-    if (!key || !pos || !has_gauss || !cached_gaussian || (!out && n) || *pos < 0 || *pos > MT_N) return SCIPNP_EINVAL;
+    SCIPNP_REQUIRE(key && pos && has_gauss && cached_gaussian && (out || !n), "null pointer");
+    SCIPNP_REQUIRE(*pos >= 0 && *pos <= MT_N, "generator position %d outside the MT19937 state (0..624)", *pos);
     Mt g{key, *pos};
     int have = *has_gauss;
     double cache = *cached_gaussian;

@@ -3,6 +3,7 @@
 // operands (fp16 32x32x16, fp16 16x16x32, fp32 32x32x2) and an HBM stream (read-only reduction, copy).  Diagnostic
 // entries of the library, driven by tools/peaks_bench.py; not on the reconstruction path.
 #include "common.hpp"
+#include "../../include/scipnp_diag.h"
 
 namespace scipnp {
 

@@ -162,7 +162,7 @@ class _FFDNetTrainer:
             def wp(ci, co):
                 f4 = (torch.empty(lib.scipnp_conv3x3_wino4_packed_floats(ci, co), dtype=F32, device=dev)
                       if (ops.wino_f4_enabled() and ops.wino_f4_shape(ci, co)) else None)
-                return ops.WinoPacked(torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev), None, ci, co, f4)
+                return ops.WinoPacked(torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev), ci, co, f4)
             self.fwd_w = [wp(ci, co) for ci, co in zip(self.cin, self.cout)]
             self.bwd_w = [None] + [wp(co, ci) for ci, co in list(zip(self.cin, self.cout))[1:]]
         self.acts = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(self.nb - 1)]

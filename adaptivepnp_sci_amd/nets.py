@@ -52,12 +52,14 @@ def ffdnet_layers(model):
 
 
 def default_precision():
-    """'f16x3' (error-compensated split-fp16 MFMA, csrc/conv_split.hip) or 'f32' (fp32 MFMA, csrc/conv.hip);
-    override with SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION).  Applies to the FFDNet and FastDVDnet
-    forward passes and to the forward / backward-data convolutions of the FFDNet online finetune (its weight-gradient
-    kernel and the FastDVDnet finetune run on the fp32 MFMA)."""
+    """'f32' (the default since round 4: every product an exact fp32 product on the fp32 MFMA, the reference's arithmetic --
+    Winograd F(4x4,3x3) / F(2x2,3x3) / direct kernels, csrc/conv_wino4.hip, conv_wino.hip, conv.hip) or the opt-in 'f16x3'
+    (error-compensated split-fp16 operands on the fp16 MFMA, csrc/conv_split.hip: 22 significant bits per operand, fp32
+    accumulation, ~1.2-1.3x faster, inside the 1e-5 / 1e-4 dB gates but NARROWER than the reference's fp32).
+    Set with SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION) or the engines' `precision=` / the solvers'
+    `conv_precision=` argument.  Applies to the FFDNet / FastDVDnet / DDnet passes and their online finetune."""
     import os
-    p = os.environ.get('SCIPNP_CONV_PRECISION', os.environ.get('SCIPNP_FFDNET_PRECISION', 'f16x3'))
+    p = os.environ.get('SCIPNP_CONV_PRECISION', os.environ.get('SCIPNP_FFDNET_PRECISION', 'f32'))
     if p not in ('f32', 'f16x3'):
         raise ValueError("SCIPNP_CONV_PRECISION must be 'f32' or 'f16x3'")
     return p
@@ -67,8 +69,10 @@ WINO_MAX_PIXELS = 1 << 25          # csrc/conv_wino.hip addresses a plane throug
 
 
 def f32_conv_form(h=None, w=None):
-    """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, csrc/conv_wino.hip -- 2.25x fewer products, every one an exact
-    fp32 product) or 'direct' (csrc/conv.hip) for the stride-1 layers of the fp32 FFDNet pass; SCIPNP_F32_CONV.
+    """'winograd' (default: F(4x4,3x3) on the fp32 MFMA for layers of >= 16 input and >= 32 output channels,
+    csrc/conv_wino4.hip -- 4x fewer products than the direct form, every one an exact fp32 product; F(2x2,3x3),
+    csrc/conv_wino.hip, for the narrower layers or with SCIPNP_WINO_F4=0) or 'direct' (csrc/conv.hip) for the stride-1
+    layers of the fp32 passes; SCIPNP_F32_CONV.
     Planes of h x w >= 2^25 pixels (FFDNet on frames beyond 11585 x 11585) take the direct form, which has no such bound."""
     import os
     f = os.environ.get('SCIPNP_F32_CONV', 'winograd')
@@ -128,7 +132,6 @@ class FFDNetEngine:
             for i in range(self.nb):
                 cin = self.cin0 if i == 0 else self.nc
                 cout = self.cout_last if i == self.nb - 1 else self.nc
-                # (96-output-channel layers also get the slab layout of the persistent kernel, csrc/conv_winop.hip)
                 self.packed_wino.append(ops.pack_conv3x3_wino_both(self.packed[i], cin, cout))
 
     def adopt(self, packed_f32, packed_split=None):

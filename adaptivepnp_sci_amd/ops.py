@@ -339,11 +339,6 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
         if packed_wino.f4 is not None and not rows16 and wino_f4_enabled():
             return conv3x3_c8w4(x, packed_wino.f4, Cout, relu=relu, residual=residual, mask_src=mask_src, out=out, head=head,
                                 shuffle=shuffle)
-        if packed_wino.p is not None and not (rows16 or shuffle) and persistent_wino_enabled():
-            _timed_call('conv3x3_c8p_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8p', _p(x, 'x'),
-                        _p(packed_wino.p, 'packed_winop'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'),
-                        n, cg * 8, Cout, h, w, flags, _stream())
-            return out
         packed_wino = packed_wino.w
     _timed_call('conv3x3_c8w_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w', _p(x, 'x'),
                 _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
@@ -377,12 +372,12 @@ def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None
 
 class WinoPacked:
     """Winograd-domain weights of one layer for conv3x3_c8w: `w` = the scipnp_pack_conv3x3_wino packing (every shape and
-    epilogue), `f4` = the F(4x4,3x3) packing of scipnp_conv3x3_c8w4 for the layer shapes that kernel is used for, else None,
-    `p` = the slab layout of the persistent F(2x2) kernel scipnp_conv3x3_c8p (96 output channels), else None."""
-    __slots__ = ('w', 'p', 'f4', 'cin', 'cout')
+    epilogue), `f4` = the F(4x4,3x3) packing of scipnp_conv3x3_c8w4 for the layer shapes that kernel is used for, else None.
+    (The persistent F(2x2) kernel of round 3, csrc/conv_winop.hip, lives in libscipnp_diag.so: measured, not adopted.)"""
+    __slots__ = ('w', 'f4', 'cin', 'cout')
 
-    def __init__(self, w, p, cin, cout, f4=None):
-        self.w, self.p, self.f4, self.cin, self.cout = w, p, f4, cin, cout
+    def __init__(self, w, cin, cout, f4=None):
+        self.w, self.f4, self.cin, self.cout = w, f4, cin, cout
 
     def data_ptr(self):                                   # (C-entry callers pass the classic packing)
         return self.w.data_ptr()
@@ -402,24 +397,11 @@ def wino_f4_shape(Cin, Cout):
     return Cin >= 16 and Cout >= 32
 
 
-def persistent_wino_enabled():
-    """SCIPNP_WINO_PERSISTENT=1 puts the 96-output-channel fp32 F(2x2,3x3) layers on the persistent kernel (csrc/conv_winop.hip).
-    Off by default: bit-identical to the classic kernel but measured 366-370 us against 334-336 us on the FFDNet body layer
-    (profiles/r03_winop_ablate.txt)."""
-    import os
-    return os.environ.get('SCIPNP_WINO_PERSISTENT', '0') == '1'
-
-
 def pack_conv3x3_wino_both(packed_f32, Cin, Cout):
     """the Winograd packings of a layer from its fp32 direct packing (device buffers)"""
     w = pack_conv3x3_wino(packed_f32, Cin, Cout)
-    p = None
-    lib = _lib.load()
-    if persistent_wino_enabled() and lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
-        p = torch.empty(lib.scipnp_conv3x3_winop_packed_floats(Cin, Cout), dtype=F32, device=packed_f32.device)
-        _call('scipnp_pack_conv3x3_winop', _p(packed_f32, 'packed_f32'), _p(p, 'packed_winop'), Cin, Cout, _stream())
     f4 = pack_conv3x3_wino4(packed_f32, Cin, Cout) if (wino_f4_enabled() and wino_f4_shape(Cin, Cout)) else None
-    return WinoPacked(w, p, Cin, Cout, f4)
+    return WinoPacked(w, Cin, Cout, f4)
 
 
 def pack_conv3x3_split(weight, bias=None, Cin=None, Cout=None, device=None, bn_scale=None, bn_shift=None):

@@ -160,22 +160,26 @@ class AdmmRun:
             self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
             self.w = torch.zeros_like(self.x_rgb) if two_stage else None
             self.out_store = torch.empty_like(self.x_rgb)
-            if denoiser == 'ffdnet_color':
-                self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
-            else:
-                from .fastdvd import FastDVDEngine
-                self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision)
-                self.rgb_w = torch.empty_like(self.x_rgb)
-            if self.eng.precision == 'f16x3':
+            # the range-guard word exists BEFORE the engines do: their constructors pack the split-fp16 weights, and a weight
+            # outside the representable range (|w| >= 31.9, e.g. after a BatchNorm fold) must raise THIS solve's word
+            from .nets import default_precision
+            if (conv_precision or default_precision()) == 'f16x3':
                 self.ovf_word = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self.dd = None
-            if model_demosaic is not None:       # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
-                if not two_stage:
-                    raise ValueError('model_demosaic is an argument of the two-stage solver only (as in the reference)')
-                from .ddnet import DDnetEngine
-                self.dd = DDnetEngine(model_demosaic, B, H, W, self.device, precision=conv_precision)
-                self.dd_planes = torch.empty_like(x0)
-                self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
+            with ops.overflow_scope(self.ovf_word):
+                if denoiser == 'ffdnet_color':
+                    self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
+                else:
+                    from .fastdvd import FastDVDEngine
+                    self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision)
+                    self.rgb_w = torch.empty_like(self.x_rgb)
+                self.dd = None
+                if model_demosaic is not None:   # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
+                    if not two_stage:
+                        raise ValueError('model_demosaic is an argument of the two-stage solver only (as in the reference)')
+                    from .ddnet import DDnetEngine
+                    self.dd = DDnetEngine(model_demosaic, B, H, W, self.device, precision=conv_precision)
+                    self.dd_planes = torch.empty_like(x0)
+                    self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
 
     # ------------------------------------------------------------------ one ADMM iteration
     def step(self, nsig, last=False):
@@ -407,11 +411,13 @@ class GrayAdmmRun:
             if model is None:
                 raise ValueError("denoiser 'ffdnet_gray' needs model= (an FFDNet(in_nc=1, out_nc=1, nc=64, nb=15) with the "
                                  'ffdnet_gray weights loaded)')
-            self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
+            from .nets import default_precision
+            if (conv_precision or default_precision()) == 'f16x3':      # before the engine packs its split-fp16 weights
+                self.ovf_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+            with ops.overflow_scope(self.ovf_word):
+                self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
             if self.eng.in_ch != 5:
                 raise ValueError('ffdnet_gray needs the grayscale network (5 -> nc -> 4 channels)')
-            if self.eng.precision == 'f16x3':
-                self.ovf_word = torch.zeros(1, dtype=torch.int32, device=self.device)
         else:
             if (H * W) % 16:
                 raise ValueError('tv_gray needs H*W to be a multiple of 16')
@@ -484,6 +490,7 @@ def _run_tv_graphed(run, total):
     256 x 256 x 8, 50 iterations, the whole call takes 5.0 ms with capture + instantiate + 49 replays against 4.1 ms for
     50 eager iterations -- one solve is too short to amortise the capture; it pays for schedules of several hundred
     iterations."""
+    run.flush()                              # a pending deferred dual update lands before deferral is switched off
     run._tv_args.defer_state = None          # (a captured step must leave its squared-error row complete)
     run.step(0)
     n = total - 1

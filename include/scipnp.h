@@ -342,7 +342,9 @@ int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const f
  * of the FFDNet / FastDVDnet / DDnet engines for their stride-1 layers (SCIPNP_F32_CONV=direct selects the direct kernel).
  * packed_wino: scipnp_conv3x3_wino_packed_floats(Cin, Cout) floats, derived ON THE DEVICE from a buffer packed by
  * scipnp_pack_conv3x3_weights / _device(_scaled) (so bias, BatchNorm folding and the transposed backward-data packing
- * carry over); layout [Cin/8][CoutP/32][16 positions][co/16][ci/4][co%16][ci%4], then bias[CoutP].
+ * carry over); layout [Cin/8][CoutP/32][xi][h][j][lane][nu] -- per channel group and 32-channel block the 16-byte vector
+ * a lane reads for (patch row xi, channel half h, k-step j): its four column positions nu, lane = (ci%4)*16 + co%16
+ * (pack_wino_kernel, csrc/conv_wino.hip) -- then bias[CoutP].
  * flags: bit0 ReLU, bit1 add `residual`, bit3 PixelShuffle(2) folded into the store (out and residual [n][Cout/32][2h][2w][8],
  *        Cout a multiple of 32, as scipnp_conv3x3_c8_ex; the shuffled tile is assembled in LDS and stored in whole 128-byte lines),
  *        bit4 ReLU-backward mask from `mask_src`, bit8 head-layer tag (as conv3x3_c8_ex).
@@ -358,7 +360,7 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
 /* ---- fp32 Winograd F(4x4,3x3) form (csrc/conv_wino4.hip, round 3): 36 exact fp32 products per 16 outputs and channel pair,
  * 2.25 multiply-adds per output (F(2x2): 4, direct: 9), interpolation points 0, +-1, +-2, inf, fp32 accumulation on
  * v_mfma_f32_16x16x4_f32; results equal to scipnp_conv3x3_c8 up to fp32 re-association and the transforms' rounding
- * (<= 3e-6 relative L2 per layer in tests/test_gpu_ops.py; 3e-7 through the 12 FFDNet layers against float64).
+ * (<= 4e-6 relative L2 per layer in tests/test_gpu_ops.py; 3e-7 through the 12 FFDNet layers against float64).
  * packed_wino4: scipnp_conv3x3_wino4_packed_floats(Cin, Cout) floats derived on the device from the fp32 direct packing
  * (U = G g G^T in double), layout [2*Cin/8 k-steps][CoutP/32][xi half][9 vectors][lane][4], then bias[CoutP].
  * flags: bit0 ReLU, bit1 add `residual`, bit3 PixelShuffle(2) folded into the store (out and residual [n][Cout/32][2h][2w][8], Cout a
@@ -376,45 +378,6 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
  * scipnp_conv3x3_c8w with packed_wino[l]; other arguments as scipnp_ffdnet_forward_c8w. */
 int scipnp_ffdnet_forward_c8w4(const float* in_c8, float* out_c8, const float* const* packed_wino, const float* const* packed_wino4,
                                int nb, int nc, float* scratch0, float* scratch1, int B, int M, int N, scipnp_stream_t s);
-
-/* DIAGNOSTIC instantiation of scipnp_conv3x3_c8w4 with s_memtime stamps of wave 0 of every workgroup, written by scalar stores
- * (128 words per workgroup, grid = ceil(w/64)*ceil(h/8)*n*ceil(Cout/32); tools/probes/wino4_stamps.py): [0] entry, [1] first
- * tiles / slab in LDS, [2] first column pass done, [8 + 4g + {0,1,2,3}] k-step (g,0) MFMAs issued | its barrier passed | k-step
- * (g,1) MFMAs issued | its barrier passed (g < 24), [3] loop left, [4] partial tiles exchanged, [5] stores issued, [6] stores
- * acknowledged, [7] XCC_ID << 32 | HW_ID.  No product path calls it; the product kernel executes no stamp. */
-int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
-                                int flags, unsigned long long* stamps, scipnp_stream_t s);
-/* diagnostic: the F(4x4) kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
- * diag: bit0 no input transform, bit1 no raw-tile staging, bit2 no U LDS-DMA, bit3 no barriers in the K loop, bit4 no MFMAs,
- * bit5 no output transform / stores */
-int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
-                             int flags, int diag, scipnp_stream_t s);
-
-/* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
- * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
- * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of
- * 4-row x 32-column units with the channel-group pipeline running across unit boundaries.  Weights in their own slab layout:
- * scipnp_pack_conv3x3_winop from the fp32 direct packing (scipnp_conv3x3_winop_packed_floats floats; 0 if unsupported).
- * flags: bit0 ReLU, bit1 residual (fp32 c8, output shape), bit4 ReLU mask (mask_src), bit8 head tag; stride 1 only.
- * scipnp_conv3x3_c8p_supported(Cin, Cout) = 1 for Cin % 8 == 0, Cout == 96. */
-int scipnp_conv3x3_c8p_supported(int Cin, int Cout);
-size_t scipnp_conv3x3_winop_packed_floats(int Cin, int Cout);
-int scipnp_pack_conv3x3_winop(const float* packed_f32, float* packed_winop, int Cin, int Cout, scipnp_stream_t s);
-int scipnp_conv3x3_c8p(const float* in, const float* packed_winop, float* out, const float* residual, const float* mask_src,
-                       int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
-/* diagnostic: the same kernel with parts switched off (timing only, WRONG results) -- tools/probes/winop_ablate.py */
-int scipnp_conv3x3_c8p_diag(const float* in, const float* packed_winop, float* out, int n, int Cin, int Cout, int h, int w,
-                            int flags, int diag, scipnp_stream_t s);
-
-/* DIAGNOSTIC instantiation of scipnp_conv3x3_c8w (layers with more than 16 outputs, flags bit0 only): the same kernel
- * with six s_memtime stamps per workgroup; no product path calls it and the product kernel executes no stamp.
- * stamps: 80 words per workgroup (grid = ceil(w/32)*ceil(h/8)*n*ceil(Cout/32)), written by its first lane:
- * [0] kernel entry, [1] first raw tiles + U slab in LDS, [2] first input transform done, [3] channel-group loop done,
- * [4] output transform done and stores issued, [5] stores acknowledged, [6] XCC_ID << 32 | HW_ID, [7] s_memrealtime
- * (100 MHz) at the end ([31]: at entry), [8 + g] end of channel group g (g < 24); with flags bit11 also
- * [32 + 16(g - 4) + p] after Winograd position p of groups g = 4, 5.  tools/probes/wino_stamps.py reads them. */
-int scipnp_conv3x3_c8w_stamped(const float* in, const float* packed_wino, float* out, int n, int Cin, int Cout, int h, int w,
-                               int flags, unsigned long long* stamps, scipnp_stream_t s);
 
 /* The whole FFDNet-colour pass (test_ffdnet_ipol.py:340-359 -> network_ffdnet.py:65-66) as ONE call on the Winograd
  * kernel: same arguments as scipnp_ffdnet_forward with every layer packed by scipnp_pack_conv3x3_wino. */
@@ -634,24 +597,6 @@ int scipnp_ddnet_mix(const float* branches, const float* gates, float* out, int 
  * entry does not. */
 int scipnp_host_legacy_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, double loc, double scale,
                               double* out, size_t n);
-
-/* ---------------------------------------------------------------------------------------------------------------
- * Diagnostics: measured ceilings for the rooflines (tools/peaks_bench.py; not on the reconstruction path).
- * scipnp_bench_mfma: register-resident MFMA loop on pseudo-random operands, mode 0 v_mfma_f32_32x32x16_f16,
- * 1 v_mfma_f32_16x16x32_f16, 2 v_mfma_f32_32x32x2_f32; `blocks` workgroups of 4 waves, iters x 4 (mode 1: x 8)
- * independent MFMAs per wave; out: blocks*256 floats.  scipnp_bench_stream: mode 0 reads n floats (sink: blocks*256
- * floats), mode 1 copies n floats.
- * ------------------------------------------------------------------------------------------------------------- */
-int scipnp_bench_mfma(float* out, int blocks, int iters, int mode, scipnp_stream_t s);
-/* scipnp_bench_mfma_valu: how much vector-ALU issue a matrix instruction hides -- per MFMA (f32 != 0:
- * v_mfma_f32_16x16x4_f32, else v_mfma_f32_32x32x16_f16; 32 matrix-pipe cycles either way) nv (0, 1, 2, 4, 6, 8) independent
- * v_add_f32 of the same wave; cycles[blocks*4]: s_memtime ticks of each wave's loop of iters x 16 MFMAs. */
-int scipnp_bench_mfma_valu(float* out, unsigned long long* cycles, int blocks, int iters, int nv, int f32, scipnp_stream_t s);
-/* accumulation-chain issue patterns of v_mfma_f32_16x16x4_f32: second use of an accumulator `dist` MFMAs behind the first */
-int scipnp_bench_mfma_dep(float* out, unsigned long long* cycles, int blocks, int iters, int dist, scipnp_stream_t s);
-/* VGPR-bank placement of the A / B operands of v_mfma_f32_16x16x4_f32 (var 0..3, csrc/peaks.hip) */
-int scipnp_bench_mfma_bank(float* out, unsigned long long* cycles, int blocks, int iters, int var, scipnp_stream_t s);
-int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,9 @@ def test_bench_rccl_gather_world_size_1(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['ranks'] == 1 and line['units_gathered_on_rank0'] == 1
-    assert 'RCCL' in line['collective'] and line['dtype'] == 'f32' and line['fast_path']['dtype'] == 'f16x3'
+    assert 'RCCL' in line['collective'] and line['dtype'] == 'f32' and line['forms']['f16x3']['value'] > 0
+    assert line['world_size'] == 1 and 'nccl' in line['backend'] and line['ranks_devices'][0][:2] == [0, 0]
+    assert len(r.stdout.strip().splitlines()) == 1 and len(r.stdout) < 4200        # ONE compact line on stdout, nothing else
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'bench_rccl_world1.log'), 'w') as f:
@@ -94,7 +96,8 @@ def test_bench_spawns_two_ranks_sharing_the_gpu():
     assert len(out) == 1, out
     line = json.loads(out[0])
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['units_gathered_on_rank0'] == 2
-    assert line['cpu_baseline'] is None and line['value'] > 0 and line['fast_path']['value'] > line['value']
+    assert line['cpu_baseline'] is None and line['value'] > 0 and line['forms']['f16x3']['value'] > line['value']
+    assert line['world_size'] == 2 and [d[0] for d in line['ranks_devices']] == [0, 1] and len(out[0]) <= 4096
 
 
 @pytest.mark.gpu
@@ -115,7 +118,12 @@ def test_bench_fixed_total_modes_two_ranks_sharing_the_gpu(mode):
     assert line['units_per_rank'] == [n_units // 2] * 2
     assert len(line['per_rank_solve_s']) == 2 and len(line['per_rank_gather_s']) == 2 and min(line['per_rank_solve_s']) > 0
     assert line['value'] > 0 and abs(line['ms_per_step'] * line['steps'] - 1e3 * line['timed_region_s']) < 1e-6
-    assert 0 < line['roofline']['frac'] <= 1
+    assert 0 < line['roofline']['frac'] <= 1 and len(out[0]) <= 4096
+    # the roofline describes the launch this mode RUNS: 256x256x16 tiles / 512x512x8 cubes, their own FLOPs
+    shape = [256, 256, 16] if 'tile1024' in mode else [512, 512, 8]
+    assert line['roofline']['launch_shape'] == shape
+    assert abs(line['roofline']['flop_per_launch'] / (2 * 9 * 96 * 96 * (shape[0] // 2) * (shape[1] // 2) * shape[2] / 4) - 1) < 1e-3
+    assert line['roofline']['traffic'] is None
     if 'tile1024' in mode:
         assert line['finetune_events_per_tile'] == 1 and line['stitched_psnr_db'] > 12
 
@@ -130,3 +138,78 @@ def test_driver_sigma_schedule_scales_with_steps():
     half = [b.driver_sigma(k, 50) for k in range(50)]
     assert half == [25 / 255] * 30 + [12 / 255] * 12 + [6 / 255] * 8
     assert b.driver_sigma(0, 1) == 25 / 255 or b.driver_sigma(0, 1) in b.DRIVER_SIGMA
+
+
+# ------------------------------------------------------------------------------------------------ the output contract
+def _bench_module(name='bench_mod_emit'):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def _canned_records():
+    """full records of earlier judged runs (round 3's 23 KB line, which the driver could not parse, among them)"""
+    prof = os.path.join(ROOT, 'profiles')
+    out = {}
+    for f in ('r03f_bench_line.json', 'r03f_bench_tile1024_line.json', 'r03f_bench_cubes2_line.json', 'r02l_bench_line.json'):
+        txt = [l for l in open(os.path.join(prof, f)) if l.startswith('{')][-1]
+        out[f] = json.loads(txt)
+    return out
+
+
+def test_compact_line_fits_and_round_trips():
+    """the final stdout line: <= 4096 bytes, valid JSON, carrying the contract's keys and the roofline / cpu_baseline blocks"""
+    b = _bench_module()
+    recs = _canned_records()
+    assert len(json.dumps(recs['r03f_bench_line.json'])) > 20000                 # the record that broke the driver's parser
+    for name, full in recs.items():
+        line = b.compact_line(full, 'gpurun_out/bench_detail_x.json')
+        assert len(line) <= 4096 and '\n' not in line, (name, len(line))
+        got = json.loads(line)
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                  'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'detail'):
+            assert k in got, (name, k)
+        assert abs(got['value'] / full['value'] - 1) < 1e-3 and got['config']['workload']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in got['roofline'], (name, k)
+        assert abs(got['roofline']['frac'] - full['roofline']['frac']) < 1e-3
+    head = json.loads(b.compact_line(recs['r03f_bench_line.json']))
+    assert head['cpu_baseline']['cores'] == 14 and head['cpu_baseline']['kind'] == 'port' and head['cpu_baseline']['parity']['f32']
+    assert head['forms']['f16x3']['value'] > head['value'] and head['configs']['fastdvd_512']['f32']['ms_per_iteration'] > 0
+    assert head['phi_step']['frac'] > 0 and head['phi_step']['chain']['frac'] > 0
+
+
+def test_compact_line_never_exceeds_the_limit_whatever_the_record_holds():
+    b = _bench_module('bench_mod_emit2')
+    full = _canned_records()['r03f_bench_line.json']
+    full['configs'] = {f'config_{i}': {'f32': {'ms_per_iteration': 1.0 + i, 'frac': 0.5, 'layers': [{'x': 1.0}] * 100},
+                                        'parity': {'f32': {'max_rel_l2_per_iterate': 1e-7}}} for i in range(200)}
+    full['data'] = 'x' * 3000
+    line = b.compact_line(full, 'd.json')
+    assert len(line) <= 4096
+    got = json.loads(line)
+    assert got['value'] == float(f"{full['value']:.4g}") and got['roofline']['frac'] > 0 and got['cpu_baseline']['value'] > 0
+
+
+def test_emit_prints_exactly_one_line_and_writes_the_detail_file(tmp_path):
+    """emit(): the full record lands in the detail file, stdout gets the compact line and nothing else -- even when the
+    process printed log lines before (claim_stdout sends them to stderr)"""
+    code = (
+        'import importlib.util, json, sys\n'
+        f'spec = importlib.util.spec_from_file_location("bench_mod", {BENCH!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n'
+        'b.claim_stdout()\n'
+        'print("loss: 0.0640")\n'
+        'import ctypes; ctypes.CDLL(None).puts(b"C-level banner")\n'
+        f'full = json.loads([l for l in open({os.path.join(ROOT, "profiles", "r03f_bench_line.json")!r}) if l.startswith("{{")][-1])\n'
+        'b.emit(full, "unit_test_n1")\n')
+    r = subprocess.run([sys.executable, '-c', code], env=_env(SCIPNP_BENCH_DETAIL_DIR=str(tmp_path)), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and len(lines[0]) <= 4096
+    line = json.loads(lines[0])
+    assert 'loss: 0.0640' in r.stderr and 'C-level banner' in r.stderr
+    detail = json.load(open(tmp_path / 'bench_detail_unit_test_n1.json'))
+    assert detail['configs']['fastdvd_512']['f32']['layers'] and line['detail'].endswith('bench_detail_unit_test_n1.json')

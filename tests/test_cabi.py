@@ -20,10 +20,16 @@ def lib():
     return _lib.load()
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, 'include', 'scipnp.h')).read()
+def header_symbols(name='scipnp.h'):
+    src = open(os.path.join(ROOT, 'include', name)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(scipnp_\w+)\s*\(', src)))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('scipnp_')})
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
@@ -34,6 +40,29 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f'{n} declared in include/scipnp.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.py'
     assert sorted(_lib.SIGNATURES) == names
+    # ... and the product library exports NOTHING else: no micro-benchmark, no stamped / ablated kernel instantiation
+    assert exported_symbols(_lib.LIB_PATH) == names
+
+
+def test_the_laboratory_is_a_separate_library(lib):
+    """include/scipnp_diag.h <-> libscipnp_diag.so: peaks.hip's micro-benchmarks, the DIAG / stamped instantiations of the
+    Winograd kernels and conv_winop.hip are built, exported and bound THERE; the product header and library hold none of them"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import diaglib
+    from adaptivepnp_sci_amd import _lib
+    dlib = diaglib.load()
+    names = header_symbols('scipnp_diag.h')
+    assert len(names) == 13 and sorted(diaglib.SIGNATURES) == names
+    assert exported_symbols(diaglib.DIAG_LIB_PATH) == names
+    assert not set(names) & set(header_symbols()) and not set(names) & set(_lib.SIGNATURES)
+    for n in names:
+        assert hasattr(dlib, n) and not hasattr(lib, n), n
+    # argument errors of the laboratory entries surface through the product library's error string
+    assert dlib.scipnp_bench_mfma(C.c_void_p(256), 1, 1, 7, None) == -1 and lib.scipnp_last_error()
+    for src in ('peaks.o', 'conv_winop.o'):                                  # (objects of the lab never enter the product link)
+        mk = open(os.path.join(ROOT, 'adaptivepnp_sci_amd', 'csrc', 'Makefile')).read()
+        assert src in mk.split('DIAG_OBJS =')[1].splitlines()[0] and src.replace('.o', '.hip') not in mk.split('\nSRCS =')[1].splitlines()[0]
 
 
 def test_identity(lib):
@@ -125,7 +154,6 @@ def test_argument_errors_of_the_wider_entries(lib):
     assert lib.scipnp_frame_metrics(None, None, None, 32, 32, 8, 7, 1.0, C.byref(nb), None) == 0 and nb.value == 16   # size query
     assert lib.scipnp_conv3x3_wgrad_split(p, p, p, p, 0, 1, 96, 96, 96, 96, 8, 8, 1.0, None) == -1   # nslab = 0
     assert lib.scipnp_conv3x3_wgrad_split(C.c_void_p(260), p, p, p, 4, 1, 96, 96, 96, 96, 8, 8, 1.0, None) == -2
-    assert lib.scipnp_bench_mfma(p, 1, 1, 7, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')

@@ -884,3 +884,40 @@ def test_fastdvdnet_solver_short_and_odd_cubes(solver, B):
     for k in range(2):
         assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, (B, k, rel_l2(tr.it[k], o['theta_iterates'][k]))
     assert rel_l2(res[0], o['rgb']) <= REL_TOL
+
+
+@pytest.mark.parametrize('entry', ['bayer', 'gray'])
+def test_out_of_range_weight_is_reported_by_the_split_fp16_path(solver, ffdnet_state_dict, entry, monkeypatch):
+    """the split-fp16 range guard must cover the engine's INITIAL weight packing (the constructors pack before the
+    first step): a weight outside the representable range (|w| >= 31.9 after the 2^11 pre-scale; e.g. from a BatchNorm
+    fold) has to surface as ScipnpError at the end of the solve, not as silently degraded iterates.  The fp32 default takes
+    the same model without complaint."""
+    from adaptivepnp_sci_amd import _lib, synth
+    if entry == 'bayer':
+        sd = {k: v.clone() for k, v in ffdnet_state_dict.items()}
+        sd['model.2.weight'][3, 5, 1, 1] = 100.0
+        y, Phi, orig = synth.make_problem(32, 32, 4, seed=2)
+
+        def run(prec):
+            monkeypatch.setenv('SCIPNP_CONV_PRECISION', prec)
+            return solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2], False, [25 / 255], X_orig=orig,
+                                                     model_denoise=make_ffdnet(sd), logf=io.StringIO())
+    else:
+        from adaptivepnp_sci_amd.nets import FFDNet
+        g = load_gold('ffdnet_gray_weights')
+        sd = {k: torch.from_numpy(g[k]).clone() for k in g.files}
+        sd['model.2.weight'][3, 5, 1, 1] = 100.0
+        rng = np.random.default_rng(0)
+        orig = rng.random((32, 32, 4), dtype=np.float32)
+        Phi = (rng.random((32, 32, 4)) > 0.5).astype(np.float32)
+        y = (Phi * orig).sum(2).astype(np.float32)
+
+        def run(prec):
+            monkeypatch.setenv('SCIPNP_CONV_PRECISION', prec)
+            net = FFDNet(in_nc=1, out_nc=1, nc=64, nb=15)
+            net.load_state_dict(sd)
+            return solver.admm_denoise_gray(y, Phi, None, 'ffdnet_gray', iter_max=[2], sigma=[25 / 255], X_orig=orig, model=net,
+                                            logf=io.StringIO())
+    with pytest.raises(_lib.ScipnpError, match='fp16'):
+        run('f16x3')
+    run('f32')

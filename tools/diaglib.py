@@ -1,0 +1,81 @@
+"""ctypes binding of libscipnp_diag.so -- the laboratory beside the product library (include/scipnp_diag.h): MFMA / HBM
+micro-benchmarks, stamped and ablated instantiations of the Winograd kernels, the persistent F(2x2) kernel that was measured and
+not adopted.  Used by bench.py (`measured_peaks`), tools/peaks_bench.py, tools/probes/* and two -m gpu tests; nothing under
+adaptivepnp_sci_amd/ imports this module."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from adaptivepnp_sci_amd import _lib  # noqa: E402
+
+DIAG_LIB_PATH = os.environ.get('SCIPNP_DIAG_LIB', os.path.join(ROOT, 'adaptivepnp_sci_amd', 'libscipnp_diag.so'))
+_vp, _int, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/scipnp_diag.h declares
+SIGNATURES = {
+    'scipnp_bench_mfma': (_int, [_vp, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_valu': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_dep': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_bench_mfma_bank': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
+    'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
+    'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
+    'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8p_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+}
+
+_diag = None
+
+
+def load():
+    """libscipnp_diag.so with every declared symbol bound (loads the product library first: the two share the error string)"""
+    global _diag
+    if _diag is not None:
+        return _diag
+    _lib.load()
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise _lib.ScipnpError(f'{DIAG_LIB_PATH} not found: `make -C adaptivepnp_sci_amd/csrc` builds it next to libscipnp.so')
+    lib = C.CDLL(DIAG_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise _lib.ScipnpError(f'libscipnp_diag.so lacks symbol {name}; rebuild the library') from e
+        fn.restype = res
+        fn.argtypes = args
+    _diag = lib
+    return lib
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def pack_winop(packed_f32, Cin, Cout):
+    """slab layout of the persistent F(2x2,3x3) kernel from the fp32 direct packing (device buffers); None if unsupported"""
+    import torch
+    lib = load()
+    if not lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
+        return None
+    p = torch.empty(lib.scipnp_conv3x3_winop_packed_floats(Cin, Cout), dtype=torch.float32, device=packed_f32.device)
+    _lib.check(lib.scipnp_pack_conv3x3_winop(_p(packed_f32), _p(p), Cin, Cout, _lib.stream_ptr()), 'scipnp_pack_conv3x3_winop')
+    return p
+
+
+def conv3x3_c8p(x, packed_winop, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+    """the persistent 96-output-channel F(2x2,3x3) kernel (csrc/conv_winop.hip); arguments as ops.conv3x3_c8w"""
+    import torch
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
+    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0)
+    _lib.check(load().scipnp_conv3x3_c8p(_p(x), _p(packed_winop), _p(out), _p(residual), _p(mask_src), n, cg * 8, Cout, h, w, flags,
+                                         _lib.stream_ptr()), 'scipnp_conv3x3_c8p')
+    return out

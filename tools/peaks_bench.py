@@ -6,7 +6,9 @@ import ctypes as C, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import _lib
-lib = _lib.load()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+lib = diaglib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 

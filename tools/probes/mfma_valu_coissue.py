@@ -5,7 +5,9 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import _lib
-lib = _lib.load()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
+import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+lib = diaglib.load()
 iters = 4000
 names = {1: 'v_mfma_f32_16x16x4_f32 + v_add_f32   ', 2: 'v_mfma_f32_16x16x4_f32 + v_pk_add_f32', 3: 'v_mfma_f32_16x16x4_f32 + ds_read_b128',
          0: 'v_mfma_f32_32x32x16_f16 + v_add_f32  '}

@@ -7,7 +7,9 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import _lib, ops
-lib = _lib.load()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
+import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+lib = diaglib.load()
 n, c, h, w = 8, 96, 256, 256
 g = torch.Generator().manual_seed(0)
 x8 = ops.to_c8(torch.randn(n, c, h, w, generator=g).cuda())

@@ -12,7 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
+import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+lib = diaglib.load()
 dev = torch.device('cuda:0')
 B, Cn, M, N = 8, int(os.environ.get('WS_C', 96)), 256, 256
 torch.manual_seed(0)
