@@ -679,8 +679,8 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
         peak_meas = measured.get('mfma_f32_32x32x2_2wave_per_simd_TFLOPs')
         tr = _pick(traffic, 'conv3x3_c8_kernel<3, 0')
     src = traffic_src
-    if shape is not None and tuple(shape) != (H, W, B):
-        tr, src = None, 'not collected for this launch shape'
+    if shape is not None:                            # fixed-total modes: no PMC pass runs for them, no borrowed figure either
+        tr, src = None, 'not collected in this mode'
     elif tr is None:                                 # no live PMC pass: the committed profile, named
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):

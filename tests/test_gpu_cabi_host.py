@@ -129,8 +129,12 @@ def test_plain_c_host_reconstructs_like_the_python_solver(tmp_path):
     warm = admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [tv_iters], False, [0], logf=io.StringIO())[0]
     net = FFDNet()
     net.load_state_dict({k: torch.from_numpy(g[k]) for k in g.files})
-    ref = twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [iters], False, [float(sigma)], x0_bayer=warm,
-                                     model_denoise=net, logf=io.StringIO())[1]
+    os.environ['SCIPNP_CONV_PRECISION'] = 'f16x3'          # the C host's first mode is the (opt-in) split-fp16 path
+    try:
+        ref = twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [iters], False, [float(sigma)], x0_bayer=warm,
+                                         model_denoise=net, logf=io.StringIO())[1]
+    finally:
+        os.environ.pop('SCIPNP_CONV_PRECISION', None)
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
     # the same from C in fp32 arithmetic (Winograd kernels; scipnp_twostage_ffdnet_args.packed_wino / net_in_c8)
     out32 = str(tmp_path / 'out32.bin')

@@ -3,11 +3,14 @@ golden vectors generated from the reference.  Tolerances are written next to eac
 streaming kernels are expected BIT-EXACT (same fp32 operations in the same order as the
 reference's PyTorch expressions); the Malvar correlations, TV and the MFMA convolutions differ from
 the CPU libraries only in summation order -> tight relative-L2 bounds."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_gold, rel_l2
+from conftest import ROOT, load_gold, rel_l2
 
 pytestmark = pytest.mark.gpu
 

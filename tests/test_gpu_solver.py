@@ -916,7 +916,7 @@ def test_out_of_range_weight_is_reported_by_the_split_fp16_path(solver, ffdnet_s
             monkeypatch.setenv('SCIPNP_CONV_PRECISION', prec)
             net = FFDNet(in_nc=1, out_nc=1, nc=64, nb=15)
             net.load_state_dict(sd)
-            return solver.admm_denoise_gray(y, Phi, None, 'ffdnet_gray', iter_max=[2], sigma=[25 / 255], X_orig=orig, model=net,
+            return solver.admm_denoise_gray(y, Phi, denoiser='ffdnet_gray', iter_max=[2], sigma=[25 / 255], X_orig=orig, model=net,
                                             logf=io.StringIO())
     with pytest.raises(_lib.ScipnpError, match='fp16'):
         run('f16x3')
