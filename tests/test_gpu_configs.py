@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import load_gold, rel_l2
 
 pytestmark = pytest.mark.gpu
 REL_TOL, PSNR_TOL = 1e-5, 1e-4
@@ -88,6 +88,39 @@ def test_config2_fastdvdnet_512x512x8(solver, precision, monkeypatch):
     for k in range(2):
         assert rel_l2(tr.it[k], o['theta_iterates'][k]) <= REL_TOL, k
     assert rel_l2(res[0], o['rgb']) <= REL_TOL
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_config2_fastdvdnet_driver_schedule_vs_reference_golden(solver, precision, monkeypatch):
+    """The reference driver's own FastDVDnet schedule, free-running, against iterates captured FROM THE REFERENCE
+    (tests/golden/fastdvdadmm_long_64x64x8.npz, tools/make_golden.py fastdvdlong): sigma 8/255 x 18 iterations, rho 0.55, online
+    finetune lr 2e-6 x 2 Adam steps firing once at k = 9 (two_stage_ADMM_Online_FastDVD_Warm.py:68-75), 64 x 64 x 8, seeded
+    synthetic weights -- EVERY one of the 18 iterates within 1e-5 relative L2, every per-iteration PSNR within 1e-4 dB,
+    through the weight update.  (The full-size 18-iteration run below is checked through the agreement of the three
+    convolution forms; this test is the parity evidence for the long schedule.)"""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
+    g = load_gold('fastdvdadmm_long_64x64x8')
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
+    np.random.seed(42)                                           # worker_init_fn(0) of the reference (utilspy.py:22-25)
+    tr = Trace()
+    solver.ITERATE_HOOK = tr
+    res = solver.twoStageAdmm_denoise_bayer(g['y'], g['Phi'], 1, 0.01, 'fastdvd_color', [18], False, [8 / 255], x0_bayer=g['warm'],
+                                            X_orig=g['orig'], model_denoise=net, logf=io.StringIO(), lr_=2e-6, inital_iter=1,
+                                            interval_iter=9, update_=True, update_per_iter=2, update_times=1)
+    assert len(tr.it) == 18
+    errs = [rel_l2(tr.it[k], g['theta'][k]) for k in range(18)]
+    assert max(errs) <= REL_TOL, errs
+    assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL
+    assert rel_l2(res[1], g['final']) <= REL_TOL and rel_l2(res[0], g['rgb']) <= REL_TOL
+    assert np.abs(np.array(res[2]) - g['psnr_frames']).max() <= PSNR_TOL
+    # the one finetune event changed the weights by what the reference's Adam steps changed them
+    w0 = synth_fastdvdnet_weights(0).state_dict()
+    sd = net.state_dict()
+    for key in ('temp1.inc.convblock.0.weight', 'temp2.outc.convblock.3.weight', 'temp2.downc0.convblock.0.weight'):
+        d = float(torch.norm(sd['module.' + key].float() - w0[key].float()))
+        want = float(g[key.replace('.', '_') + '_dnorm'])
+        assert want > 0 and abs(d / want - 1) < 2e-2, (key, d, want)
 
 
 def test_config2_fastdvdnet_full_driver_schedule(solver, monkeypatch):

