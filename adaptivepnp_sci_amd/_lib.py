@@ -37,6 +37,9 @@ SIGNATURES = {
     'scipnp_cube_to_rgb': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_pm_setup': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_pm_project': (_int, [_vp] * 6 + [_int, _int, _int, _int, _flt, _flt, _vp]),
+    'scipnp_pm_setup_units': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_pm_dual_project_blocks': (_int, [_int, _int, _int, _int, _int]),
+    'scipnp_pm_project_units': (_int, [_vp] * 6 + [_int, _int, _int, _int, _int, _flt, _flt, _vp]),
     'scipnp_tv_workspace_bytes': (_sz, [_int, _int, _int, _int]),
     'scipnp_tv_chambolle': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _flt, _flt, _int, _vp, _sz, _vp, _vp]),
     'scipnp_tv_chambolle_ex': (_int, [_vp, _vp, _flt, _vp, _int, _int, _int, _flt, _flt, _int, _vp, _sz, _vp, _int, _vp]),
@@ -133,7 +136,7 @@ class AdmmTvArgs(C.Structure):
                 ('c0', C.c_double), ('c1', C.c_double), ('tv_weight', C.c_float), ('tv_iters', C.c_int),
                 ('tv_workspace', C.c_void_p), ('tv_workspace_bytes', C.c_size_t),
                 ('orig', C.c_void_p), ('sse_part', C.c_void_p),
-                ('defer_state', C.POINTER(C.c_int)), ('sse_part_prev', C.c_void_p)]
+                ('defer_state', C.POINTER(C.c_int)), ('sse_part_prev', C.c_void_p), ('units', C.c_int)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)
@@ -152,7 +155,8 @@ class TwoStageFfdnetArgs(C.Structure):
                 ('sigma', C.c_float), ('first_iter', C.c_int),
                 ('packed_wino', C.c_void_p), ('net_in_c8', C.c_void_p),
                 ('overflow_word', C.c_void_p), ('side_stream', C.c_void_p),
-                ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p), ('packed_wino4', C.c_void_p)]
+                ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p), ('packed_wino4', C.c_void_p),
+                ('units', C.c_int)]
 
     def __init__(self, **kw):
         super().__init__(C.sizeof(type(self)), **kw)

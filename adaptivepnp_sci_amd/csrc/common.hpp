@@ -258,10 +258,11 @@ __device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc,
 // element i of channel c = i / MN comes from theta_raw[(sel[c] - 1) * img + i]) and scipnp_pm_dual_project doing the stop test
 // of the candidate form itself (cd != nullptr; weight / eps of the TV step as doubles)
 int pm_dual_update_sel(const float* theta_raw, const int32_t* sel, const float* x, float* theta, float* b, const float* orig,
-                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st);
+                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st, int units = 1);
+void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid);
 int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cd, double tv_weight, double tv_eps, float* x, float* theta,
                         float* b, const float* Phi, const float* y, const float* Phisum, const float* orig, double* sse_part,
-                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st);
+                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st, int units = 1);
 // tv.hip: Chambolle TV + ADMM dual update of planes up to 128 x 128 in one launch (used by iterate.hip)
 bool tv_plane_dual_fits(int M, int N, int C, int nfill, bool want_sse);
 int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int N, int C, float weight, float eps,

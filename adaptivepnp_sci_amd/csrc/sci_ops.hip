@@ -447,13 +447,16 @@ pm_project_anyB_kernel(const float* __restrict__ theta, const float* __restrict_
     }
 }
 
+// units > 1: U independent problems of one shape in the UNIT-BATCHED layout, state [B][U][4][M][N], measurement [U][4][M][N] --
+// the projection is per mosaic pixel with a sum over the pixel's own B frames, so the U units are simply 4 M N U pixels.
 template <int MODE>
 static int launch_pm_project(const float* theta, const float* b, const float* Phi, const float* y,
                              const float* Phisum_in, float* Phisum_out, float* x, int M, int N, int B,
-                             float c0, float c1, hipStream_t st) {
+                             float c0, float c1, hipStream_t st, int units = 1) {
     SCIPNP_REQUIRE(M > 0 && N > 0 && B > 0 && B <= TORCH_SUM_RT_MAX, "bad shape M=%d N=%d B=%d (B <= %d)", M, N, B,
                    TORCH_SUM_RT_MAX);
-    const long long Q = 4LL * M * N;
+    SCIPNP_REQUIRE(units >= 1, "units must be >= 1 (got %d)", units);
+    const long long Q = 4LL * M * N * units;
     const bool vec = (Q % 4 == 0) && aligned16(Phi) && aligned16(y) && (x == nullptr || aligned16(x)) &&
                      (MODE == 2 ? aligned16(Phisum_out) : (aligned16(theta) && aligned16(b) && aligned16(Phisum_in)));
     const int threads = 256;
@@ -497,11 +500,12 @@ __global__ void __launch_bounds__(256)
 pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates cd, int use_cd, double tv_weight, double tv_eps,
                        float* xio, float* theta, float* bb,
                        const float* __restrict__ Phi, const float* __restrict__ y, const float* __restrict__ Phisum,
-                       const float* __restrict__ orig, double* sse_part, int nfill, long long Q, int B, float c0, float c1, int CH) {
+                       const float* __restrict__ orig, double* sse_part, int nfill, long long Q, long long MN, int B, float c0,
+                       float c1, int CH) {
     using V = typename VecT<VEC>::type;
     __shared__ double red[16];
-    __shared__ int s_sel[4 * 32];                       // [plane of the workgroup's pixels - first one][frame]
-    const long long MN = Q >> 2;
+    __shared__ int s_sel[4 * 32];                       // [plane of the workgroup's pixels - first one][frame] (host: <= 4 planes)
+    const int P = (int)(Q / MN);                        // planes per frame: 4 Bayer planes x units (unit-batched layout)
     // a workgroup owns CH consecutive chunks of blockDim.x * VEC pixels (CH > 1 only where one workgroup per chunk would be
     // more squared-error partials than the caller's buffer holds)
     const long long per = (long long)blockDim.x * VEC;
@@ -537,7 +541,7 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
                     const int j = j0 + ((threadIdx.x & 63) >> 3);
                     const bool on = j < nib * B;
                     const int t = on ? j % B : 0, ibl = on ? j / B : 0;
-                    const int c = t * 4 + ib_lo + ibl;
+                    const int c = t * P + ib_lo + ibl;
                     const int st = tv_band_stop_test8(on ? cd.part + (size_t)c * cd.nbands * 2 * cd.n_iter : nullptr, cd.nbands,
                                                       cd.n_iter, cd.MN, tv_weight, tv_eps);
                     if (on && (threadIdx.x & 7) == 0) s_sel[ibl * 32 + t] = st;
@@ -545,7 +549,7 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
             } else {
                 for (int j = wave; j < nib * B; j += nw) {
                     const int t = j % B, ibl = j / B;
-                    const int c = t * 4 + ib_lo + ibl;
+                    const int c = t * P + ib_lo + ibl;
                     const int st = tv_band_stop_test(cd.part + (size_t)c * cd.nbands * 2 * cd.n_iter, cd.nbands, cd.n_iter, cd.MN,
                                                      tv_weight, tv_eps);
                     if ((threadIdx.x & 63) == 0) s_sel[ibl * 32 + t] = st;
@@ -615,6 +619,19 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
         if (blockIdx.x == 0)
             for (int i = gridDim.x + threadIdx.x; i < nfill; i += blockDim.x) sse_part[i] = 0.0;
     }
+}
+
+// launch shape of pm_dual_project_kernel: pixels per thread, chunks per workgroup (more than one only where one workgroup per
+// chunk would be more squared-error partials than the caller's nfill entries), workgroups
+void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid) {
+    const int threads = 256;
+    const bool wide = Q / 4 >= 512LL * threads;               // (as launch_pm_project: small states take one pixel per thread)
+    const int v = (vec_ok && wide) ? (B <= 16 ? 4 : 2) : 1;
+    const long long nchunks = (Q / v + threads - 1) / threads;
+    const int ch = nfill > 0 ? (int)((nchunks + nfill - 1) / nfill) : 1;
+    *VEC = v;
+    *CH = ch;
+    *grid = (unsigned)((nchunks + ch - 1) / ch);
 }
 
 // ===================================================================== dual update (+ SSE partials)
@@ -781,17 +798,33 @@ int scipnp_pm_project(const float* theta, const float* b, const float* Phi, cons
 int scipnp_pm_dual_update(const float* theta_raw, const float* x, float* theta, float* b,
                           const float* orig, double* sse_part, int which, float sign, int M, int N, int B,
                           int* nblocks, scipnp_stream_t s) {
-    return pm_dual_update_sel(theta_raw, nullptr, x, theta, b, orig, sse_part, which, sign, M, N, B, nblocks, (hipStream_t)s);
+    return pm_dual_update_sel(theta_raw, nullptr, x, theta, b, orig, sse_part, which, sign, M, N, B, nblocks, (hipStream_t)s, 1);
+}
+
+/* unit-batched layout (include/scipnp.h, "Unit batches"): U problems of one shape, state [B][U][4][M][N], y / Phisum [U][4][M][N] */
+int scipnp_pm_setup_units(const float* Phi, const float* y, float* Phisum, float* x0, int M, int N, int B, int units,
+                          scipnp_stream_t s) {
+    SCIPNP_REQUIRE(Phi && y && Phisum, "null pointer");
+    return launch_pm_project<2>(nullptr, nullptr, Phi, y, nullptr, Phisum, x0, M, N, B, 0.f, 0.f, (hipStream_t)s, units);
+}
+
+int scipnp_pm_project_units(const float* theta, const float* b, const float* Phi, const float* y, const float* Phisum, float* x,
+                            int M, int N, int B, int units, int mode, float c0, float c1, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(theta && b && Phi && y && Phisum && x, "null pointer");
+    SCIPNP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (two-stage) or 1 (one-stage)");
+    if (mode == 0) return launch_pm_project<0>(theta, b, Phi, y, Phisum, nullptr, x, M, N, B, c0, c1, (hipStream_t)s, units);
+    return launch_pm_project<1>(theta, b, Phi, y, Phisum, nullptr, x, M, N, B, c0, c1, (hipStream_t)s, units);
 }
 
 }  // extern "C"
 
 namespace scipnp {
 int pm_dual_update_sel(const float* theta_raw, const int32_t* sel, const float* x, float* theta, float* b, const float* orig,
-                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st) {
+                       double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st, int units) {
     SCIPNP_REQUIRE(theta_raw && x && theta && b, "null pointer");
     SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
-    const long long total = 4LL * M * N * B;
+    SCIPNP_REQUIRE(units >= 1, "units must be >= 1");
+    const long long total = 4LL * M * N * B * units;
     const int per = RED_THREADS * RED_PER_THREAD;
     const unsigned blocks = (unsigned)((total + per - 1) / per);
     if (nblocks) *nblocks = (int)blocks;
@@ -805,11 +838,21 @@ extern "C" {
 
 int scipnp_pm_dual_project_fits(int M, int N, int B) { return M > 0 && N > 0 && B > 0 && B <= 32; }
 
+/* workgroups (= squared-error partials actually written; the rest of the nfill entries are zeros) of the fused launch on
+ * `units` problems of M x N x B with 16-byte aligned buffers -- for a caller that cuts the partials at unit boundaries */
+int scipnp_pm_dual_project_blocks(int M, int N, int B, int units, int nfill) {
+    if (M <= 0 || N <= 0 || B <= 0 || B > 32 || units < 1) return 0;
+    int vec, ch;
+    unsigned grid;
+    scipnp::dual_project_shape(4LL * M * N * units, B, nfill, (long long)M * N % 4 == 0, &vec, &ch, &grid);
+    return (int)grid;
+}
+
 int scipnp_pm_dual_project(const float* theta_raw, float* x, float* theta, float* b, const float* Phi, const float* y,
                            const float* Phisum, const float* orig, double* sse_part, int nfill, int M, int N, int B, int mode,
                            float c0, float c1, scipnp_stream_t s) {
     return pm_dual_project_sel(theta_raw, nullptr, 0.0, 0.0, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, M, N, B, mode, c0,
-                               c1, (hipStream_t)s);
+                               c1, (hipStream_t)s, 1);
 }
 
 }  // extern "C"
@@ -817,8 +860,9 @@ int scipnp_pm_dual_project(const float* theta_raw, float* x, float* theta, float
 namespace scipnp {
 int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double tv_weight, double tv_eps, float* x, float* theta,
                         float* b, const float* Phi, const float* y, const float* Phisum, const float* orig, double* sse_part,
-                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st) {
+                        int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st, int units) {
     SCIPNP_REQUIRE(theta_raw && x && theta && b && Phi && y && Phisum, "null pointer");
+    SCIPNP_REQUIRE(units >= 1, "units must be >= 1");
     TvCandidates cd = {};
     const int use_cd = cdp != nullptr;
     if (use_cd) cd = *cdp;
@@ -826,29 +870,30 @@ int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double 
     SCIPNP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (two-stage) or 1 (one-stage)");
     SCIPNP_REQUIRE(scipnp_pm_dual_project_fits(M, N, B), "fused dual update + projection: 1 <= B <= 32 (got %d)", B);
     SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
-    const long long Q = 4LL * M * N;
+    const long long Q = 4LL * M * N * units, MN = (long long)M * N;
     // (vector paths: every thread's pixels in one Bayer plane and every candidate plane set 16-byte aligned)
     const bool vec = ((long long)M * N % 4 == 0) && aligned16(Phi) && aligned16(y) && aligned16(x) && aligned16(theta) && aligned16(b) &&
                      aligned16(Phisum) && aligned16(theta_raw) && (orig == nullptr || aligned16(orig));
     const int threads = 256;
+    int VECs, CH;
     unsigned grid;
+    dual_project_shape(Q, B, sse_part ? nfill : 0, vec, &VECs, &CH, &grid);
+    SCIPNP_REQUIRE(sse_part == nullptr || nfill > 0, "sse_part needs nfill > 0");
+    // the candidate form keeps the stop iteration of at most 4 planes per workgroup (always true for one unit)
+    SCIPNP_REQUIRE(!use_cd || units == 1 || ((long long)CH * threads * VECs - 1) / MN + 2 <= 4,
+                   "unit-batched candidate form: planes of %lld pixels are too small for this launch shape", MN);
 #define SCIPNP_DP(VEC, MAXB)                                                                                     \
     do {                                                                                                         \
-        const long long nchunks = (Q / VEC + threads - 1) / threads;                                             \
-        SCIPNP_REQUIRE(sse_part == nullptr || nfill > 0, "sse_part needs nfill > 0");                            \
-        const int CH = sse_part ? (int)((nchunks + nfill - 1) / nfill) : 1;                                      \
-        grid = (unsigned)((nchunks + CH - 1) / CH);                                                              \
         if (mode == 0)                                                                                           \
             hipLaunchKernelGGL((pm_dual_project_kernel<VEC, MAXB, 0>), dim3(grid), dim3(threads), 0, st, theta_raw, cd, use_cd, \
-                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, B, c0, c1, CH); \
+                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1, CH); \
         else                                                                                                     \
             hipLaunchKernelGGL((pm_dual_project_kernel<VEC, MAXB, 1>), dim3(grid), dim3(threads), 0, st, theta_raw, cd, use_cd, \
-                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, B, c0, c1, CH); \
+                               tv_weight, tv_eps, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1, CH); \
     } while (0)
-    const bool wide = Q / 4 >= 512LL * threads;               // (as launch_pm_project: small states take one pixel per thread)
-    if (vec && wide && B <= 8) SCIPNP_DP(4, 8);
-    else if (vec && wide && B <= 16) SCIPNP_DP(4, 16);
-    else if (vec && wide) SCIPNP_DP(2, 32);
+    if (VECs == 4 && B <= 8) SCIPNP_DP(4, 8);
+    else if (VECs == 4) SCIPNP_DP(4, 16);
+    else if (VECs == 2) SCIPNP_DP(2, 32);
     else if (B <= 8) SCIPNP_DP(1, 8);
     else if (B <= 16) SCIPNP_DP(1, 16);
     else SCIPNP_DP(1, 32);

@@ -149,11 +149,26 @@ def pm_setup(Phi, y, want_x0=True):
     return Phisum, x0
 
 
-def pm_project(theta, b, Phi, y, Phisum, mode, c0, c1, out):
-    B, _, M, N = Phi.shape
-    _call('scipnp_pm_project', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
-          _p(out, 'out'), M, N, B, int(mode), float(np.float32(c0)), float(np.float32(c1)), _stream())
+def pm_project(theta, b, Phi, y, Phisum, mode, c0, c1, out, units=1):
+    """units > 1: the unit-batched layout (include/scipnp.h, "Unit batches"): Phi [B*U][4][M][N] with frame f = t*U + u,
+    y / Phisum [U*4][M][N]"""
+    BU, _, M, N = Phi.shape
+    if units == 1:
+        _call('scipnp_pm_project', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
+              _p(out, 'out'), M, N, BU, int(mode), float(np.float32(c0)), float(np.float32(c1)), _stream())
+    else:
+        _call('scipnp_pm_project_units', _p(theta, 'theta'), _p(b, 'b'), _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum, 'Phisum'),
+              _p(out, 'out'), M, N, BU // units, int(units), int(mode), float(np.float32(c0)), float(np.float32(c1)), _stream())
     return out
+
+
+def pm_setup_units(Phi, y, units, want_x0=True):
+    """pm_setup on the unit-batched layout: Phi [B*U][4][M][N] (frame f = t*U + u), y [U*4][M][N] -> Phisum [U*4][M][N], x0"""
+    BU, _, M, N = Phi.shape
+    Phisum = torch.empty(units * 4, M, N, device=Phi.device, dtype=F32)
+    x0 = torch.empty_like(Phi) if want_x0 else None
+    _call('scipnp_pm_setup_units', _p(Phi, 'Phi'), _p(y, 'y'), _p(Phisum), _p(x0), M, N, BU // units, int(units), _stream())
+    return Phisum, x0
 
 
 class TvPlan:

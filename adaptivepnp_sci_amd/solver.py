@@ -76,7 +76,14 @@ class AdmmRun:
     def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
                  show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
                  update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None,
-                 conv_precision=None, Phi_sum=None):
+                 conv_precision=None, Phi_sum=None, units=None):
+        """units=U (round 4): a UNIT BATCH -- y_bayer, Phi_bayer (and x0_bayer, X_orig when given) are sequences of U
+        problems of ONE shape that share the denoiser weights; they are stepped by ONE launch sequence (the reference loops
+        its measurements one after the other, two_stage_ADMM_Online_FFD_Warm.py:241-275).  State layout [B][U][4][M][N]
+        (frame f = t*U + u): the projection sees 4 M N U pixels, every other kernel B*U frames / 4*B*U planes; each unit's
+        numbers are bit-identical to its own single-unit run.  'tv' and 'ffdnet_color' (Malvar or closed-form demosaic);
+        a finetune event needs per-unit weights: split() the batch before the gate fires.  result_mosaic(), psnr_all() and
+        final_report() then return one entry per unit."""
         if str(denoiser).lower() not in DENOISERS:
             raise ValueError('Unsupported denoiser {}!'.format(denoiser))
         denoiser = denoiser.lower()                # the reference compares denoiser.lower() (:146, :164, :214)
@@ -85,17 +92,43 @@ class AdmmRun:
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.denoiser, self.two_stage, self.model = denoiser, two_stage, model
         self.logf = logf or _NullLog()
-        Phi = _dev(Phi_bayer, self.device)
-        y = _dev(y_bayer, self.device)
+        self.U = U = 1 if units is None else int(units)
+        if units is not None:
+            if U < 1 or len(y_bayer) != U or len(Phi_bayer) != U or any(v is not None and len(v) != U for v in (x0_bayer, X_orig)):
+                raise ValueError(f'units={units}: y_bayer, Phi_bayer (x0_bayer, X_orig) must be sequences of {units} problems')
+            if denoiser not in ('tv', 'ffdnet_color') or model_demosaic is not None or Phi_sum is not None:
+                raise ValueError("unit batches: denoiser 'tv' or 'ffdnet_color', Malvar / closed-form demosaic, no Phi_sum "
+                                 '(FastDVDnet and DDnet look across the frames of a unit)')
+            ys, Phis = list(y_bayer), list(Phi_bayer)
+            x0s = None if x0_bayer is None else list(x0_bayer)
+            origs = None if X_orig is None else list(X_orig)
+        else:
+            ys, Phis = [y_bayer], [Phi_bayer]
+            x0s = None if x0_bayer is None else [x0_bayer]
+            origs = None if X_orig is None else [X_orig]
+        Phis = [_dev(p, self.device) for p in Phis]
+        ys = [_dev(v, self.device) for v in ys]
+        Phi, y = Phis[0], ys[0]
         if Phi.dim() != 3 or y.shape != Phi.shape[:2] or Phi.shape[0] % 2 or Phi.shape[1] % 2:
             raise ValueError(f'expected y (H,W) and Phi (H,W,B) with even H,W; got {tuple(y.shape)} {tuple(Phi.shape)}')
+        if any(p.shape != Phi.shape for p in Phis) or any(v.shape != y.shape for v in ys):
+            raise ValueError('unit batches: every unit must have the shape of the first one')
         self.H, self.W, self.B = Phi.shape
         self.M, self.N = self.H // 2, self.W // 2
         B, M, N, H, W = self.B, self.M, self.N, self.H, self.W
+        self.BU = BU = B * U
+
+        def batch_state(cubes):        # U cubes (H,W,B) -> [B][U][4][M][N] as a (B*U, 4, M, N) tensor (one cube: [B][4][M][N])
+            st = [ops.mosaic_to_state(_dev(c, self.device)) for c in cubes]
+            return st[0] if U == 1 else torch.stack(st, dim=1).reshape(BU, 4, M, N)
+
         # ---- setup (reference :59-95 / :347-381)
-        self.Phi = ops.mosaic_to_state(Phi)
-        self.y = ops.y_to_meas(y)
-        self.Phisum, x0 = ops.pm_setup(self.Phi, self.y, want_x0=x0_bayer is None)
+        self.Phi = batch_state(Phis)
+        self.y = ops.y_to_meas(y) if U == 1 else torch.stack([ops.y_to_meas(v) for v in ys]).reshape(U * 4, M, N)
+        if U == 1:
+            self.Phisum, x0 = ops.pm_setup(self.Phi, self.y, want_x0=x0_bayer is None)
+        else:
+            self.Phisum, x0 = ops.pm_setup_units(self.Phi, self.y, U, want_x0=x0_bayer is None)
         if Phi_sum is not None:
             # admm_denoise / gap_denoise(y, Phi, Phi_sum, ...): the caller's normaliser (H,W) is USED as given, after the
             # reference's zeros -> 1 (:74-75 / :361-362); pm_setup's own sum of Phi over the frames is dropped
@@ -105,15 +138,19 @@ class AdmmRun:
             ps[ps == 0] = 1
             self.Phisum = ops.y_to_meas(_dev(ps, self.device))
         if x0_bayer is not None:
-            x0 = ops.mosaic_to_state(_dev(x0_bayer, self.device))
+            x0 = batch_state(x0s)
         self.theta = x0                  # x and theta are ONE tensor in the reference until the first clip
         self.x = torch.empty_like(x0)
         self.b = torch.zeros_like(x0)
         self.orig = self.orig_np = None
         if X_orig is not None:
-            self.orig_np = X_orig if isinstance(X_orig, np.ndarray) else X_orig.detach().cpu().numpy()
-            self.orig = ops.mosaic_to_state(_dev(X_orig, self.device))
+            if U == 1:
+                self.orig_np = X_orig if isinstance(X_orig, np.ndarray) else X_orig.detach().cpu().numpy()
+            self.orig = batch_state(origs)
         self.iqa = bool(show_iqa and X_orig is not None)
+        if U > 1 and denoiser == 'tv' and self.iqa and (4 * M * N) % 2048:
+            raise ValueError('unit batches with per-iteration PSNR (X_orig + show_iqa) on the TV path need H*W to be a multiple of '
+                             '2048: the squared-error partials are cut at unit boundaries')
         self.sse_rows = []
         # ---- constants (reference :101-110; one-stage uses _lambda/gamma directly)
         if two_stage:
@@ -138,22 +175,32 @@ class AdmmRun:
         # range-guard word of THIS solve's split-fp16 launches (include/scipnp.h, scipnp_bind_overflow_word): bound around
         # every step, read once at the end -- a neighbouring solve on another host thread / stream has its own
         self.ovf_word = None
-        # ---- prior workspaces
+        self.conv_precision, self.model_demosaic = conv_precision, model_demosaic
+        self._init_workspaces()
+
+    def _init_workspaces(self):
+        """prior workspaces for the state as it stands (TV plan + the one-call argument block, or the RGB buffers and the
+        network engines); also run by split() for each unit of a batch"""
+        denoiser, two_stage, model, conv_precision, model_demosaic = (self.denoiser, self.two_stage, self.model, self.conv_precision,
+                                                                       self.model_demosaic)
+        B, M, N, H, W, U, x0 = self.BU, self.M, self.N, self.H, self.W, self.U, self.theta      # (B: frames of the whole batch)
         if denoiser == 'tv':
             self.plan = ops.TvPlan(M, N, 4 * B, 5, self.device)
             self.theta_raw = torch.empty_like(x0)
             # the whole iteration is one C call (scipnp_admm_tv_iterate): ten launches of 5-25 us are host-bound when
             # issued one ctypes call at a time
             c0, c1 = (self.rou, self.alpha) if two_stage else (self._lambda, self.gamma)
-            self._tv_args = _lib.AdmmTvArgs(M, N, B, int(two_stage), self.theta.data_ptr(), self.b.data_ptr(), self.x.data_ptr(),
+            self._tv_args = _lib.AdmmTvArgs(M, N, self.B, int(two_stage), self.theta.data_ptr(), self.b.data_ptr(), self.x.data_ptr(),
                                             self.theta_raw.data_ptr(), self.Phi.data_ptr(), self.y.data_ptr(),
                                             self.Phisum.data_ptr(), float(c0), float(c1), 0.1, 5, self.plan.ptr,
                                             self.plan.nbytes, 0 if self.orig is None else self.orig.data_ptr(), 0)
+            self._tv_args.units = U
             # two launches per iteration: the dual update of an iteration rides in the launch that projects the next one
             # (scipnp_admm_tv_args.defer_state); theta, b and the last squared-error row are brought up to date by flush(),
             # which every reader of the state calls.  SCIPNP_TV_DEFER=0: three launches, nothing pending between steps.
             self._tv_defer = C.c_int(0)
             self._tv_prev_row = None
+            self._row_kinds = []             # unit batches: 'flat' / 'fused' per squared-error row (see _unit_rows)
             if os.environ.get('SCIPNP_TV_DEFER', '1') != '0':
                 self._tv_args.defer_state = C.pointer(self._tv_defer)
         else:
@@ -183,19 +230,24 @@ class AdmmRun:
 
     # ------------------------------------------------------------------ one ADMM iteration
     def step(self, nsig, last=False):
-        B, M, N = self.B, self.M, self.N
+        B, M, N = self.BU, self.M, self.N          # (B: frames of the whole unit batch)
         k = self.k
         if self.denoiser == 'tv' and self.phi_events is None:
             part = self._new_sse(ops.sse_nblocks(self.x.numel())) if self.iqa else None
             self._tv_args.sse_part = 0 if part is None else part.data_ptr()
             self._tv_args.sse_part_prev = 0 if self._tv_prev_row is None else self._tv_prev_row.data_ptr()
             self._tv_prev_row = part
+            pending = self._tv_defer.value
             _lib.check(_lib.load().scipnp_admm_tv_iterate(C.byref(self._tv_args), None,
                                                           _lib.stream_ptr()),
                        'scipnp_admm_tv_iterate')
+            if part is not None and self.U > 1:          # which launch wrote which row (their partial layouts differ, _unit_rows)
+                if pending and len(self._row_kinds) >= 1:
+                    self._row_kinds[-1] = 'fused'         # the previous iteration's row: by this call's fused launch
+                self._row_kinds.append(None if self._tv_defer.value else 'flat')
             if ITERATE_HOOK is not None:
                 self.flush()
-                ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
+                ITERATE_HOOK(k, self._reported_mosaic())
             self.k += 1
             return
         self.flush()
@@ -205,10 +257,11 @@ class AdmmRun:
         if self.two_stage:
             inv_rho = 1 / self.rou
             ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 0, inv_rho, self.alpha * self.rou,
-                           out=self.x)
+                           out=self.x, units=self.U)
             coef, sign, which = inv_rho, +1.0, 0
         else:
-            ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x)
+            ops.pm_project(self.theta, self.b, self.Phi, self.y, self.Phisum, 1, self._lambda, self.gamma, out=self.x,
+                           units=self.U)
             coef, sign, which = -1.0, -1.0, 1
         if self.phi_events is not None:
             ev[1].record()
@@ -223,12 +276,15 @@ class AdmmRun:
             with ops.overflow_scope(self.ovf_word):
                 self._cnn_step(nsig, k, last)
         if ITERATE_HOOK is not None:
-            ITERATE_HOOK(k, ops.state_to_mosaic(self.theta if self.two_stage else self.x))
+            ITERATE_HOOK(k, self._reported_mosaic())
         self.k += 1
 
     def _cnn_step(self, nsig, k, last):
-        B, M, N = self.B, self.M, self.N
+        B, M, N = self.BU, self.M, self.N
         gate = bool(self.update_ and k > self.inital_iter and k % self.interval_iter == 0)
+        if gate and self.U > 1:
+            raise _lib.ScipnpError(f'iteration {k} fires the online finetune: the units of a batch share ONE set of weights; '
+                                   'split() the batch into per-unit runs (each with its own model) before this iteration')
         if self.two_stage:
             b_in, inv_rho, inv_tau, w = self.b, 1 / self.rou, 1 / self.tau, self.w
         else:
@@ -301,6 +357,8 @@ class AdmmRun:
         step pending, see __init__); a no-op otherwise"""
         if self.denoiser == 'tv' and self._tv_defer.value:
             _lib.check(_lib.load().scipnp_admm_tv_flush(C.byref(self._tv_args), None, _lib.stream_ptr()), 'scipnp_admm_tv_flush')
+            if self._row_kinds and self._row_kinds[-1] is None:
+                self._row_kinds[-1] = 'flat'              # (the flush's stand-alone dual update wrote the pending row)
 
     @property
     def log_lag(self):
@@ -315,11 +373,85 @@ class AdmmRun:
         self.sse_rows.append(t)
         return t
 
-    def psnr_all(self):
-        """One read-back for all iterations: PSNR_k = 10 log10(1 / mean sq err) (skimage formula)."""
-        if not self.sse_rows:
-            return []
+    def split(self, models=None):
+        """The units of a batch as U independent single-unit runs that continue exactly where the batch stands (iteration count,
+        state, duals, RGB buffers, per-iteration squared-error history): for the part of a schedule that needs per-unit
+        weights -- from the first online-finetune event on, models[u] (its own copy of the denoiser) is unit u's model."""
+        if self.U == 1:
+            return [self]
         self.flush()
+        U, B, H, W = self.U, self.B, self.H, self.W
+        rows = self._unit_rows(self.sse_rows) if self.sse_rows else [[] for _ in range(U)]
+        keep = ('device', 'denoiser', 'two_stage', 'logf', 'H', 'W', 'B', 'M', 'N', 'iqa', 'alpha', 'rou', 'tau', '_lambda', 'gamma',
+                'lr_', 'inital_iter', 'interval_iter', 'update_', 'update_per_iter', 'update_times', 'close_form', 'update_i', 'k',
+                'profile_events', 'phi_events', 'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
+        runs = []
+        for u in range(U):
+            r = AdmmRun.__new__(AdmmRun)
+            for name in keep:
+                if name in self.__dict__:
+                    setattr(r, name, self.__dict__[name])
+            r.U, r.BU = 1, B
+            r.model = self.model if models is None else models[u]
+            r.Phi, r.theta, r.x, r.b = (self._unit_state(t, u) for t in (self.Phi, self.theta, self.x, self.b))
+            r.orig = None if self.orig is None else self._unit_state(self.orig, u)
+            r.orig_np = None
+            r.y, r.Phisum = self.y[4 * u:4 * u + 4].contiguous(), self.Phisum[4 * u:4 * u + 4].contiguous()
+            r.sse_rows = list(rows[u])
+            r.out_rgb = None
+            r.ovf_word = None
+            r._init_workspaces()
+            if self.denoiser != 'tv':
+                for name in ('x_rgb', 'w', 'out_store'):
+                    src = getattr(self, name)
+                    if src is not None:
+                        getattr(r, name).copy_(src.view(B, U, 3, H, W)[:, u])
+            runs.append(r)
+        return runs
+
+    def _unit_state(self, t, u):
+        """unit u of a batched state tensor [B][U][4][M][N] as its own contiguous [B][4][M][N]"""
+        return t if self.U == 1 else t.view(self.B, self.U, 4, self.M, self.N)[:, u].contiguous()
+
+    def _reported_mosaic(self):
+        st = self.theta if self.two_stage else self.x
+        if self.U == 1:
+            return ops.state_to_mosaic(st)
+        return [ops.state_to_mosaic(self._unit_state(st, u)) for u in range(self.U)]
+
+    def _unit_rows(self, rows):
+        """squared-error partial rows of a unit batch -> per unit, in the order of the unit's own single-unit run: the
+        post-denoise kernel writes its partials frame-major (frame f = t*U + u), the flat dual-update / fused-projection kernels
+        pixel-major over [B][U][4 M N] resp. [U][4 M N] with unit-aligned blocks (checked in __init__)"""
+        U, B = self.U, self.B
+        out = [[] for _ in range(U)]
+        for i, r in enumerate(rows):
+            n = r.numel()
+            if self.denoiser != 'tv' or self._row_kinds[i] == 'flat':
+                v = r.view(B, U, n // (B * U)).permute(1, 0, 2).reshape(U, -1)
+            else:                                         # fused launch: one partial per workgroup over the pixel axis, then zeros
+                g = self._tv_fused_blocks()
+                v = r[:g].view(U, g // U)
+            for u in range(U):
+                out[u].append(v[u].contiguous())
+        return out
+
+    def _tv_fused_blocks(self):
+        """workgroups (= real squared-error partials) of the fused dual-update + projection launch on this state"""
+        return _lib.load().scipnp_pm_dual_project_blocks(self.M, self.N, self.B, self.U, ops.sse_nblocks(self.x.numel()))
+
+    def psnr_all(self):
+        """One read-back for all iterations: PSNR_k = 10 log10(1 / mean sq err) (skimage formula).  Unit batch: one list per unit."""
+        if not self.sse_rows:
+            return [] if self.U == 1 else [[] for _ in range(self.U)]
+        self.flush()
+        if self.U > 1:
+            n = float(self.H) * self.W * self.B
+            res = []
+            for rows in self._unit_rows(self.sse_rows):
+                sse = ops.sum_rows_f64(torch.stack(rows)).cpu().numpy()
+                res.append([float(10 * np.log10(1.0 / (v / n))) for v in sse])
+            return res
         n0 = self.sse_rows[0].numel()
         if all(r.numel() == n0 for r in self.sse_rows):            # one launch for the whole table
             sse = ops.sum_rows_f64(torch.stack(self.sse_rows)).cpu().numpy()
@@ -329,16 +461,20 @@ class AdmmRun:
         return [float(10 * np.log10(1.0 / (s / n))) for s in sse]
 
     def result_mosaic(self):
-        """(H,W,B) CUDA tensor of the reported iterate (theta two-stage, x one-stage; reference :312-315 / :538-541)."""
+        """(H,W,B) CUDA tensor of the reported iterate (theta two-stage, x one-stage; reference :312-315 / :538-541); unit batch:
+        the list of the units' mosaics."""
         self.flush()
-        return ops.state_to_mosaic(self.theta if self.two_stage else self.x)
+        return self._reported_mosaic()
 
     def final_report(self, mosaic_np=None):
         """per-frame PSNR / SSIM of the final reconstruction (reference :316-321 / :542-547), computed on the device"""
         if self.orig is None:
             return [], []
         self.flush()
-        return frame_metrics(self.orig, self.theta if self.two_stage else self.x)
+        st = self.theta if self.two_stage else self.x
+        if self.U > 1:
+            return [frame_metrics(self._unit_state(self.orig, u), self._unit_state(st, u)) for u in range(self.U)]
+        return frame_metrics(self.orig, st)
 
 
 GRAY_DENOISERS = ('tv_gray', 'ffdnet_gray')

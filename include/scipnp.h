@@ -477,6 +477,11 @@ typedef struct {
     /* fp32 path only (NULL: every layer on the F(2x2,3x3) kernel): per-layer F(4x4,3x3) packings, NULL entries for the layers
      * that keep packed_wino[l] (scipnp_ffdnet_forward_c8w4) */
     const float* const* packed_wino4;
+    /* Unit batch (round 4; 0 or 1: one problem): `units` independent problems of ONE shape that share the denoiser weights, stepped
+     * by the same launch sequence -- state, Phi, orig in the unit-batched layout [B][units][4][M][N], y / Phisum
+     * [units][4][M][N], RGB buffers and network buffers for B*units frames (frame f = t*units + u), sse_part with
+     * B*units frames of partials.  Every unit's numbers are bit-identical to its own single-unit call. */
+    int units;
 } scipnp_twostage_ffdnet_args;
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
 
@@ -509,9 +514,28 @@ typedef struct {
      * after scipnp_admm_tv_flush (same argument block; a no-op when nothing is pending).  Same results bit for bit. */
     int* defer_state;
     double* sse_part_prev;              /* sse_part of the PREVIOUS call (written during this one), or NULL */
+    /* Unit batch (round 4; 0 or 1: one problem): `units` independent problems of one shape in the unit-batched layout -- state
+     * [B][units][4][M][N], y / Phisum [units][4][M][N], tv_workspace for 4*B*units channels; the same two or three launches
+     * step all of them.  Bit-identical per unit to its own call. */
+    int units;
 } scipnp_admm_tv_args;
 int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
 int scipnp_admm_tv_flush(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+
+/* Unit batches: U independent problems of one shape stepped by ONE launch sequence (the reference loops its measurements one
+ * after the other, two_stage_ADMM_Online_FFD_Warm.py:241-275; small units -- 256x256 tiles, ADMM-TV cubes -- leave most of
+ * the chip idle that way).  Layout: frame-major with the unit inside, state [B][U][4][M][N], measurements [U][4][M][N]: the
+ * projection is per mosaic pixel, so the U units are simply 4*M*N*U pixels to it; every other kernel of the path is per
+ * frame or per plane and takes B*U frames / 4*B*U planes as it stands.  scipnp_pm_setup_units / scipnp_pm_project_units:
+ * scipnp_pm_setup / scipnp_pm_project on that layout (utilspy.py:28-44, dvp...:128-140 / :389-391 per unit). */
+int scipnp_pm_setup_units(const float* Phi, const float* y, float* Phisum, float* x0, int M, int N, int B, int units,
+                          scipnp_stream_t s);
+int scipnp_pm_project_units(const float* theta, const float* b, const float* Phi, const float* y, const float* Phisum, float* x,
+                            int M, int N, int B, int units, int mode, float c0, float c1, scipnp_stream_t s);
+/* squared-error partials the fused launch of scipnp_admm_tv_iterate's deferred form really writes (one per workgroup, each
+ * inside ONE unit when 4*M*N is a multiple of its pixels per workgroup; the remaining nfill entries are zeros): lets a caller
+ * cut the partials of a unit batch at unit boundaries.  0 for arguments the fused launch does not take. */
+int scipnp_pm_dual_project_blocks(int M, int N, int B, int units, int nfill);
 
 /* dual update of one ADMM iteration and projection of the next in ONE launch (csrc/sci_ops.hip; B <= 32:
  * scipnp_pm_dual_project_fits): theta = clip(theta_raw), b +-= x - theta, then x = project(theta, b) in place -- the
