@@ -135,7 +135,7 @@ def reconstruct_tiled(y, Phi, tile, solve, device, x0=None, orig=None, model=Non
 
 
 # ---------------------------------------------------------------------------------------------- fixed-total timed jobs
-def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=0, group=None, sync=None):
+def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=0, group=None, sync=None, batched=False):
     """A job of a FIXED total of `n_units` independent units (BASELINE configs[3]: 8 cubes; configs[4]: the 16 tiles of a
     1024 x 1024 x 16 cube) over the ranks of `group`, timed the way bench.py's contract asks:
 
@@ -148,14 +148,18 @@ def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=
     `sync()` (torch.cuda.synchronize on a GPU rank, None on CPU) is called where a time is taken.  Returns
     (units, timing): the list of all n_units tensors in unit order on rank dst (None elsewhere) and, on every rank,
     timing = {'total_s': max over ranks of t1 - t0, 'solve_s': [per rank], 'gather_s': [per rank], 'units': [per rank]}
-    -- the per-rank figures travel in one small all_gather AFTER the timed region (metrics, not the data path)."""
+    -- the per-rank figures travel in one small all_gather AFTER the timed region (metrics, not the data path).
+
+    batched=True (round 4, unit batches): the rank's units are stepped TOGETHER -- prepare(list of the rank's units) -> ONE
+    state, iterate(state, k) advances every unit of the rank by one iteration in one launch sequence
+    (solver.AdmmRun(units=...)), finish(state) -> {unit: tensor}.  Same timed region, same single gather."""
     import time
     inited = dist.is_initialized()
     world = dist.get_world_size(group) if inited else 1
     rank = dist.get_rank(group) if inited else 0
     sync = sync or (lambda: None)
     mine = partition(n_units, world, rank)
-    states = {u: prepare(u) for u in mine}
+    states = (prepare(mine) if mine else None) if batched else {u: prepare(u) for u in mine}
 
     def barrier():
         sync()
@@ -165,10 +169,15 @@ def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=
 
     barrier()
     t0 = time.perf_counter()
-    for u in mine:
-        for k in range(steps):
-            iterate(states[u], k)
-    local = {u: finish(states[u]) for u in mine}
+    if batched:
+        for k in range(steps if mine else 0):
+            iterate(states, k)
+        local = finish(states) if mine else {}
+    else:
+        for u in mine:
+            for k in range(steps):
+                iterate(states[u], k)
+        local = {u: finish(states[u]) for u in mine}
     sync()
     t_solve = time.perf_counter() - t0
     got = gather_units(local, n_units, unit_shape, device, dst=dst, group=group)

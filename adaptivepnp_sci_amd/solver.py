@@ -384,7 +384,7 @@ class AdmmRun:
         rows = self._unit_rows(self.sse_rows) if self.sse_rows else [[] for _ in range(U)]
         keep = ('device', 'denoiser', 'two_stage', 'logf', 'H', 'W', 'B', 'M', 'N', 'iqa', 'alpha', 'rou', 'tau', '_lambda', 'gamma',
                 'lr_', 'inital_iter', 'interval_iter', 'update_', 'update_per_iter', 'update_times', 'close_form', 'update_i', 'k',
-                'profile_events', 'phi_events', 'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
+                'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
         runs = []
         for u in range(U):
             r = AdmmRun.__new__(AdmmRun)
@@ -400,6 +400,7 @@ class AdmmRun:
             r.sse_rows = list(rows[u])
             r.out_rgb = None
             r.ovf_word = None
+            r.profile_events = r.phi_events = None    # (bench.py's event lists stay with the batch)
             r._init_workspaces()
             if self.denoiser != 'tv':
                 for name in ('x_rgb', 'w', 'out_store'):

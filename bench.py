@@ -847,6 +847,26 @@ def config_records(ffd_sd, budget_s=60.0):
         'bound': 'hbm (launch/VALU-latency limited at this size)', 'algorithmic_bytes_per_iteration': tv_bytes,
         'achieved_GBs': tv_bytes / (ms * 1e-3) / 1e9, 'frac': tv_bytes / (ms * 1e-3) / PEAK_HBM,
         'parity': {'iterations': 3, 'max_rel_l2_per_iterate': max(rel_l2(its[k], o['x_iterates'][k]) for k in range(3)), 'gate': 1e-5}}
+    # the same solver on a UNIT BATCH of 8 such cubes (seeds 0..7): one launch sequence steps all of them (AdmmRun(units=8))
+    U = 8
+    pr = [synth.make_problem(256, 256, 8, seed=i) for i in range(U)]
+    brun = AdmmRun([q[0] for q in pr], [q[1] for q in pr], 'tv', False, X_orig=[q[2] for q in pr], units=U)
+    ms8 = _ms_per_iter(brun, 0, 50, 5)
+    single = AdmmRun(pr[U - 1][0], pr[U - 1][1], 'tv', False, X_orig=pr[U - 1][2])
+    for _ in range(brun.k):
+        single.step(0)
+    out['admm_tv_256_x8'] = {
+        'workload': 'configs[0] as a unit batch: 8 independent 256x256x8 cubes stepped by ONE launch sequence (2 launches per '
+                    'iteration for all of them), per-iteration PSNR of every unit on device',
+        'dtype': 'f32', 'units': U, 'ms_per_iteration': ms8, 'ms_per_iteration_per_unit': ms8 / U,
+        'unit_iterations_per_s': U * 1e3 / ms8, 'speedup_per_unit_over_single_unit_run': ms / (ms8 / U),
+        'algorithmic_bytes_per_iteration': U * tv_bytes, 'achieved_GBs': U * tv_bytes / (ms8 * 1e-3) / 1e9,
+        'frac': U * tv_bytes / (ms8 * 1e-3) / PEAK_HBM,
+        'parity': {'bit_identical_to_single_unit_run': bool(torch.equal(brun.result_mosaic()[U - 1], single.result_mosaic())),
+                   'iterations': brun.k, 'max_rel_l2_per_iterate': rel_l2(brun.result_mosaic()[0].cpu().numpy(),
+                                                                         OS.one_stage_admm(pr[0][0], pr[0][1], 1, 0.01, 'tv', [brun.k], [0],
+                                                                                           X_orig=pr[0][2])['x_bayer'])
+                   if brun.k <= 60 else None, 'gate': 1e-5}}
 
     # ---- configs[2]: two-stage ADMM + FastDVDnet, 512x512x8 (synthetic weights: model.pth is not in the reference snapshot)
     y, Phi, orig = synth.make_problem(512, 512, 8, seed=1)
@@ -984,8 +1004,10 @@ def fixed_total_mode(args, ctx, net, wdesc):
     """BASELINE configs[3] (`--cubes C`: a fixed total of C independent 512x512x8 cubes, C/N per rank) and configs[4]
     (`--config tile1024`: one 1024x1024x16 colour cube as 16 patches of 256x256, per-tile model copy and online finetune,
     16/N tiles per rank, stitched on rank 0).  One step = one ADMM iteration of EVERY unit of the job; the units of a rank
-    run one after the other, ONE gather (RCCL) ends the timed region; strong scaling.  Rank 0 prints the JSON line with the
-    per-rank solve and gather times."""
+    advance TOGETHER as one unit batch (solver.AdmmRun(units=...): one launch sequence for all of them while they share the
+    denoiser weights -- the tiles until their online finetune fires, then split() into per-tile runs; --no-unit-batch: one
+    after the other, as in round 3 and in the reference's loop); ONE gather (RCCL) ends the timed region; strong scaling.
+    Rank 0 prints the JSON line with the per-rank solve and gather times."""
     import copy
     from adaptivepnp_sci_amd import shard, synth
     from adaptivepnp_sci_amd.solver import AdmmRun
@@ -1000,23 +1022,67 @@ def fixed_total_mode(args, ctx, net, wdesc):
     else:
         n_units, ushape, fkw = args.cubes, (H, W, B), {}
         units = None
-    events, event_unit = [], []                                             # event pairs on the FIRST timed unit of the rank only
+    events = []
+    batch = not args.no_unit_batch
 
-    def prepare(u, throwaway=False):
+    def inputs(u):
         if tiled:
             y_u, Phi_u, _x0, orig_u = units[u]
-        else:
-            y_u, Phi_u, orig_u = synth.make_problem(H, W, B, seed=u)
-        tv = AdmmRun(y_u, Phi_u, 'tv', False)                               # TV warm start, as the reference driver; untimed
-        for _ in range(40):
-            tv.step(0)
+            return y_u, Phi_u, orig_u
+        return synth.make_problem(H, W, B, seed=u)
+
+    def tv_warm(ins):
+        """TV warm starts (40 iterations, as the reference driver; untimed) -- of all the rank's units in ONE unit batch"""
+        if len(ins) > 1 and batch:
+            tv = AdmmRun([i[0] for i in ins], [i[1] for i in ins], 'tv', False, units=len(ins))
+            for _ in range(40):
+                tv.step(0)
+            return tv.result_mosaic()
+        out = []
+        for y_u, Phi_u, _o in ins:
+            tv = AdmmRun(y_u, Phi_u, 'tv', False)
+            for _ in range(40):
+                tv.step(0)
+            out.append(tv.result_mosaic())
+        return out
+
+    def prepare(u, throwaway=False):                                        # one unit, its own run (and --no-unit-batch)
+        y_u, Phi_u, orig_u = inputs(u)
         kw = dict(fkw, interval_iter=2) if throwaway else fkw
-        run = AdmmRun(y_u, Phi_u, 'ffdnet_color', True, x0_bayer=tv.result_mosaic(), X_orig=orig_u,
+        run = AdmmRun(y_u, Phi_u, 'ffdnet_color', True, x0_bayer=tv_warm([(y_u, Phi_u, orig_u)])[0], X_orig=orig_u,
                       model=copy.deepcopy(net) if tiled else net, conv_precision='f32', **kw)
-        if not throwaway and not event_unit:
-            event_unit.append(u)
+        if not throwaway and not events and not getattr(prepare, 'claimed', False):
+            prepare.claimed = True
             run.profile_events = events
         return run
+
+    def prepare_all(mine_):
+        """the rank's units as ONE unit batch (solver.AdmmRun(units=...)): they share the weights -- for the tiles until the
+        online finetune fires (split() into per-tile runs with the model copies made here, untimed)"""
+        ins = [inputs(u) for u in mine_]
+        run = AdmmRun([i[0] for i in ins], [i[1] for i in ins], 'ffdnet_color', True, x0_bayer=tv_warm(ins),
+                      X_orig=[i[2] for i in ins], model=net, conv_precision='f32', units=len(ins), **fkw)
+        run.profile_events = events
+        return {'batch': run, 'parts': None, 'mine': list(mine_), 'models': [copy.deepcopy(net) for _ in ins] if tiled else None}
+
+    def gate(k):                                                            # solver.AdmmRun._cnn_step's finetune gate
+        return bool(fkw) and k > fkw['inital_iter'] and k % fkw['interval_iter'] == 0
+
+    def iterate_all(st, k):
+        sig = driver_sigma(k, args.steps) if tiled else SIGMA
+        if st['parts'] is None and gate(k):                                 # per-tile weights from here on
+            st['parts'] = st['batch'].split(models=st['models'])
+            st['batch'] = None
+        if st['parts'] is None:
+            st['batch'].step(sig)
+        else:
+            for part in st['parts']:
+                part.step(sig)
+
+    def finish_all(st):
+        ms = [part.result_mosaic() for part in st['parts']] if st['parts'] is not None else st['batch'].result_mosaic()
+        ms = ms if isinstance(ms, list) else [ms]
+        return {u: (m if cdev == dev else m.cpu()) for u, m in zip(st['mine'], ms)}
 
     mine = shard.partition(n_units, world, rank)
     if mine:
@@ -1039,7 +1105,11 @@ def fixed_total_mode(args, ctx, net, wdesc):
         m = run.result_mosaic()
         return m if cdev == dev else m.cpu()
 
-    got, timing = shard.timed_job(n_units, prepare, iterate, finish, ushape, cdev, args.steps, sync=torch.cuda.synchronize)
+    if batch:
+        got, timing = shard.timed_job(n_units, prepare_all, iterate_all, finish_all, ushape, cdev, args.steps,
+                                      sync=torch.cuda.synchronize, batched=True)
+    else:
+        got, timing = shard.timed_job(n_units, prepare, iterate, finish, ushape, cdev, args.steps, sync=torch.cuda.synchronize)
     if rank != 0:
         return
     dt = timing['total_s']
@@ -1062,8 +1132,11 @@ def fixed_total_mode(args, ctx, net, wdesc):
                        f'ONE {dist.get_backend()} gather on host copies (SCIPNP_BENCH_BACKEND test hook)'),
         'denoiser_direct_form_TFLOPs': flop_px * px * args.steps / dt / 1e12,
         # the body launch of the unit shape this mode RUNS (256x256x16 tiles / 512x512x8 cubes), its own FLOPs and event time
+        # frames of one body launch: the whole unit batch of the rank while the units share the weights
+        'units_batched_per_launch': (timing['units'][0] if batch else 1),
         'roofline': None if body_s is None else roofline_record('f32', body_s, None, 'not collected in this mode', {},
-                                                                 roofline_form(ctx['f32_form']), shape=ushape),
+                                                                 roofline_form(ctx['f32_form']),
+                                                                 shape=(ushape[0], ushape[1], ushape[2] * (len(mine) if batch else 1))),
         'cpu_baseline': None, 'cpu_baseline_note': 'reported by the default mode (python bench.py), N = 1',
     }
     if tiled:
@@ -1102,6 +1175,8 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU-oracle work per cpu_baseline run')
     ap.add_argument('--cubes', type=int, default=0, help='BASELINE configs[3]: a FIXED total of this many 512x512x8 cubes over '
                                                          'the ranks (strong scaling); 0 = one cube per rank (weak, the default)')
+    ap.add_argument('--no-unit-batch', action='store_true', help='fixed-total modes: step the units of a rank one after the other '
+                                                                  '(round 3 behaviour) instead of as one unit batch')
     ap.add_argument('--config', choices=['headline', 'tile1024'], default='headline',
                     help='tile1024 = BASELINE configs[4]: 1024x1024x16 cube as 16 tiles of 256x256 with the online finetune')
     args = ap.parse_args()

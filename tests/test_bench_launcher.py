@@ -121,7 +121,8 @@ def test_bench_fixed_total_modes_two_ranks_sharing_the_gpu(mode):
     assert 0 < line['roofline']['frac'] <= 1 and len(out[0]) <= 4096
     # the roofline describes the launch this mode RUNS: 256x256x16 tiles / 512x512x8 cubes, their own FLOPs
     shape = [256, 256, 16] if 'tile1024' in mode else [512, 512, 8]
-    assert line['roofline']['launch_shape'] == shape
+    shape[2] *= n_units // 2                                     # one launch covers the rank's whole unit batch
+    assert line['roofline']['launch_shape'] == shape and line['units_batched_per_launch'] == n_units // 2
     assert abs(line['roofline']['flop_per_launch'] / (2 * 9 * 96 * 96 * (shape[0] // 2) * (shape[1] // 2) * shape[2] / 4) - 1) < 1e-3
     assert line['roofline']['traffic'] is None
     if 'tile1024' in mode:

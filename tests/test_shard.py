@@ -123,7 +123,7 @@ def test_tile_grid_and_stitch_round_trip():
         shard.tile_grid(9, 9, 3)
 
 
-def _job_worker(rank, world, port, n_units, tiled, ret):
+def _job_worker(rank, world, port, n_units, tiled, ret, batched=False):
     sys.path.insert(0, ROOT)
     from adaptivepnp_sci_amd import shard
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -147,7 +147,24 @@ def _job_worker(rank, world, port, n_units, tiled, ret):
             st['x'] += 1.0
             st['k'] += 1
 
-        got, timing = shard.timed_job(n_units, prepare, iterate, lambda st: st['x'], shape, torch.device('cpu'), steps=5)
+        if batched:
+            # unit batches: the rank's units advance TOGETHER, one iterate call per step (bench.py --cubes / tile1024 on
+            # solver.AdmmRun(units=...)); same timed region, same single gather
+            calls = []
+
+            def prepare_all(mine):
+                return {u: prepare(u) for u in mine}
+
+            def iterate_all(sts, k):
+                calls.append(k)
+                for st in sts.values():
+                    iterate(st, k)
+
+            got, timing = shard.timed_job(n_units, prepare_all, iterate_all, lambda sts: {u: st['x'] for u, st in sts.items()},
+                                          shape, torch.device('cpu'), steps=5, batched=True)
+            assert calls == ([0, 1, 2, 3, 4] if shard.partition(n_units, world, rank) else [])
+        else:
+            got, timing = shard.timed_job(n_units, prepare, iterate, lambda st: st['x'], shape, torch.device('cpu'), steps=5)
         assert prepared == shard.partition(n_units, world, rank)
         assert timing['units'] == [len(shard.partition(n_units, world, r)) for r in range(world)]
         assert len(timing['solve_s']) == world and len(timing['gather_s']) == world
@@ -167,15 +184,16 @@ def _job_worker(rank, world, port, n_units, tiled, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_units,tiled', [(8, False), (16, True), (3, False)])
-def test_fixed_total_timed_job_gloo(n_units, tiled):
+@pytest.mark.parametrize('batched', [False, True])
+@pytest.mark.parametrize('n_units,tiled', [(8, False), (16, True), (3, False), (1, False)])
+def test_fixed_total_timed_job_gloo(n_units, tiled, batched):
     """bench.py --cubes 8 / --config tile1024 plumbing (BASELINE configs[3] / [4]): a fixed total of units over 2 ranks,
     K steps per unit, ONE gather, per-rank solve / gather times collected after the timed region"""
     world = 2
     ctx = mp.get_context('spawn')
     ret = ctx.Queue()
-    port = 33500 + (os.getpid() + n_units) % 2000
-    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_units, tiled, ret)) for r in range(world)]
+    port = 33500 + (os.getpid() + n_units + 7 * int(batched)) % 2000
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_units, tiled, ret, batched)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
