@@ -373,41 +373,58 @@ class AdmmRun:
         self.sse_rows.append(t)
         return t
 
-    def split(self, models=None):
-        """The units of a batch as U independent single-unit runs that continue exactly where the batch stands (iteration count,
-        state, duals, RGB buffers, per-iteration squared-error history): for the part of a schedule that needs per-unit
-        weights -- from the first online-finetune event on, models[u] (its own copy of the denoiser) is unit u's model."""
+    _SPLIT_KEEP = ('device', 'denoiser', 'two_stage', 'logf', 'H', 'W', 'B', 'M', 'N', 'iqa', 'alpha', 'rou', 'tau', '_lambda', 'gamma',
+                   'lr_', 'inital_iter', 'interval_iter', 'update_', 'update_per_iter', 'update_times', 'close_form',
+                   'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
+
+    def prepare_split(self, models=None):
+        """Build the U single-unit runs split() hands out -- their state buffers, RGB buffers, TV plans / network engines
+        (packed from models[u], unit u's own copy of the denoiser; None: the batch's shared model) -- WITHOUT touching the
+        batch: allocation and weight packing happen here, split() then only copies the state across.  Optional: split()
+        prepares on its own when this was not called."""
         if self.U == 1:
-            return [self]
-        self.flush()
-        U, B, H, W = self.U, self.B, self.H, self.W
-        rows = self._unit_rows(self.sse_rows) if self.sse_rows else [[] for _ in range(U)]
-        keep = ('device', 'denoiser', 'two_stage', 'logf', 'H', 'W', 'B', 'M', 'N', 'iqa', 'alpha', 'rou', 'tau', '_lambda', 'gamma',
-                'lr_', 'inital_iter', 'interval_iter', 'update_', 'update_per_iter', 'update_times', 'close_form', 'update_i', 'k',
-                'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
-        runs = []
+            return
+        U, B, M, N = self.U, self.B, self.M, self.N
+        self._split_runs = []
         for u in range(U):
             r = AdmmRun.__new__(AdmmRun)
-            for name in keep:
+            for name in self._SPLIT_KEEP:
                 if name in self.__dict__:
                     setattr(r, name, self.__dict__[name])
             r.U, r.BU = 1, B
             r.model = self.model if models is None else models[u]
-            r.Phi, r.theta, r.x, r.b = (self._unit_state(t, u) for t in (self.Phi, self.theta, self.x, self.b))
-            r.orig = None if self.orig is None else self._unit_state(self.orig, u)
-            r.orig_np = None
+            r.Phi, r.orig = self._unit_state(self.Phi, u), (None if self.orig is None else self._unit_state(self.orig, u))
             r.y, r.Phisum = self.y[4 * u:4 * u + 4].contiguous(), self.Phisum[4 * u:4 * u + 4].contiguous()
-            r.sse_rows = list(rows[u])
-            r.out_rgb = None
-            r.ovf_word = None
+            r.theta, r.x, r.b = (torch.empty(B, 4, M, N, dtype=F32, device=self.device) for _ in range(3))
+            r.orig_np = None
+            r.sse_rows, r.out_rgb, r.ovf_word, r.update_i, r.k = [], None, None, 0, 0
             r.profile_events = r.phi_events = None    # (bench.py's event lists stay with the batch)
             r._init_workspaces()
+            self._split_runs.append(r)
+
+    def split(self, models=None):
+        """The units of a batch as U independent single-unit runs that continue exactly where the batch stands (iteration count,
+        state, duals, RGB buffers, per-iteration squared-error history): for the part of a schedule that needs per-unit
+        weights -- from the first online-finetune event on, models[u] (its own copy of the denoiser) is unit u's model.
+        The batch must not be stepped afterwards."""
+        if self.U == 1:
+            return [self]
+        self.flush()
+        if getattr(self, '_split_runs', None) is None:
+            self.prepare_split(models)
+        U, B, H, W = self.U, self.B, self.H, self.W
+        rows = self._unit_rows(self.sse_rows) if self.sse_rows else [[] for _ in range(U)]
+        runs, self._split_runs = self._split_runs, None
+        for u, r in enumerate(runs):
+            r.k, r.update_i = self.k, self.update_i
+            for name in ('theta', 'x', 'b'):
+                getattr(r, name).copy_(getattr(self, name).view(B, U, 4, self.M, self.N)[:, u])
+            r.sse_rows = list(rows[u])
             if self.denoiser != 'tv':
                 for name in ('x_rgb', 'w', 'out_store'):
                     src = getattr(self, name)
                     if src is not None:
                         getattr(r, name).copy_(src.view(B, U, 3, H, W)[:, u])
-            runs.append(r)
         return runs
 
     def _unit_state(self, t, u):
@@ -450,7 +467,11 @@ class AdmmRun:
             n = float(self.H) * self.W * self.B
             res = []
             for rows in self._unit_rows(self.sse_rows):
-                sse = ops.sum_rows_f64(torch.stack(rows)).cpu().numpy()
+                n0 = rows[0].numel()
+                if all(r.numel() == n0 for r in rows):
+                    sse = ops.sum_rows_f64(torch.stack(rows)).cpu().numpy()
+                else:                                     # (fused-launch rows and stand-alone dual-update rows differ in length)
+                    sse = torch.cat([ops.sum_rows_f64(r) for r in rows]).cpu().numpy()
                 res.append([float(10 * np.log10(1.0 / (v / n))) for v in sse])
             return res
         n0 = self.sse_rows[0].numel()
@@ -494,6 +515,7 @@ class GrayAdmmRun:
     is the state plus the sigma map; with TV the state is the frames themselves, [B][H][W]."""
 
     two_stage = False
+    U = 1                  # (no unit batches in the grayscale mode)
     update_ = False
     update_i = 0
     update_times = -1

@@ -1063,7 +1063,10 @@ def fixed_total_mode(args, ctx, net, wdesc):
         run = AdmmRun([i[0] for i in ins], [i[1] for i in ins], 'ffdnet_color', True, x0_bayer=tv_warm(ins),
                       X_orig=[i[2] for i in ins], model=net, conv_precision='f32', units=len(ins), **fkw)
         run.profile_events = events
-        return {'batch': run, 'parts': None, 'mine': list(mine_), 'models': [copy.deepcopy(net) for _ in ins] if tiled else None}
+        models = [copy.deepcopy(net) for _ in ins] if tiled else None
+        if tiled:
+            run.prepare_split(models)                # per-tile buffers and engines exist before the timed region (as the
+        return {'batch': run, 'parts': None, 'mine': list(mine_), 'models': models}          # per-unit prepare() builds them)
 
     def gate(k):                                                            # solver.AdmmRun._cnn_step's finetune gate
         return bool(fkw) and k > fkw['inital_iter'] and k % fkw['interval_iter'] == 0
