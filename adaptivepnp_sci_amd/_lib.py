@@ -103,6 +103,7 @@ SIGNATURES = {
                                         _vp, _sz]),
     'scipnp_twostage_ffdnet_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_admm_tv_iterate': (_int, [_vp, C.POINTER(_int), _vp]),
+    'scipnp_admm_tv_plane_path': (_int, [_vp]),
     'scipnp_admm_tv_flush': (_int, [_vp, C.POINTER(_int), _vp]),
     'scipnp_pm_dual_project_fits': (_int, [_int, _int, _int]),
     'scipnp_pm_dual_project': (_int, [_vp] * 9 + [_int, _int, _int, _int, _int, _flt, _flt, _vp]),

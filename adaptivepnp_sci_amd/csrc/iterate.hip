@@ -3,10 +3,62 @@
 //   two-stage + FFDNet-colour (Malvar demosaic):  dvp_linear_inv_2_stage_ADMM_tensor_online.py:121-271, one pass
 //   ADMM-TV, either solver:                       :121-160 + :265-271  /  :385-407 + :500-509
 #include "common.hpp"
+#include <cstdlib>
 
 using namespace scipnp;
 
+static int device_cu_count() {
+    static const int n = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+        return cu > 0 ? cu : 256;
+    }();
+    return n;
+}
+
+// which launches an ADMM-TV call on this argument block takes
+struct TvPath {
+    bool banded;    // the banded TV kernel (many workgroups per plane) + a dual update
+    bool plane;     // ONE whole-plane kernel for all TV iterations, the stop test and the dual update (planes up to 128 x 128)
+    bool defer;     // banded, in its candidate form, the dual update fused into the next call's projection
+    int nstd;       // squared-error partials of the stand-alone dual update's grid (the size of sse_part)
+};
+
+static TvPath tv_path(const scipnp_admm_tv_args* a) {
+    const int M = a->M, N = a->N, B = a->B, U = a->units > 1 ? a->units : 1, BU = B * U;
+    TvPath p = {};
+    scipnp_sse_partials(a->x, a->x, (size_t)4 * M * N * BU, nullptr, &p.nstd, nullptr);   // size query: pm_dual_update's grid
+    const bool want_sse = a->sse_part && a->orig;
+    // planes up to 256 columns take the banded TV kernel (many workgroups per plane, one launch) followed by the dual update;
+    // narrower problems that leave the chip idle either way keep the one-launch whole-plane form with the dual update in its epilogue
+    bool banded = tv_band_fits(M, N, a->tv_iters) && (long long)4 * BU * ((M + 31) / 32) >= 128;
+    // unit batches of small planes: ONE workgroup per plane (all TV iterations in registers, the stop test and the dual update in
+    // the same launch, no candidates written) fills the chip once there is a plane per CU -- 256 planes of 128 x 128 take 1 x
+    // the whole-plane kernel's time where the banded form + fused projection pay per plane (tools/probes/tv_units_probe.py)
+    if (banded && U > 1 && tv_plane_dual_fits(M, N, 4 * BU, p.nstd, want_sse)) {
+        static const int force = [] { const char* e = getenv("SCIPNP_TV_PLANE_BATCH"); return e ? atoi(e) : -1; }();
+        const int cus = device_cu_count();
+        const long long planes = 4LL * BU, gens = (planes + cus - 1) / cus;
+        const bool fills = planes * 4 >= gens * cus * 3;                    // the last generation leaves at most a quarter idle
+        if (force == 1 || (force != 0 && fills)) banded = false;
+    }
+    p.banded = banded;
+    p.plane = !banded && tv_plane_dual_fits(M, N, 4 * BU, p.nstd, want_sse);
+    // deferred form: TV in its one-launch candidate form (no second launch, nothing recomputed; theta_raw is not written), the
+    // dual update -- which then also picks every channel's candidate -- fused into the next call's projection
+    // (unit batches: the fused launch keeps the stop iterations of at most 4 planes per workgroup -- planes of >= 1024 pixels)
+    p.defer = banded && a->defer_state && scipnp_pm_dual_project_fits(M, N, B) && tv_candidates_fit(M, N, a->tv_iters) &&
+              (U == 1 || (long long)M * N >= 1024);
+    return p;
+}
+
 extern "C" {
+
+/* 1 if scipnp_admm_tv_iterate on this block runs the whole-plane kernel (its squared-error partials: one per plane, then zeros) */
+int scipnp_admm_tv_plane_path(const scipnp_admm_tv_args* a) {
+    if (!a || a->struct_size != sizeof(scipnp_admm_tv_args)) return 0;
+    return tv_path(a).plane ? 1 : 0;
+}
 
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s) {
     SCIPNP_REQUIRE(a, "null argument block");
@@ -55,15 +107,9 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
     int rc;
     // planes up to 256 columns take the banded TV kernel (many workgroups per plane, one launch) followed by the dual update;
     // narrower problems that leave the chip idle either way keep the one-launch whole-plane form with the dual update in its epilogue
-    int nstd = 0;
-    scipnp_sse_partials(a->x, a->x, (size_t)4 * M * N * BU, nullptr, &nstd, s);          // size query: pm_dual_update's grid
-    const bool want_sse = a->sse_part && a->orig;
-    const bool banded = tv_band_fits(M, N, a->tv_iters) && (long long)4 * BU * ((M + 31) / 32) >= 128;
-    // deferred form: TV in its one-launch candidate form (no second launch, nothing recomputed; theta_raw is not written), the
-    // dual update -- which then also picks every channel's candidate -- fused into the next call's projection
-    // (unit batches: the fused launch keeps the stop iterations of at most 4 planes per workgroup -- planes of >= 1024 pixels)
-    const bool defer = banded && a->defer_state && scipnp_pm_dual_project_fits(M, N, B) && tv_candidates_fit(M, N, a->tv_iters) &&
-                       (U == 1 || (long long)M * N >= 1024);
+    const TvPath path = tv_path(a);
+    const int nstd = path.nstd;
+    const bool want_sse = a->sse_part && a->orig, defer = path.defer;
     TvCandidates cd = {};
     if (defer) tv_candidate_ptrs(M, N, 4 * BU, a->tv_iters, a->tv_workspace, &cd);
     float coef, sign, pc0, pc1;
@@ -84,7 +130,7 @@ int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_st
         rc = scipnp_pm_project_units(a->theta, a->b, a->Phi, a->y, a->Phisum, a->x, M, N, B, U, mode, pc0, pc1, s);
     if (rc) return rc;
     if (a->defer_state) *a->defer_state = 0;
-    if (!banded && tv_plane_dual_fits(M, N, 4 * BU, nstd, want_sse)) {
+    if (path.plane) {
         if (nblocks) *nblocks = nstd;
         return tv_plane_dual(a->x, a->b, coef, a->theta, M, N, 4 * BU, a->tv_weight, 2e-4f, a->tv_iters, a->orig,
                              want_sse ? a->sse_part : nullptr, a->two_stage ? 0 : 1, sign, nstd, (hipStream_t)s);

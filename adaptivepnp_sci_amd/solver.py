@@ -244,7 +244,7 @@ class AdmmRun:
             if part is not None and self.U > 1:          # which launch wrote which row (their partial layouts differ, _unit_rows)
                 if pending and len(self._row_kinds) >= 1:
                     self._row_kinds[-1] = 'fused'         # the previous iteration's row: by this call's fused launch
-                self._row_kinds.append(None if self._tv_defer.value else 'flat')
+                self._row_kinds.append(None if self._tv_defer.value else self._tv_row_kind())
             if ITERATE_HOOK is not None:
                 self.flush()
                 ITERATE_HOOK(k, self._reported_mosaic())
@@ -445,7 +445,9 @@ class AdmmRun:
         out = [[] for _ in range(U)]
         for i, r in enumerate(rows):
             n = r.numel()
-            if self.denoiser != 'tv' or self._row_kinds[i] == 'flat':
+            if self.denoiser == 'tv' and self._row_kinds[i] == 'plane':     # whole-plane kernel: one partial per plane, then zeros
+                v = r[:4 * B * U].view(B, U, 4).permute(1, 0, 2).reshape(U, -1)
+            elif self.denoiser != 'tv' or self._row_kinds[i] == 'flat':
                 v = r.view(B, U, n // (B * U)).permute(1, 0, 2).reshape(U, -1)
             else:                                         # fused launch: one partial per workgroup over the pixel axis, then zeros
                 g = self._tv_fused_blocks()
@@ -453,6 +455,11 @@ class AdmmRun:
             for u in range(U):
                 out[u].append(v[u].contiguous())
         return out
+
+    def _tv_row_kind(self):
+        """which kernel writes the squared-error row of a NON-deferred ADMM-TV call on this state (csrc/iterate.hip): the
+        whole-plane kernel ('plane': one partial per plane) or the stand-alone dual update ('flat')"""
+        return 'plane' if _lib.load().scipnp_admm_tv_plane_path(C.byref(self._tv_args)) else 'flat'
 
     def _tv_fused_blocks(self):
         """workgroups (= real squared-error partials) of the fused dual-update + projection launch on this state"""

@@ -521,6 +521,10 @@ typedef struct {
 } scipnp_admm_tv_args;
 int scipnp_admm_tv_iterate(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
 int scipnp_admm_tv_flush(const scipnp_admm_tv_args* a, int* nblocks, scipnp_stream_t s);
+/* 1 if scipnp_admm_tv_iterate on this block runs the whole-plane TV kernel with the dual update in its epilogue (its
+ * squared-error partials: one per plane -- plane (t*units + u)*4 + ib -- then zeros up to the dual update's grid size);
+ * 0: the banded kernel (partials as scipnp_pm_dual_update / the fused launch write them).  Host-only query. */
+int scipnp_admm_tv_plane_path(const scipnp_admm_tv_args* a);
 
 /* Unit batches: U independent problems of one shape stepped by ONE launch sequence (the reference loops its measurements one
  * after the other, two_stage_ADMM_Online_FFD_Warm.py:241-275; small units -- 256x256 tiles, ADMM-TV cubes -- leave most of
