@@ -71,6 +71,7 @@ struct Wino4Args {
     int CGin, CGout, NCB;    // NCB = CoutP / 32
     int H, W;
     int ntx, nty;
+    unsigned m_ncb, m_ntx, m_nty;   // floor(2^32 / d) of the three divisors of the block index (w4_div below), set by w4_geometry
     int flags;
     unsigned long long* dbg; // STAMP instantiation (DIAG bit6) only: 128 words per workgroup, see scipnp_conv3x3_c8w4_stamped
 };
@@ -191,6 +192,22 @@ __host__ __device__ __forceinline__ void half_op(const f32x2 i0, const f32x2 i1,
     }
 }
 
+// x / d and x % d by a host-made reciprocal m = floor(2^32 / d) (0xFFFFFFFF for d = 1): q = mulhi(x, m) is the quotient or one
+// short of it, one correction makes it exact for every 32-bit x -- six scalar instructions where the compiler's division by a
+// run-time value takes some thirty-five (three of them open every workgroup's life)
+__host__ __device__ __forceinline__ unsigned w4_div(unsigned x, unsigned d, unsigned m, unsigned& rem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned q = __umulhi(x, m);
+#else
+    unsigned q = (unsigned)(((unsigned long long)x * m) >> 32);
+#endif
+    unsigned r = x - q * d;
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+static inline unsigned w4_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)d); }
+
 // DIAG (timing experiments only, wrong results): bit0 no transform, 1 no raw staging, 2 no U DMA, 3 no barriers, 4 no MFMAs, 5 no epilogue
 template <int TAG, int DIAG = 0, bool SHUF = false>
 __global__ void __launch_bounds__(W4_THREADS, 2)
@@ -217,11 +234,30 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         const unsigned total = gridDim.x;
         if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
     }
-    const int split = lin % a.NCB;
-    unsigned t = lin / a.NCB;
-    const int bx = t % a.ntx;
-    t /= a.ntx;
-    const int by = t % a.nty, n = t / a.nty;
+    unsigned r_split, r_bx, r_by;
+    unsigned t = w4_div(lin, (unsigned)a.NCB, a.m_ncb, r_split);
+    const int split = (int)r_split;
+    const float* w_g = a.wpk + (size_t)split * W4_SLAB;                         // advanced by NCB*SLAB per k-step
+    const size_t w_step = (size_t)a.NCB * W4_SLAB;
+    // the U slab of k-step 0 is requested HERE, before anything else is known about the block: its addresses need only the
+    // output-channel split, and its latency then runs under the address arithmetic of the raw tile below
+    if (!(DIAG & 4)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto r_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, W4_SLAB * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < W4_DMA_ITERS; ++k) {
+            int pc = wvu + 4 * k;
+            if (pc >= W4_PIECES) pc -= 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w0, (__attribute__((address_space(3))) void*)((char*)u_lds + 1024 * pc), 16,
+                                                     (unsigned)(1024 * pc + 16 * lane), 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    w_g += w_step;
+    t = w4_div(t, (unsigned)a.ntx, a.m_ntx, r_bx);
+    const int n = (int)w4_div(t, (unsigned)a.nty, a.m_nty, r_by);
+    const int bx = (int)r_bx, by = (int)r_by;
     const int x0 = bx * W4_TW, y0 = by * W4_TH;
 
     // ---- staging plan of the raw tile: LDS unit u = 64 * piece + lane = (hf * THP + r) * TWP + slot -> pixel (r, c) of the halo
@@ -235,14 +271,18 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         const int u = pc * 64 + lane;
         const int hf = u >= W4_UNITS / 2 ? 1 : 0;
         const int v = u - hf * (W4_UNITS / 2);
-        const int r = v / W4_RSL, sl = v - r * W4_RSL;
-        const int c = 16 * (sl / 17) + sl % 17;                                 // (sl % 17 == 16: a padding slot)
+        // v / 70 and sl / 17 as multiply-shifts (exact for v < 1259, sl < 70: W4_RSL = 70 slots per row, 17 per 16 pixels)
+        static_assert(W4_RSL == 70 && W4_UNITS / 2 < 1259, "the reciprocal 937 / 2^16 is exact for v < 1259 only");
+        const int r = (int)(((unsigned)v * 937u) >> 16), sl = v - r * W4_RSL;
+        const int g17 = (int)(((unsigned)sl * 241u) >> 12);                      // sl / 17
+        const int c = sl - g17;                                                  // 16 (sl / 17) + sl % 17; sl % 17 == 16: a padding slot
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        in_off[k] = (u < W4_UNITS && sl % 17 != 16 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * 32 + 16 * hf) : 0xFFFFFF00u;
+        // (bitwise, not short-circuit: a guarded offset compiles to an exec-masked branch per piece)
+        const bool ok = (u < W4_UNITS) & (sl - 17 * g17 != 16) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        const unsigned off = (unsigned)((gy * W + gx) * 32 + 16 * hf);
+        in_off[k] = ok ? off : 0xFFFFFF00u;
     }
     const float* in_g = a.in + (size_t)n * a.CGin * HW * 8;                     // advanced by HW*8 per group
-    const float* w_g = a.wpk + (size_t)split * W4_SLAB;                         // advanced by NCB*SLAB per k-step
-    const size_t w_step = (size_t)a.NCB * W4_SLAB;
     const unsigned plane_bytes = (unsigned)(HW * 32);
     (void)w_g; (void)plane_bytes; (void)in_g; (void)wvu;
 
@@ -278,11 +318,6 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
 #pragma unroll
         for (int k = 0; k < W4_IN_ITERS; ++k) issue_raw_piece(dst, k);
         raw_done(last);
-    };
-    auto issue_u = [&](float* dst, bool last) {
-#pragma unroll
-        for (int k = 0; k < W4_DMA_ITERS; ++k) issue_u_piece(dst, k);
-        u_done(last);
     };
 
     f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]; zeroed behind the first requests
@@ -373,9 +408,10 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             else half_op<false, k - 6>(T[r][1], T[r][2], T[r][3], T[r][4], T[r][5], V[r][3], V[r][4], V[r][5], ta, tb, m5);
         };
 
-        {   // prologue: raw tiles of groups 0 and 1, U of k-step 0; column pass of group 0
+        {   // prologue: U of k-step 0, raw tiles of groups 0 and 1; column pass of group 0.  (U first: its addresses need only the
+            // block's output-channel split, so its latency starts before the staging offsets of the raw tile are formed; the wait
+            // below -- all but the W4_IN_ITERS youngest requests -- covers U and the first raw tile in this order too)
             issue_raw(raw_lds, CG <= 1);
-            issue_u(u_lds, false);
             issue_raw(raw_lds + W4_RAW, CG <= 2);
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
@@ -739,6 +775,7 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
     a.H = h; a.W = w;
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
+    a.m_ncb = w4_magic(a.NCB); a.m_ntx = w4_magic(a.ntx); a.m_nty = w4_magic(a.nty);
     a.flags = flags;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
@@ -797,6 +834,7 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
     a.H = h; a.W = w;
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
+    a.m_ncb = w4_magic(a.NCB); a.m_ntx = w4_magic(a.ntx); a.m_nty = w4_magic(a.nty);
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
@@ -832,6 +870,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
     a.CGin = Cin / 8; a.CGout = Cout / 8; a.NCB = round_up_w4(Cout, 32) / 32;
     a.H = h; a.W = w;
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
+    a.m_ncb = w4_magic(a.NCB); a.m_ntx = w4_magic(a.ntx); a.m_nty = w4_magic(a.nty);
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");

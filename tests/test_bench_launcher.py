@@ -101,6 +101,27 @@ def test_bench_spawns_two_ranks_sharing_the_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: one rank per device on the real RCCL backend')
+def test_bench_two_ranks_on_two_gpus_over_rccl():
+    """the path the driver's N = 2, 4, 8 scaling runs take, whenever the box has the devices: `bench.py --gpus 2` starts two
+    ranks, each binds ITS device before any allocation (LOCAL_RANK -> torch.cuda.set_device), the process group is `nccl`
+    (= RCCL) with world size 2, every rank solves its own cube and ONE RCCL gather brings the mosaics to rank 0; the line
+    names the devices the ranks sat on"""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--preheat', '5'],
+                       env=_env(NCCL_DEBUG='VERSION'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and len(out[0]) <= 4096, out
+    line = json.loads(out[0])
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['world_size'] == 2 and 'nccl' in line['backend']
+    assert 'RCCL' in line['collective'] and line['units_gathered_on_rank0'] == 2 and line['scaling'] == 'weak'
+    devs = line['ranks_devices']
+    assert [d[0] for d in devs] == [0, 1] and [d[1] for d in devs] == [0, 1] and devs[0][2] != devs[1][2]     # two PCI devices
+    assert line['value'] > 0 and line['cpu_baseline'] is None
+    assert 'RCCL' in r.stderr or 'NCCL' in r.stderr                              # the library's own version banner
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('mode', [['--cubes', '4'], ['--config', 'tile1024']])
 def test_bench_fixed_total_modes_two_ranks_sharing_the_gpu(mode):
     """BASELINE configs[3] / configs[4] as bench modes: a FIXED total of units (4 cubes here; the 16 tiles of the 1024x1024x16
