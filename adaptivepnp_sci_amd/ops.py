@@ -178,7 +178,8 @@ class TvPlan:
         self.M, self.N, self.C, self.n_iter_max = M, N, C_, n_iter_max
         nbytes = _lib.load().scipnp_tv_workspace_bytes(M, N, C_, n_iter_max)
         self.nbytes = nbytes
-        # zero once: the one-launch banded kernel counts finished bands per channel here (include/scipnp.h)
+        # (no kernel needs an initial value any more -- the banded kernels keep per-band partial sums, no counters or atomics, and
+        # write every word they later read -- but a zeroed workspace keeps debug reads of unused slots deterministic)
         self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         off = (-self.ws.data_ptr()) % 256
         self.ptr = self.ws.data_ptr() + off

@@ -217,9 +217,10 @@ def test_tv_banded_kernel_equals_the_tiled_kernel(ops, shape, n_iter):
     o0 = torch.full_like(x, -3.0)
     ops.tv_chambolle(x, b, -1.0, o0, plan2, 0.1, kernel=0)      # the library's own choice
     assert torch.equal(o0, o1)
-    # kernel 4 = the CANDIDATE form (one launch stores every iteration's `out`, the last band of a channel does the stop test,
-    # nothing is recomputed; here followed by the selection launch); the per-channel band counters of the workspace are back
-    # at zero after every call, so a plan is reusable at once -- the same plan runs both banded forms, twice
+    # kernel 4 = the CANDIDATE form (one launch stores every iteration's `out` and the bands' partial sums -- no counters, no
+    # atomics, no communication between bands -- nothing is recomputed; here followed by the stop-test / selection launches); a
+    # call leaves nothing behind in the workspace that the next one reads, so a plan is reusable at once -- the same plan runs
+    # both banded forms, twice
     if n_iter >= 2:
         for kernel in (4, 3, 4, 4):
             o4 = torch.full_like(x, -9.0)
