@@ -724,7 +724,7 @@ def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
     torch.cuda.synchronize()
     lb = 16.0 * Hl * Hl * Bl + 8.0 * Hl * Hl
     ls = e0.elapsed_time(e1) / 20 * 1e-3
-    phi_large = {'cube': [Hl, Hl, Bl], 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'achieved': lb / ls / 1e9,
+    phi_large = {'cube': [Hl, Hl, Bl], 'kernel': 'pm_project_kernel<4,8,0>', 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'achieved': lb / ls / 1e9,
                  'unit': 'GB/s', 'frac': lb / ls / PEAK_HBM}
     del th, bb, ph, yy, ps, xo
     # and on the bench's own 512 x 512 x 8 state, 50 launches between one event pair (no per-launch event overhead)
@@ -766,7 +766,9 @@ def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
                  'frac': chain_bytes / chain_s / PEAK_HBM,
                  'frac_of_measured_hbm_read_peak': (chain_bytes / chain_s / 1e9 / measured['hbm_read_GBs']) if measured.get('hbm_read_GBs') else None}
     del st, part
-    return {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
+    # (the 512x512x8 state is 65536 four-pixel chunks: below the kernel's 4-pixels-per-thread threshold, so it runs one pixel per
+    # thread, <VEC=1,MAXB=8,MODE=0>; the 2048x2048x8 state of `large_state` runs <4,8,0> -- the names rocprofv3 shows)
+    return {'bound': 'hbm', 'kernel': 'pm_project_kernel<1,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
             'non_denoiser_chain': chain_rec,
             # primary figure: 50 launches back to back between one event pair (per-launch event overhead excluded; agrees
             # with the rocprofv3 kernel time in profiles/); `in_step` = the event pair around the single launch inside the timed steps

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+T=${1:-r04h}
+for v in "" build/variants/libscipnp_vblk4.so build/variants/libscipnp_vblk12.so ""; do
+  echo "== SCIPNP_LIB=$v"
+  SCIPNP_LIB=${v:+$GRAFT_REPO_ROOT/$v} timeout -k 10 200 python tools/wino_bench.py 2>&1 | grep "F(4x4)" | cut -c1-200
+done | tee gpurun_out/${T}_vblk_ab.txt
+echo done
