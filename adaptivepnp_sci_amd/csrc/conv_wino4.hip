@@ -72,6 +72,7 @@ struct Wino4Args {
     int H, W;
     int ntx, nty;
     unsigned m_ncb, m_ntx, m_nty;   // floor(2^32 / d) of the three divisors of the block index (w4_div below), set by w4_geometry
+    unsigned total_units;           // (tile, output-channel block) units of the launch; the grid of the classic form, walked by the persistent one
     int flags;
     unsigned long long* dbg; // STAMP instantiation (DIAG bit6) only: 128 words per workgroup, see scipnp_conv3x3_c8w4_stamped
 };
@@ -209,9 +210,20 @@ __host__ __device__ __forceinline__ unsigned w4_div(unsigned x, unsigned d, unsi
 static inline unsigned w4_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)d); }
 
 // DIAG (timing experiments only, wrong results): bit0 no transform, 1 no raw staging, 2 no U DMA, 3 no barriers, 4 no MFMAs, 5 no epilogue
-template <int TAG, int DIAG = 0, bool SHUF = false>
+// PERSIST (round 4 experiment, NOT instantiated by the library): a grid of two workgroups per CU, each walking the units
+// blockIdx.x, blockIdx.x + gridDim.x, ...: the next unit's first U slab and raw tiles are requested from inside the current
+// unit's epilogue -- after the partial tiles have been exchanged through LDS, before the stores -- so their latency would run
+// under the store phase instead of opening the next unit's life.  Correct (the F(4x4) tests pass on it), and slower: 330 us
+// against 253 us on the FFDNet body layer, with or without a start stagger of half the grid (profiles/r04k_persist_stagger.txt).
+// The unit loop keeps ~15 more values alive than the 256-register budget of two waves per SIMD holds next to the 144
+// accumulators: 92 spilled registers, scratch accesses that share the vmcnt queue with the LDS-DMA requests (the compiler's
+// own vmcnt(0) in front of a spill at the head of the K loop waits for every request in flight), and the two workgroups of a CU
+// run in phase.  Same wall as round 3's persistent form; the classic form (one unit per workgroup: the loop below runs once) is
+// the product.
+template <int TAG, int DIAG = 0, bool SHUF = false, bool PERSIST = false>
 __global__ void __launch_bounds__(W4_THREADS, 2)
 conv3x3_c8w4_kernel(const Wino4Args a) {
+    static_assert(!(PERSIST && SHUF), "the PixelShuffle epilogue assembles its tile in LDS: no requests may be in flight there");
 
     extern __shared__ __attribute__((aligned(16))) float smem_w4[];
     float* const raw_lds = smem_w4;                    // [2][RAW]
@@ -227,62 +239,12 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
 
-    // XCD-aware order (as conv_wino.hip): one XCD works through a contiguous run of (tile, co-block) pairs, the co-blocks of
-    // a tile adjacent, so the input tile is fetched from HBM once
-    unsigned lin = blockIdx.x;
-    {
-        const unsigned total = gridDim.x;
-        if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
-    }
-    unsigned r_split, r_bx, r_by;
-    unsigned t = w4_div(lin, (unsigned)a.NCB, a.m_ncb, r_split);
-    const int split = (int)r_split;
-    const float* w_g = a.wpk + (size_t)split * W4_SLAB;                         // advanced by NCB*SLAB per k-step
-    const size_t w_step = (size_t)a.NCB * W4_SLAB;
-    // the U slab of k-step 0 is requested HERE, before anything else is known about the block: its addresses need only the
-    // output-channel split, and its latency then runs under the address arithmetic of the raw tile below
-    if (!(DIAG & 4)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        auto r_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, W4_SLAB * 4, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < W4_DMA_ITERS; ++k) {
-            int pc = wvu + 4 * k;
-            if (pc >= W4_PIECES) pc -= 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w0, (__attribute__((address_space(3))) void*)((char*)u_lds + 1024 * pc), 16,
-                                                     (unsigned)(1024 * pc + 16 * lane), 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    w_g += w_step;
-    t = w4_div(t, (unsigned)a.ntx, a.m_ntx, r_bx);
-    const int n = (int)w4_div(t, (unsigned)a.nty, a.m_nty, r_by);
-    const int bx = (int)r_bx, by = (int)r_by;
-    const int x0 = bx * W4_TW, y0 = by * W4_TH;
-
-    // ---- staging plan of the raw tile: LDS unit u = 64 * piece + lane = (hf * THP + r) * TWP + slot -> pixel (r, c) of the halo
-    // tile, channels 4hf .. 4hf+3; wave w fetches the pieces w, w + 4, ...  Pixels outside the image (and the padding units of the
-    // last piece) get an offset past the buffer descriptor's range and arrive as zeros.
+    // ---- per-unit state (a unit = one 8 x 64-pixel tile x one 32-channel output block; the classic form runs exactly one)
+    int split = 0, n = 0, x0 = 0, y0 = 0;
+    const float* w_g = nullptr;                                                 // advanced by NCB*SLAB per k-step
+    const float* in_g = nullptr;                                                // advanced by HW*8 per group
     unsigned in_off[W4_IN_ITERS];
-#pragma unroll
-    for (int k = 0; k < W4_IN_ITERS; ++k) {
-        int pc = wvu + 4 * k;
-        if (pc >= W4_RAW_PIECES) pc -= 4;
-        const int u = pc * 64 + lane;
-        const int hf = u >= W4_UNITS / 2 ? 1 : 0;
-        const int v = u - hf * (W4_UNITS / 2);
-        // v / 70 and sl / 17 as multiply-shifts (exact for v < 1259, sl < 70: W4_RSL = 70 slots per row, 17 per 16 pixels)
-        static_assert(W4_RSL == 70 && W4_UNITS / 2 < 1259, "the reciprocal 937 / 2^16 is exact for v < 1259 only");
-        const int r = (int)(((unsigned)v * 937u) >> 16), sl = v - r * W4_RSL;
-        const int g17 = (int)(((unsigned)sl * 241u) >> 12);                      // sl / 17
-        const int c = sl - g17;                                                  // 16 (sl / 17) + sl % 17; sl % 17 == 16: a padding slot
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        // (bitwise, not short-circuit: a guarded offset compiles to an exec-masked branch per piece)
-        const bool ok = (u < W4_UNITS) & (sl - 17 * g17 != 16) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-        const unsigned off = (unsigned)((gy * W + gx) * 32 + 16 * hf);
-        in_off[k] = ok ? off : 0xFFFFFF00u;
-    }
-    const float* in_g = a.in + (size_t)n * a.CGin * HW * 8;                     // advanced by HW*8 per group
+    const size_t w_step = (size_t)a.NCB * W4_SLAB;
     const unsigned plane_bytes = (unsigned)(HW * 32);
     (void)w_g; (void)plane_bytes; (void)in_g; (void)wvu;
 
@@ -320,13 +282,76 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         raw_done(last);
     };
 
+    // ---- a unit's opening requests: U slab of k-step 0, raw tiles of groups 0 and 1 (in this order: the wait at the head of the
+    // K loop -- all but the W4_IN_ITERS youngest requests, plus whatever stores follow -- then covers the slab and the first tile)
+    auto begin_unit = [&](unsigned unit) {
+        // XCD-aware order (as conv_wino.hip): one XCD works through a contiguous run of (tile, co-block) pairs, the co-blocks of
+        // a tile adjacent, so the input tile is fetched from HBM once
+        unsigned lin = unit;
+        {
+            const unsigned total = a.total_units;
+            if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+        }
+        unsigned r_split, r_bx, r_by;
+        unsigned t = w4_div(lin, (unsigned)a.NCB, a.m_ncb, r_split);
+        split = (int)r_split;
+        w_g = a.wpk + (size_t)split * W4_SLAB;
+        // the U slab of k-step 0 is requested HERE, before anything else is known about the unit: its addresses need only the
+        // output-channel split, and its latency then runs under the address arithmetic of the raw tile below
+#pragma unroll
+        for (int k = 0; k < W4_DMA_ITERS; ++k) issue_u_piece(u_lds, k);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        w_g += w_step;
+        t = w4_div(t, (unsigned)a.ntx, a.m_ntx, r_bx);
+        n = (int)w4_div(t, (unsigned)a.nty, a.m_nty, r_by);
+        x0 = (int)r_bx * W4_TW;
+        y0 = (int)r_by * W4_TH;
+        // staging plan of the raw tile: LDS unit u = 64 * piece + lane = (hf * THP + r) * RSL + slot -> pixel (r, c) of the halo tile,
+        // channels 4hf .. 4hf+3; wave w fetches the pieces w, w + 4, ...  Pixels outside the image (and the padding units of the last
+        // piece) get an offset past the buffer descriptor's range and arrive as zeros.
+#pragma unroll
+        for (int k = 0; k < W4_IN_ITERS; ++k) {
+            int pc = wvu + 4 * k;
+            if (pc >= W4_RAW_PIECES) pc -= 4;
+            const int u = pc * 64 + lane;
+            const int hf = u >= W4_UNITS / 2 ? 1 : 0;
+            const int v = u - hf * (W4_UNITS / 2);
+            // v / 70 and sl / 17 as multiply-shifts (exact for v < 1259, sl < 70: W4_RSL = 70 slots per row, 17 per 16 pixels)
+            static_assert(W4_RSL == 70 && W4_UNITS / 2 < 1259, "the reciprocal 937 / 2^16 is exact for v < 1259 only");
+            const int r = (int)(((unsigned)v * 937u) >> 16), sl = v - r * W4_RSL;
+            const int g17 = (int)(((unsigned)sl * 241u) >> 12);                      // sl / 17
+            const int c = sl - g17;                                                  // 16 (sl / 17) + sl % 17; sl % 17 == 16: a padding slot
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            // (bitwise, not short-circuit: a guarded offset compiles to an exec-masked branch per piece)
+            const bool ok = (u < W4_UNITS) & (sl - 17 * g17 != 16) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            const unsigned off = (unsigned)((gy * W + gx) * 32 + 16 * hf);
+            in_off[k] = ok ? off : 0xFFFFFF00u;
+        }
+        in_g = a.in + (size_t)n * a.CGin * HW * 8;
+        issue_raw(raw_lds, a.CGin <= 1);
+        issue_raw(raw_lds + W4_RAW, a.CGin <= 2);
+    };
+
     f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]; zeroed behind the first requests
 
     // per-lane LDS offsets (floats): patch of tile (tg, tn), channel pair q (half-pixel plane q >> 1, 8 bytes (q & 1) of the
     // unit); U vectors of half xh
-    const int b_row = (((q >> 1) * W4_THP + 4 * tg + xh) * W4_RSL) * 4 + (q & 1) * 2;        // wave xh reads the patch rows xh .. xh + 4
-    const int b_off0 = b_row + (4 * tn + (tn >> 2)) * 4, b_off1 = b_row + (4 * tn + ((tn + 1) >> 2)) * 4;   // columns 0..3 | 4, 5
-    const int a_off = xh * (9 * 256) + lane * 4;                                             // + v * 256
+    // (persistent form: re-derived from the lane number at the head of every unit, see loop_offsets(), so that they do not stay
+    // live through the epilogue, whose output transform needs every register)
+    int b_off0 = 0, b_off1 = 0, a_off = 0;
+    auto loop_offsets = [&]() {
+        int l = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (PERSIST) asm volatile("" : "+v"(l));                                   // opaque: a fresh value every unit
+#endif
+        const int tn_ = l & 15, q_ = l >> 4;
+        const int b_row = (((q_ >> 1) * W4_THP + 4 * tg + xh) * W4_RSL) * 4 + (q_ & 1) * 2;  // wave xh reads the patch rows xh .. xh + 4
+        b_off0 = b_row + (4 * tn_ + (tn_ >> 2)) * 4;                                         // columns 0..3
+        b_off1 = b_row + (4 * tn_ + ((tn_ + 1) >> 2)) * 4;                                   // columns 4, 5
+        a_off = xh * (9 * 256) + l * 4;                                                      // + v * 256
+    };
 
     const int CG = a.CGin;
     // one vector of the k-step slab, stored by the packer in the order the k-step walks its accumulators (see pack_wino4_kernel)
@@ -378,7 +403,7 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     //        with make room);
     //   V  = own rows of B^T d B, formed from T by the row pass during k-step (g, 0), one row per third of its MFMAs (that k-step
     //        walks row by row; only the first row's pass runs ahead of the MFMAs).
-    auto k_loop = [&](auto LO) {
+    auto k_loop = [&](auto LO, int stores_behind) {
         constexpr bool lo = decltype(LO)::value;
         f32x2 T[3][6], V[3][6];
         f32x2 ta = {0.f, 0.f}, tb = {0.f, 0.f};
@@ -408,11 +433,7 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             else half_op<false, k - 6>(T[r][1], T[r][2], T[r][3], T[r][4], T[r][5], V[r][3], V[r][4], V[r][5], ta, tb, m5);
         };
 
-        {   // prologue: U of k-step 0, raw tiles of groups 0 and 1; column pass of group 0.  (U first: its addresses need only the
-            // block's output-channel split, so its latency starts before the staging offsets of the raw tile are formed; the wait
-            // below -- all but the W4_IN_ITERS youngest requests -- covers U and the first raw tile in this order too)
-            issue_raw(raw_lds, CG <= 1);
-            issue_raw(raw_lds + W4_RAW, CG <= 2);
+        {   // head of a unit: begin_unit() has requested U of k-step 0 and the raw tiles of groups 0 and 1; column pass of group 0
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -425,7 +446,11 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W4_IN_ITERS) : "memory");
+            // landed by now: U of k-step 0 and the first raw tile -- everything but the W4_IN_ITERS requests of the second tile and
+            // (persistent form) the previous unit's output stores, which were issued behind them: vmcnt counts in issue order
+            if (stores_behind == 16) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W4_IN_ITERS + 16) : "memory");
+            else if (stores_behind == 8) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W4_IN_ITERS + 8) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W4_IN_ITERS) : "memory");
             W4_STAMP(1);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -514,179 +539,216 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             if (g < 24) W4_STAMP(11 + 4 * g);
         }
     };
-    if (xh == 0) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
-    W4_STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetched last slab must not land in the exchange buffer)
-    __syncthreads();
+    unsigned unit = blockIdx.x;
+    begin_unit(unit);
+    int stores_behind = 0;              // output stores of the previous unit issued behind this unit's opening requests (persistent form)
+    for (;;) {
+        loop_offsets();
+        if (xh == 0) k_loop(std::true_type{}, stores_behind);
+        else k_loop(std::false_type{}, stores_behind);
+        W4_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetched last slab must not land in the exchange buffer)
+        __syncthreads();
 
-    // ---- output transform.  Own rows xi: R[xi][j] = sum_nu M[xi][nu] A^T[j][nu], then the partial tile P[i][j] = sum_xi A^T[i][xi] R[xi][j];
-    // wave xh finishes the output rows 2xh, 2xh+1 and hands the other two to its partner through LDS.
-    // lane: tile (tg, tn), channels 32*split + 16*h + 4*q + r.
-    if (DIAG & 32) return;
-    float* const xbuf = smem_w4;                        // [wave 4][slot 16][lane 64][4]
-    f32x4 keep[2][4][2];                                // [row 2xh + il][j][h]
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f32x4 R[3][4];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const f32x4 m0 = acc[x][0][h], m1 = acc[x][1][h], m2 = acc[x][2][h], m3 = acc[x][3][h], m4 = acc[x][4][h], m5 = acc[x][5][h];
-            const f32x4 s1 = m1 + m2, d1 = psub4(m1, m2), s2 = m3 + m4, d2 = psub4(m3, m4);
-            R[x][0] = (m0 + s1) + s2;
-            R[x][1] = pk_fma(splat<f32x4>(2.f), d2, d1);
-            R[x][2] = pk_fma(splat<f32x4>(4.f), s2, s1);
-            R[x][3] = pk_fma(splat<f32x4>(8.f), d2, d1) + m5;
-        }
-        auto finish = [&](auto LO) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 P[4];
-                if constexpr (decltype(LO)::value) {        // rows xi = 0, 1, 2 of A^T: (1,0,0,0) (1,1,1,1) (1,-1,1,-1)
-                    const f32x4 s = R[1][j] + R[2][j], d = psub4(R[1][j], R[2][j]);
-                    P[0] = R[0][j] + s; P[1] = d; P[2] = s; P[3] = d;
-                } else {                                    // rows xi = 3, 4, 5: (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
-                    const f32x4 s = R[0][j] + R[1][j], d = psub4(R[0][j], R[1][j]);
-                    P[0] = s; P[1] = d * 2.f; P[2] = s * 4.f; P[3] = pk_fma(splat<f32x4>(8.f), d, R[2][j]);
-                }
-                constexpr int KEEP = decltype(LO)::value ? 0 : 2, SEND = decltype(LO)::value ? 2 : 0;
-#pragma unroll
-                for (int il = 0; il < 2; ++il) {
-                    keep[il][j][h] = P[KEEP + il];
-                    *(f32x4*)(xbuf + ((wvu * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4) = P[SEND + il];
-                }
+        // ---- output transform.  Own rows xi: R[xi][j] = sum_nu M[xi][nu] A^T[j][nu], then the partial tile P[i][j] = sum_xi A^T[i][xi] R[xi][j];
+        // wave xh finishes the output rows 2xh, 2xh+1 and hands the other two to its partner through LDS.
+        // lane: tile (tg, tn), channels 32*split + 16*h + 4*q + r.
+        if (DIAG & 32) return;
+        float* const xbuf = smem_w4;                        // [wave 4][slot 16][lane 64][4]
+        f32x4 keep[2][4][2];                                // [row 2xh + il][j][h]
+    #pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 R[3][4];
+    #pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const f32x4 m0 = acc[x][0][h], m1 = acc[x][1][h], m2 = acc[x][2][h], m3 = acc[x][3][h], m4 = acc[x][4][h], m5 = acc[x][5][h];
+                const f32x4 s1 = m1 + m2, d1 = psub4(m1, m2), s2 = m3 + m4, d2 = psub4(m3, m4);
+                R[x][0] = (m0 + s1) + s2;
+                R[x][1] = pk_fma(splat<f32x4>(2.f), d2, d1);
+                R[x][2] = pk_fma(splat<f32x4>(4.f), s2, s1);
+                R[x][3] = pk_fma(splat<f32x4>(8.f), d2, d1) + m5;
             }
-        };
-        if (xh == 0) finish(std::true_type{});
-        else finish(std::false_type{});
-    }
-    __syncthreads();
-    W4_STAMP(4);
-    const float* bias = a.wpk + (size_t)2 * a.CGin * w_step;
-    const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
-    (void)relu; (void)add_res; (void)mask; (void)bias;
-    if constexpr (SHUF) {
-        // PixelShuffle(2) folded into the store (flags bit3, as scipnp_conv3x3_c8w): conv channel 4c + 2dy + dx -> channel c of pixel
-        // (2y + dy, 2x + dx); the 32 conv channels of this workgroup are the 8 channels of output group `split`, and a lane's four
-        // values are the 2x2 sub-pixels of ONE output channel c = 4h + q.  The shuffled 16 x 128-pixel tile is assembled in LDS (the
-        // exchange area is free once every wave has read its partner's rows) and leaves in whole 128-byte lines: one thread = four
-        // consecutive pixels x 8 channels, skip tensor (same layout) added there.  out = relu?(conv + bias + res).
-        constexpr int ROW = 128 * 8 + 32 * 4;               // floats per shuffled row: 4 floats of padding per 4 pixels
-        static_assert(16 * ROW * 4 <= W4_LDS_BYTES, "shuffled tile");
-        float* const tile = smem_w4;
+            auto finish = [&](auto LO) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 P[4];
+                    if constexpr (decltype(LO)::value) {        // rows xi = 0, 1, 2 of A^T: (1,0,0,0) (1,1,1,1) (1,-1,1,-1)
+                        const f32x4 s = R[1][j] + R[2][j], d = psub4(R[1][j], R[2][j]);
+                        P[0] = R[0][j] + s; P[1] = d; P[2] = s; P[3] = d;
+                    } else {                                    // rows xi = 3, 4, 5: (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
+                        const f32x4 s = R[0][j] + R[1][j], d = psub4(R[0][j], R[1][j]);
+                        P[0] = s; P[1] = d * 2.f; P[2] = s * 4.f; P[3] = pk_fma(splat<f32x4>(8.f), d, R[2][j]);
+                    }
+                    constexpr int KEEP = decltype(LO)::value ? 0 : 2, SEND = decltype(LO)::value ? 2 : 0;
+    #pragma unroll
+                    for (int il = 0; il < 2; ++il) {
+                        keep[il][j][h] = P[KEEP + il];
+                        *(f32x4*)(xbuf + ((wvu * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4) = P[SEND + il];
+                    }
+                }
+            };
+            if (xh == 0) finish(std::true_type{});
+            else finish(std::false_type{});
+        }
+        __syncthreads();
+        W4_STAMP(4);
+        const float* bias = a.wpk + (size_t)2 * a.CGin * w_step;
+        const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
+        (void)relu; (void)add_res; (void)mask; (void)bias;
+        if constexpr (SHUF) {
+            // PixelShuffle(2) folded into the store (flags bit3, as scipnp_conv3x3_c8w): conv channel 4c + 2dy + dx -> channel c of pixel
+            // (2y + dy, 2x + dx); the 32 conv channels of this workgroup are the 8 channels of output group `split`, and a lane's four
+            // values are the 2x2 sub-pixels of ONE output channel c = 4h + q.  The shuffled 16 x 128-pixel tile is assembled in LDS (the
+            // exchange area is free once every wave has read its partner's rows) and leaves in whole 128-byte lines: one thread = four
+            // consecutive pixels x 8 channels, skip tensor (same layout) added there.  out = relu?(conv + bias + res).
+            constexpr int ROW = 128 * 8 + 32 * 4;               // floats per shuffled row: 4 floats of padding per 4 pixels
+            static_assert(16 * ROW * 4 <= W4_LDS_BYTES, "shuffled tile");
+            float* const tile = smem_w4;
+            f32x4 v[2][2][4];
+    #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 bs = *(const f32x4*)(bias + (split * 4 + h * 2 + (q >> 1)) * 8 + 4 * (q & 1));
+    #pragma unroll
+                for (int il = 0; il < 2; ++il)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[h][il][j] = (keep[il][j][h] + *(const f32x4*)(xbuf + (((wvu ^ 1) * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4)) + bs;
+            }
+            __syncthreads();                                    // partner rows read: the area becomes the shuffled tile
+    #pragma unroll
+            for (int h = 0; h < 2; ++h)
+    #pragma unroll
+                for (int il = 0; il < 2; ++il)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int yl = 2 * (4 * tg + 2 * xh + il) + (e >> 1), xl = 2 * (4 * tn + j) + (e & 1);
+                            tile[yl * ROW + xl * 8 + (xl >> 2) * 4 + 4 * h + q] = v[h][il][j][e];
+                        }
+            __syncthreads();
+    #if defined(__HIP_DEVICE_COMPILE__)
+            const int H2 = 2 * H, W2 = 2 * W;
+            const size_t plane = ((size_t)n * a.NCB + split) * (size_t)H2 * W2 * 8;               // floats; NCB = Cout/32 output groups
+            const unsigned pbytes = (unsigned)((size_t)H2 * W2 * 32);
+            auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, pbytes, 0x00020000);
+            auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)((add_res ? a.residual : a.out) + plane), 0, pbytes, 0x00020000);
+    #pragma unroll
+            for (int it = 0; it < 2; ++it) {                    // 16 rows x 32 groups of 4 pixels = 512 items, two per thread
+                const int item = tid + it * W4_THREADS, yl = item >> 5, xg = item & 31;
+                const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg;
+                const float* src = tile + yl * ROW + xg * 36;
+                f32x4 px[8];
+    #pragma unroll
+                for (int k = 0; k < 8; ++k) px[k] = *(const f32x4*)(src + 4 * k);
+                unsigned off[4];
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) off[k] = (y2 < H2 && x2 + k < W2) ? (unsigned)(((size_t)y2 * W2 + x2 + k) * 32) : 0x80000000u;
+                if (add_res) {
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        px[k] = px[k] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[k >> 1] + 16 * (k & 1), 0, 0));
+                }
+                if (relu) {
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k)
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) px[k][e] = fmaxf(px[k][e], 0.f);
+                }
+    #pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[k]), r_out, off[k >> 1] + 16 * (k & 1), 0, 0);
+            }
+    #endif
+            return;
+        }
+        // ---- plain store.  Everything that READS memory comes first (partner rows from LDS, bias, residual / mask source), then -- in
+        // the persistent form -- the next unit's opening requests, then the 16 stores of this unit: the requests' latency runs
+        // under the store phase, and no load of this epilogue ever queues behind them (vmcnt counts in issue order).
         f32x4 v[2][2][4];
+        unsigned off[2][2][4];
+        bool h_on[2];
+        const float* outp[2];
+        int le = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (PERSIST) asm volatile("" : "+v"(le));        // (tile / channel-pair numbers re-derived here: not live through the K loop)
+#endif
+        const int tn = le & 15, q = le >> 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f32x4 bs = *(const f32x4*)(bias + (split * 4 + h * 2 + (q >> 1)) * 8 + 4 * (q & 1));
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[h][il][j] = (keep[il][j][h] + *(const f32x4*)(xbuf + (((wvu ^ 1) * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4)) + bs;
-        }
-        __syncthreads();                                    // partner rows read: the area becomes the shuffled tile
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int yl = 2 * (4 * tg + 2 * xh + il) + (e >> 1), xl = 2 * (4 * tn + j) + (e & 1);
-                        tile[yl * ROW + xl * 8 + (xl >> 2) * 4 + 4 * h + q] = v[h][il][j][e];
-                    }
-        __syncthreads();
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int H2 = 2 * H, W2 = 2 * W;
-        const size_t plane = ((size_t)n * a.NCB + split) * (size_t)H2 * W2 * 8;               // floats; NCB = Cout/32 output groups
-        const unsigned pbytes = (unsigned)((size_t)H2 * W2 * 32);
-        auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, pbytes, 0x00020000);
-        auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)((add_res ? a.residual : a.out) + plane), 0, pbytes, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {                    // 16 rows x 32 groups of 4 pixels = 512 items, two per thread
-            const int item = tid + it * W4_THREADS, yl = item >> 5, xg = item & 31;
-            const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg;
-            const float* src = tile + yl * ROW + xg * 36;
-            f32x4 px[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) px[k] = *(const f32x4*)(src + 4 * k);
-            unsigned off[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) off[k] = (y2 < H2 && x2 + k < W2) ? (unsigned)(((size_t)y2 * W2 + x2 + k) * 32) : 0x80000000u;
-            if (add_res) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    px[k] = px[k] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[k >> 1] + 16 * (k & 1), 0, 0));
-            }
-            if (relu) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) px[k][e] = fmaxf(px[k][e], 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[k]), r_out, off[k >> 1] + 16 * (k & 1), 0, 0);
-        }
-#endif
-        return;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)
-        if (cog0 >= a.CGout) continue;                         // wave-uniform
-        const bool lane_ok = cog0 + (q >> 1) < a.CGout;
-        const f32x4 bs = *(const f32x4*)(bias + (cog0 + (q >> 1)) * 8 + 4 * (q & 1));          // bias holds CoutP entries
-        f32x4 v[2][4];
-        unsigned off[2][4];
-#pragma unroll
-        for (int il = 0; il < 2; ++il)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int y = y0 + 4 * tg + 2 * xh + il, x = x0 + 4 * tn + j;
-                const f32x4 other = *(const f32x4*)(xbuf + (((wvu ^ 1) * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4);
-                v[il][j] = (keep[il][j][h] + other) + bs;
-                off[il][j] = (lane_ok && y < H && x < W)
-                                 ? (unsigned)((y * W + x) * 32 + 16 * (q & 1)) + (unsigned)(q >> 1) * plane_bytes
-                                 : 0x80000000u;
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-        const size_t half0 = ((size_t)n * a.CGout + cog0) * HW * 8;                            // floats
-        if (add_res) {
-            auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + half0), 0, 2 * plane_bytes, 0x00020000);
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[il][j] = v[il][j] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[il][j], 0, 0));
-        }
-        if (relu) {
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[il][j][e] = fmaxf(v[il][j][e], 0.f);
-        }
-        if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
-            auto r_m = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_src + half0), 0, 2 * plane_bytes, 0x00020000);
+            const int cog0 = split * 4 + h * 2;                    // this lane's group: cog0 + (q >> 1)
+            h_on[h] = cog0 < a.CGout;                              // wave-uniform
+            outp[h] = a.out + ((size_t)n * a.CGout + cog0) * HW * 8;
+            if (!h_on[h]) continue;
+            const bool lane_ok = cog0 + (q >> 1) < a.CGout;
+            const f32x4 bs = *(const f32x4*)(bias + (cog0 + (q >> 1)) * 8 + 4 * (q & 1));          // bias holds CoutP entries
 #pragma unroll
             for (int il = 0; il < 2; ++il)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 fw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_m, off[il][j], 0, 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[il][j][e] = (fw[e] > 0.f) ? v[il][j][e] : 0.f;
+                    const int y = y0 + 4 * tg + 2 * xh + il, x = x0 + 4 * tn + j;
+                    const f32x4 other = *(const f32x4*)(xbuf + (((wvu ^ 1) * 16 + (il * 4 + j) * 2 + h) * 64 + lane) * 4);
+                    v[h][il][j] = (keep[il][j][h] + other) + bs;
+                    off[h][il][j] = (lane_ok && y < H && x < W)
+                                        ? (unsigned)((y * W + x) * 32 + 16 * (q & 1)) + (unsigned)(q >> 1) * plane_bytes
+                                        : 0x80000000u;
                 }
-        }
-        auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + half0), 0, 2 * plane_bytes, 0x00020000);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const size_t half0 = ((size_t)n * a.CGout + cog0) * HW * 8;                            // floats
+            if (add_res) {
+                auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + half0), 0, 2 * plane_bytes, 0x00020000);
 #pragma unroll
-        for (int il = 0; il < 2; ++il)
+                for (int il = 0; il < 2; ++il)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[il][j]), r_out, off[il][j], 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        v[h][il][j] = v[h][il][j] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[h][il][j], 0, 0));
+            }
+            if (relu) {
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[h][il][j][e] = fmaxf(v[h][il][j][e], 0.f);
+            }
+            if (mask) {   // ReLU backward: pass the gradient where the forward activation was > 0
+                auto r_m = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_src + half0), 0, 2 * plane_bytes, 0x00020000);
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 fw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_m, off[h][il][j], 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[h][il][j][e] = (fw[e] > 0.f) ? v[h][il][j][e] : 0.f;
+                    }
+            }
 #endif
+        }
+        bool more = false;
+        const unsigned next = unit + gridDim.x;
+        if constexpr (PERSIST) {
+            more = next < a.total_units;
+            if (more) {
+                __syncthreads();                                   // every wave has read its partner's rows: the LDS is free again
+                begin_unit(next);                                  // (overwrites split, n, x0, y0: the stores below use outp / off)
+            }
+        }
+        stores_behind = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!h_on[h]) continue;
+            auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)outp[h], 0, 2 * plane_bytes, 0x00020000);
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h][il][j]), r_out, off[h][il][j], 0, 0);
+            stores_behind += 8;
+        }
+#endif
+        if (!more) break;
+        unit = next;
     }
     W4_STAMP(5);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -779,6 +841,7 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     a.flags = flags;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.total_units = (unsigned)total;
     const int tag = (flags & 0x100) ? 1 : 0;
     const void* fns[2] = {(const void*)conv3x3_c8w4_kernel<0>, (const void*)conv3x3_c8w4_kernel<1>};
     static LdsAttrOnce attr[2];
@@ -838,6 +901,7 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.total_units = (unsigned)total;
     const dim3 grid((unsigned)total), block(W4_THREADS);
     // flags bits 12.. select a stamped build with parts switched off (diag bits 0..2 of scipnp_conv3x3_c8w4_diag; wrong results)
 #define W4_STAMP_CASE(D)                                                                                                     \
@@ -874,6 +938,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
     a.flags = flags & 1;
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
+    a.total_units = (unsigned)total;
     const dim3 grid((unsigned)total), block(W4_THREADS);
 #define W4_DIAG_CASE(D)                                                                                                    \
     case D: {                                                                                                              \
