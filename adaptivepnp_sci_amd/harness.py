@@ -191,9 +191,51 @@ class _Tee:
 
 
 # ------------------------------------------------------------------------------------------------ drivers
-def run_tv_warm_start(scene, logf=None, schedule=None, save_to=None, echo=True):
+def _tv_warm_start_batched(scene, sch, log, v, psnr, ssim, psnr_all):
+    """the measurements of a scene as ONE unit batch (solver.AdmmRun(units=nmea)): they are independent ADMM-TV problems on the same
+    masks, so one launch sequence steps all of them (about 3x the per-measurement throughput at 256 x 256 x 8, DESIGN section 7);
+    results bit-identical to the loop, the log text the loop would have written (measurement after measurement), the running
+    time reported per measurement = the batch's time / nmea"""
+    from . import ops
+    from .solver import AdmmRun, _as_lists, iteration_log_line
+    H, W, nmea = scene.meas.shape
+    nmask = scene.nmask
+    pairs = [scene.measurement(i) for i in range(nmea)]
+    have = pairs[0][1] is not None
+    sigma, iter_max = _as_lists(sch['sigma'], sch['iter_max'])
+    t0 = time.time()
+    run = AdmmRun([p[0] for p in pairs], [scene.mask] * nmea, 'tv', False, X_orig=[p[1] for p in pairs] if have else None,
+                  _lambda=1, gamma=0.01, units=nmea)
+    nsigs = []
+    for nsig, iters in zip(sigma, iter_max):
+        for _ in range(iters):
+            run.step(nsig)
+            nsigs.append(nsig)
+    mosaics, pall, reports = run.result_mosaic(), run.psnr_all(), (run.final_report() if have else None)
+    xs = [ops.to_host(m) for m in mosaics]
+    dt = (time.time() - t0) / nmea
+    for i in range(nmea):
+        log.write('Measurement Frame {}.\n'.format(i))
+        log.write('tv_denoiser start.\n')
+        for k, val in enumerate(pall[i]):
+            if (k + 1) % 2 == 0:
+                line, tail = iteration_log_line('TV', k, nsigs[k], val, False)
+                print(line)                                  # (as the solver does while it runs)
+                log.write(line + tail)
+        sl = slice(i * nmask, (i + 1) * nmask)
+        v[:, :, sl] = xs[i]
+        if have:
+            p, s_ = reports[i]
+            psnr[sl, 0], ssim[sl, 0] = p, s_
+            log.say('ADMM-{} PSNR {:2.2f} dB, SSIM {:.4f}, running time {:.1f} seconds.'.format('TV', mean(p), mean(s_), dt))
+        psnr_all.append(pall[i])
+
+
+def run_tv_warm_start(scene, logf=None, schedule=None, save_to=None, echo=True, batch=False):
     """ADMM-TV on every measurement of a scene (ADMM_TV_Warm_Start_save.py:112-178).  Returns
-    dict(v (H,W,nmask*nmea) in [0,1] units, psnr, ssim (nmask*nmea,1), psnr_all per measurement)."""
+    dict(v (H,W,nmask*nmea) in [0,1] units, psnr, ssim (nmask*nmea,1), psnr_all per measurement).
+    batch=True: the measurements are stepped together as one unit batch (same results and log text, see _tv_warm_start_batched);
+    needs H*W to be a multiple of 2048 when the scene carries ground truth (per-iteration PSNR of every unit)."""
     sch = schedule or TV_SCHEDULE
     H, W, nmea = scene.meas.shape
     nmask = scene.nmask
@@ -204,6 +246,11 @@ def run_tv_warm_start(scene, logf=None, schedule=None, save_to=None, echo=True):
     psnr_all = []
     log.write(scene.name + ':\n')
     log.write('tv_denoiser start...\n')
+    if batch and nmea > 1:
+        _tv_warm_start_batched(scene, sch, log, v, psnr, ssim, psnr_all)
+        if save_to:
+            save_warm_start(save_to, v, psnr, ssim)
+        return dict(v=v, psnr=psnr, ssim=ssim, psnr_all=psnr_all)
     for i in range(nmea):
         log.write('Measurement Frame {}.\n'.format(i))
         y, orig = scene.measurement(i)
@@ -381,6 +428,8 @@ def main(argv=None):
     ap.add_argument('--results', default='./results')
     ap.add_argument('--no-update', action='store_true', help='disable the online finetune')
     ap.add_argument('--no-reuse-model', action='store_true')
+    ap.add_argument('--batch-tv', action='store_true', help='ADMM-TV warm start of all measurements as one unit batch (same results, '
+                                                           '~3x the throughput on small scenes)')
     args = ap.parse_args(argv)
     worker_init_fn(0)
     _lib.cap_host_threads()
@@ -392,7 +441,7 @@ def main(argv=None):
         if os.path.exists(wpath):
             warm = load_warm_start(wpath)
         else:
-            warm = run_tv_warm_start(scene, f, save_to=wpath)['v']
+            warm = run_tv_warm_start(scene, f, save_to=wpath, batch=args.batch_tv)['v']
         dd = None
         if args.ddnet_weights:
             from .ddnet import DDnet

@@ -722,19 +722,19 @@ class _LogStream:
             self._emit(k, nsig, psnr)
 
     def _emit(self, k, nsig, psnr):
-        if not self.noise_estimate and nsig is not None:
-            if nsig < 1:
-                line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255, PSNR {3:2.2f} dB.'.format(self.name, k + 1, nsig * 255, psnr)
-                print(line)
-                self.logf.write(line + ' \n')
-            else:
-                line = '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}, PSNR {3:2.2f} dB.'.format(self.name, k + 1, nsig, psnr)
-                print(line)
-                self.logf.write(line + '\n')
-        else:
-            line = '  ADMM-{0} iteration {1: 3d}, PSNR {2:2.2f} dB.'.format(self.name, k + 1, psnr)
-            print(line)
-            self.logf.write(line + '\n')
+        line, tail = iteration_log_line(self.name, k, nsig, psnr, self.noise_estimate)
+        print(line)
+        self.logf.write(line + tail)
+
+
+def iteration_log_line(name, k, nsig, psnr, noise_estimate):
+    """(line, line ending) of the reference's per-iteration PSNR report for 0-based iteration k (dvp...:282-304 / :513-535: three
+    formats, the sigma < 1 one with a blank before the newline)"""
+    if not noise_estimate and nsig is not None:
+        if nsig < 1:
+            return '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}/255, PSNR {3:2.2f} dB.'.format(name, k + 1, nsig * 255, psnr), ' \n'
+        return '  ADMM-{0} iteration {1: 3d}, sigma {2: 3g}, PSNR {3:2.2f} dB.'.format(name, k + 1, nsig, psnr), '\n'
+    return '  ADMM-{0} iteration {1: 3d}, PSNR {2:2.2f} dB.'.format(name, k + 1, psnr), '\n'
 
 
 def _run_schedule(run, sigma, iter_max, log=None):

@@ -222,3 +222,27 @@ def test_cli_runs_a_v73_scene(tmp_path):
     sc = harness.load_scene(scene)
     assert os.path.exists(harness.warm_start_path(res, sc))
     assert harness.load_warm_start(harness.warm_start_path(res, sc)).shape == (12, 16, 8)
+
+
+@pytest.mark.gpu
+def test_tv_warm_start_as_a_unit_batch_equals_the_loop(tmp_path):
+    """ADMM_TV_Warm_Start_save.py loops over the measurements of a scene; batch=True steps them together as one unit batch
+    (solver.AdmmRun(units=nmea)): the same v, PSNR / SSIM tables, per-iteration PSNR and -- but for the running-time figure --
+    the same log text, measurement after measurement"""
+    import re
+    meas, mask, orig = _scene_arrays(64, 64, nmea=3)
+    sc = harness.Scene('Toy_bayer', meas, mask, orig)
+    logs = []
+    outs = []
+    for batch in (False, True):
+        log = io.StringIO()
+        outs.append(harness.run_tv_warm_start(sc, log, schedule=dict(sigma=[0], iter_max=[12]), echo=False, batch=batch,
+                                              save_to=str(tmp_path / f'warm_{int(batch)}.mat')))
+        logs.append(re.sub(r'running time [0-9.]+ seconds', 'running time T seconds', log.getvalue()))
+    a, b = outs
+    assert np.array_equal(a['v'], b['v'])
+    assert np.allclose(a['psnr'], b['psnr'], atol=1e-6) and np.allclose(a['ssim'], b['ssim'], atol=1e-9)
+    for pa, pb in zip(a['psnr_all'], b['psnr_all']):
+        assert len(pa) == len(pb) == 12 and np.abs(np.array(pa) - np.array(pb)).max() < 1e-9
+    assert logs[0] == logs[1] and logs[0].count('Measurement Frame') == 3
+    assert np.array_equal(harness.load_warm_start(str(tmp_path / 'warm_0.mat')), harness.load_warm_start(str(tmp_path / 'warm_1.mat')))
