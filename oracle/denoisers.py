@@ -162,18 +162,57 @@ def fastdvdnet_pass(vnoisy, sigma, y_planes=None, Phi_planes=None, model=None, l
     return out, model
 
 
-def ddnet_pass(x_bayer_3ch, model):
-    """Deep demosaicking of a (H,W,3,B) CFA-site cube (`oneCh2ThreeCh` of the mosaic): sliding 5-frame window with
-    circular temporal indexing, reflect-pad to multiples of 4, no finetune on this call path (the solver passes no
-    `args`).  reference packages/DDnet/DDnet_test.py:166-216 (ddnet_seqdenoise), :218-321 (test_ddnet)."""
-    model.eval()
-    seq = x_bayer_3ch.permute(3, 2, 0, 1)
+def _ddnet_seq(seq, model):
+    """packages/DDnet/DDnet_test.py:166-206 (ddnet_seqdenoise): sliding 5-frame window with circular temporal indexing,
+    reflect-pad to multiples of 4, one network call per frame"""
     N, C, H, W = seq.shape
     out = torch.empty((N, C, H, W))
     wpad, hpad = (-W) % 4, (-H) % 4
+    for n in range(N):
+        idx = (torch.arange(n, n + NUM_IN_FR_EXT) - 2) % N
+        win = F.pad(seq[idx].reshape((1, -1, H, W)), (0, wpad, 0, hpad), mode='reflect')
+        out[n] = model(win)[:, :, :H, :W]
+    return out
+
+
+def bayer_sites(rgb_video):
+    """packages/DDnet/DDnet_test.py:208-216 (gen_bayer_img): (H,W,3,F) -> the CFA samples of every frame at their sites,
+    zeros elsewhere, as (F,3,H,W)"""
+    bayer = torch.zeros_like(rgb_video)
+    bayer[0::2, 0::2, 0, :] = rgb_video[0::2, 0::2, 0, :]
+    bayer[0::2, 1::2, 1, :] = rgb_video[0::2, 1::2, 1, :]
+    bayer[1::2, 0::2, 1, :] = rgb_video[1::2, 0::2, 1, :]
+    bayer[1::2, 1::2, 2, :] = rgb_video[1::2, 1::2, 2, :]
+    return bayer.permute(3, 2, 0, 1)
+
+
+def ddnet_pass(x_bayer_3ch, model, dm_update=False, dm_lr=1e-6, dm_update_per_iter=1, trace=None):
+    """Deep demosaicking of a (H,W,3,B) CFA-site cube (`oneCh2ThreeCh` of the mosaic): sliding 5-frame window with
+    circular temporal indexing, reflect-pad to multiples of 4.  reference packages/DDnet/DDnet_test.py:166-216
+    (ddnet_seqdenoise), :218-321 (test_ddnet).
+
+    dm_update (the `args.dm_update` branch, :248-296; the solver never passes `args`, a caller of the plug-in may):
+    `dm_update_per_iter` steps of { all frames through the network (train mode: no BatchNorm or dropout in DDnet, so the
+    same function), loss = MSE(input cube, CFA samples of the output), a NEW Adam(model.parameters(), lr=dm_lr) every step,
+    backward, step }, then the pass itself without gradients.  Returns (out, model) then, like the reference.
+    trace: list receiving the loss of every step."""
+    seq = x_bayer_3ch.permute(3, 2, 0, 1)
+    if dm_update:
+        mse = torch.nn.MSELoss()
+        model.train()
+        for _ in range(dm_update_per_iter):
+            outv = _ddnet_seq(seq, model).permute(2, 3, 1, 0)
+            total_loss = mse(seq, bayer_sites(outv))
+            optimizer = torch.optim.Adam(model.parameters(), lr=dm_lr)
+            optimizer.zero_grad()
+            total_loss.backward()
+            optimizer.step()
+            if trace is not None:
+                trace.append(float(total_loss))
+        with torch.no_grad():
+            out = _ddnet_seq(seq, model)
+        return out.permute(2, 3, 1, 0), model
+    model.eval()
     with torch.no_grad():
-        for n in range(N):
-            idx = (torch.arange(n, n + NUM_IN_FR_EXT) - 2) % N
-            win = F.pad(seq[idx].reshape((1, -1, H, W)), (0, wpad, 0, hpad), mode='reflect')
-            out[n] = model(win)[:, :, :H, :W]
+        out = _ddnet_seq(seq, model)
     return out.permute(2, 3, 1, 0)

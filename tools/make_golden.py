@@ -608,6 +608,79 @@ def g_ddnet():
          psnr_ffdnet=res[4], theta_fastdvd=ref_it2, rgb_fastdvd=res2[0])
 
 
+def g_ddnettune():
+    """DDnet's own online finetune (`args.dm_update`, packages/DDnet/DDnet_test.py:218-296): two steps of { all frames through
+    the network, MSE(input cube, CFA samples of the output), a NEW Adam over every parameter, backward, step }, then the pass.
+    Captured from the reference: the output cube, the reference's `.grad` after the first backward (every gate tensor and
+    one conv weight per layer type in full, the norm of every tensor), the weights' change, the losses."""
+    import types
+    from models.network_demosaicking import DDnet as RefDDnet
+    onet = ON.synth_ddnet_weights(0)
+    rnet = RefDDnet()
+    rnet.load_state_dict(onet.state_dict(), strict=True)
+    sd0 = {k: v.clone() for k, v in onet.state_dict().items()}
+    rng = np.random.default_rng(29)
+    H, W, B = 32, 48, 8
+    # a smooth scene seen through the CFA, so that the demosaicker's loss gradient has structure
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    mosaic = np.stack([0.5 + 0.3 * np.sin(0.21 * xx + 0.13 * yy + 0.4 * t) * np.cos(0.17 * yy - 0.1 * t) for t in range(B)], 2)
+    mosaic = torch.from_numpy((mosaic + 0.05 * rng.standard_normal(mosaic.shape)).clip(0, 1).astype(np.float32))
+    v = R.oneCh2ThreeCh(mosaic)
+    args = types.SimpleNamespace(dm_update=True, dm_lr=2e-5, dm_update_per_iter=2)
+    grads = {}
+    orig_step = torch.optim.Adam.step
+
+    def step(opt, *a, **k):
+        if not grads:
+            for (n, p_) in rnet.named_parameters():
+                grads[n] = None if p_.grad is None else p_.grad.detach().clone()
+        return orig_step(opt, *a, **k)
+    torch.optim.Adam.step = step
+    try:
+        seed_all()
+        ref, rmodel = R.test_ddnet(v, None, None, rnet, True, args)
+    finally:
+        torch.optim.Adam.step = orig_step
+    trace = []
+    ograds = {}
+
+    def ostep(opt, *a, **k):
+        if not ograds:
+            for (n, p_) in onet.named_parameters():
+                ograds[n] = None if p_.grad is None else p_.grad.detach().clone()
+        return orig_step(opt, *a, **k)
+    torch.optim.Adam.step = ostep
+    try:
+        mine, omodel = OD.ddnet_pass(OO.one_to_three_channel(mosaic), onet, dm_update=True, dm_lr=2e-5, dm_update_per_iter=2,
+                                     trace=trace)
+    finally:
+        torch.optim.Adam.step = orig_step
+    check('ddnet dm_update output cube', mine.detach(), ref.detach())
+    rsd, osd = rmodel.state_dict(), omodel.state_dict()
+    assert max(rel(osd[k], rsd[k]) for k in rsd) == 0.0
+    assert set(k for k, g_ in grads.items() if g_ is None) == set(k for k in grads if '.inc.' in k), 'only the unused inc blocks lack a gradient'
+    for k in grads:
+        if grads[k] is not None:
+            check(f'first-step gradient {k}', ograds[k], grads[k])
+    full = ('weight_tensor_in', 'weight_tensor_in2', 'weight_tensor_out', 'temp1.inc_1.convblock.0.weight', 'temp1.outc.convblock.2.weight',
+            'temp2.inc_1.convblock.2.weight', 'temp2.downc0.convblock.0.weight', 'temp2.upc1.convblock.1.weight',
+            'temp11.inc_1.convblock.0.weight', 'temp11.downc1.convblock.2.convblock.0.weight', 'temp11.fusion.convblock.0.weight',
+            'temp11.fusion.convblock.2.weight', 'temp11.outc.convblock.2.weight')
+    out = {}
+    for k, g_ in grads.items():
+        if g_ is None:
+            continue
+        key = k.replace('.', '_')
+        out['gradnorm_' + key] = float(torch.linalg.vector_norm(g_.double()))
+        out['dnorm_' + key] = float(torch.linalg.vector_norm((rsd[k].float() - sd0[k].float()).double()))
+        if k in full:
+            out['grad_' + key] = g_.numpy()
+            out['delta_' + key] = (rsd[k].float() - sd0[k].float()).numpy()
+    print(f'   losses {trace}; |d weight_tensor_out| {out["dnorm_weight_tensor_out"]:.3e}')
+    save('ddnet_finetune_32x48x8', mosaic=mosaic.numpy(), out=ref.detach().numpy(), losses=np.array(trace), lr=np.float64(2e-5),
+         steps=np.int32(2), **out)
+
+
 def g_logs():
     """Log text of both solvers (dvp...:282-309, :513-535) for every branch of the formatting code: sigma < 1 and
     sigma >= 1, noise_estimate on/off, with and without ground truth; tiny TV problems, real reference run."""
@@ -626,7 +699,7 @@ def g_logs():
     save('log_text_16x16x4', y=y, Phi=Phi, orig=orig, **out)
 
 
-GROUPS = dict(fastdvdlong=g_fastdvdlong, ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+GROUPS = dict(ddnettune=g_ddnettune, fastdvdlong=g_fastdvdlong, ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
