@@ -98,6 +98,11 @@ SIGNATURES = {
     'scipnp_ddnet_finish': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'scipnp_bilinear_up2_c8': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ddnet_mix': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    'scipnp_ddnet_loss_grad': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_ddnet_mix_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_ddnet_finish_bwd': (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    'scipnp_ddnet_gather_bwd': (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_bilinear_up2_bwd_c8': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'scipnp_ffdnet_forward': (_int, [_vp, _vp, C.POINTER(_vp), _int, _int, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_host_legacy_normal': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_double), C.c_double, C.c_double,
                                         _vp, _sz]),

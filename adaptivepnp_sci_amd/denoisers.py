@@ -85,11 +85,12 @@ def fastdvdnet_denoiser_full_tensor_v2(vnoisy, sigma, y_bayer=None, Phi=None, mo
 def test_ddnet(vnoisy, yall=None, Phiall=None, model=None, useGPU=True, args=None, gray=False):
     """Deep demosaicking plug-in: vnoisy (H,W,3,B) CUDA tensor holding the mosaic at its CFA sites (`oneCh2ThreeCh`)
     -> demosaicked (H,W,3,B).  The network only sees the channel sum (network_demosaicking.py:425-429), i.e. the
-    mosaic.  `args` with dm_update (online finetune of the demosaicker) is never passed by the solver and is not
-    supported."""
+    mosaic.  `args` (an object with dm_update, dm_lr, dm_update_per_iter; the solver never passes one): with dm_update the
+    demosaicker is first finetuned online on MSE(input, CFA samples of its output) -- DDnet_test.py:248-296, a new Adam per
+    step, `model` updated in place (ddnet_train.ddnet_online_finetune) -- and (out, model) is returned like the reference."""
     from .ddnet import DDnetEngine
-    if gray or (args is not None and getattr(args, 'dm_update', False)):
-        raise NotImplementedError('grayscale / online-finetuned DDnet is outside the hot path (the solver never uses it)')
+    if gray:
+        raise NotImplementedError('grayscale DDnet is outside the Bayer hot path')
     H, W, _, B = vnoisy.shape
     mosaic3 = ops.cube_sum3(vnoisy.float().contiguous())                   # (H,W,B): one non-zero term per pixel
     planes = ops.mosaic_to_state(mosaic3)
@@ -97,6 +98,10 @@ def test_ddnet(vnoisy, yall=None, Phiall=None, model=None, useGPU=True, args=Non
     ops.pm_ddnet_inputs(planes, None, 0.0, torch.empty_like(planes), mosaic)
     eng = DDnetEngine(model, B, H, W, vnoisy.device)
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=vnoisy.device)
+    if args is not None and getattr(args, 'dm_update', False):
+        from .ddnet_train import ddnet_online_finetune
+        ddnet_online_finetune(model, eng, planes, mosaic, args.dm_lr, args.dm_update_per_iter)
+        return ops.rgb_to_cube(eng.forward(planes, mosaic, out)), model
     return ops.rgb_to_cube(eng.forward(planes, mosaic, out))
 
 

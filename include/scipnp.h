@@ -618,6 +618,28 @@ int scipnp_bilinear_up2_c8(const float* in, float* out_c8, void* out_c8s, int E,
 /* x_out = gates[0][c]*branches[n] + gates[1][c]*branches[B+n], planar [2B][3][H*W] -> [B][3][H*W]  -- :461 */
 int scipnp_ddnet_mix(const float* branches, const float* gates, float* out, int B, int H, int W, scipnp_stream_t s);
 
+/* ---- online finetune of the demosaicker (`args.dm_update`, packages/DDnet/DDnet_test.py:248-296; adaptivepnp_sci_amd/ddnet_train.py):
+ * scipnp_ddnet_loss_grad  MSE(input CFA-site cube, CFA samples of the output) over F*3*H*W elements (:208-216, :273-275): dout
+ *                         [B][3][H][W] = its gradient, loss_part = per-block sums of the squared differences (fp64; *nblocks
+ *                         entries; out == NULL: size query);
+ * scipnp_ddnet_mix_bwd    adjoint of scipnp_ddnet_mix: d_branches [2B][3][H][W], part = 6 rows (gate (branch, channel)) of *ncols
+ *                         partial sums of d gates;
+ * scipnp_ddnet_finish_bwd the planar gradient [E][Cout][h][w] at a DenBlock's output as the c8 gradient of its 8-channel tail;
+ * scipnp_ddnet_gather_bwd adjoint of scipnp_ddnet_gather plus the `in1 +` path of scipnp_ddnet_finish (d_center: gradient at the
+ *                         block output, Cd channels; NULL: none): part = (E / Bn) * 3 * C rows (gate (window j, slot i, channel c),
+ *                         evaluation e = j * Bn + n) of *ncols partial sums of g * src (NULL: no gate gradients), d_src = g * scale
+ *                         scattered to the source frames (NULL: not wanted; every frame must be referenced once);
+ * scipnp_bilinear_up2_bwd_c8  adjoint of scipnp_bilinear_up2_c8: d_in [E][4][h][w] from the c8 gradient at [E][1][2h][2w]. */
+int scipnp_ddnet_loss_grad(const float* out, const float* mosaic, float* dout, double* loss_part, int H, int W, int B,
+                           int* nblocks, scipnp_stream_t s);
+int scipnp_ddnet_mix_bwd(const float* dout, const float* branches, const float* gates, float* d_branches, double* part, int B,
+                         int H, int W, int* ncols, scipnp_stream_t s);
+int scipnp_ddnet_finish_bwd(const float* d_out, float* d_x8, int E, int Cout, int h, int w, scipnp_stream_t s);
+int scipnp_ddnet_gather_bwd(const float* d_tin_c8, const float* d_center, int Cd, const float* src, const int* idx,
+                            const float* scale, float* d_src, double* part, int E, int Bn, int C, int h, int w, int* ncols,
+                            scipnp_stream_t s);
+int scipnp_bilinear_up2_bwd_c8(const float* d_up_c8, float* d_in, int E, int h, int w, scipnp_stream_t s);
+
 /* HOST function (no GPU involved): n deviates of NumPy's LEGACY normal stream -- np.random.normal(loc, scale, n) on the
  * global RandomState, bit for bit -- from / to a generator state in np.random.get_state() form (key[624], pos,
  * has_gauss, cached_gaussian).  The reference draws its FastDVDnet finetune noise from that stream
