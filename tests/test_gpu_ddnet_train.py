@@ -115,7 +115,8 @@ def test_ddnet_glue_adjoints_vs_autograd():
     d_up = torch.zeros(E, 1, 2 * h, 2 * w, 8)
     d_up[:, 0, :, :, :4] = gup.permute(0, 2, 3, 1).float()
     d_in = torch.empty(E, 4, h, w, device='cuda')
-    _lib.check(lib.scipnp_bilinear_up2_bwd_c8(P(d_up.cuda()), P(d_in), E, h, w, st()), 'bilinear bwd')
+    d_up_d = d_up.cuda()                                  # (device copies are kept in variables: a temporary would be freed -- and its
+    _lib.check(lib.scipnp_bilinear_up2_bwd_c8(P(d_up_d), P(d_in), E, h, w, st()), 'bilinear bwd')        # memory reused -- before the launch)
     assert rel_l2(d_in.cpu().numpy(), x.grad.numpy()) <= 1e-6
     # ---- gather (+ centre path) for C = 1 (centre gradient summed over 3 output channels) and C = 4
     for Cc, Cd in ((1, 3), (4, 4), (3, 3)):
@@ -140,7 +141,8 @@ def test_ddnet_glue_adjoints_vs_autograd():
         ncols = C.c_int(0)
         _lib.check(lib.scipnp_ddnet_gather_bwd(None, None, 0, None, None, None, None, None, E, Bn, Cc, hh, ww, C.byref(ncols), None), 'size')
         part = torch.empty(9 * Cc, ncols.value, dtype=torch.float64, device='cuda')
-        _lib.check(lib.scipnp_ddnet_gather_bwd(P(d_tin_c8), P(g_c.float().cuda()), Cd, P(src.cuda()), P(idx.cuda()), None, None, P(part), E,
+        g_c_d, src_d, idx_d = g_c.float().cuda(), src.cuda(), idx.cuda()
+        _lib.check(lib.scipnp_ddnet_gather_bwd(P(d_tin_c8), P(g_c_d), Cd, P(src_d), P(idx_d), None, None, P(part), E,
                                                Bn, Cc, hh, ww, C.byref(ncols), st()), 'gather bwd')
         got = ops.sum_rows_f64(part).cpu().numpy().reshape(3, 3, Cc)
         assert rel_l2(got, gate.grad.numpy()) <= 1e-6, (Cc, rel_l2(got, gate.grad.numpy()))
@@ -156,7 +158,8 @@ def test_ddnet_glue_adjoints_vs_autograd():
     _lib.check(lib.scipnp_ddnet_mix_bwd(None, None, None, None, None, B, H, W, C.byref(ncols), None), 'size')
     part = torch.empty(6, ncols.value, dtype=torch.float64, device='cuda')
     d_s2 = torch.empty(2 * B, 3, H, W, device='cuda')
-    _lib.check(lib.scipnp_ddnet_mix_bwd(P(gout.float().cuda()), P(s2.cuda()), P(a3.detach().float().cuda()), P(d_s2), P(part), B, H, W,
+    gout_d, s2_d, a3_d = gout.float().cuda(), s2.cuda(), a3.detach().float().cuda()
+    _lib.check(lib.scipnp_ddnet_mix_bwd(P(gout_d), P(s2_d), P(a3_d), P(d_s2), P(part), B, H, W,
                                         C.byref(ncols), st()), 'mix bwd')
     assert rel_l2(d_s2.cpu().numpy(), s2d.grad.numpy()) <= 1e-6
     assert rel_l2(ops.sum_rows_f64(part).cpu().numpy().reshape(2, 3), a3.grad.numpy()) <= 1e-6
