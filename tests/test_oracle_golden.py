@@ -230,3 +230,21 @@ def test_gray_oracle_projection_is_the_pinned_bayer_projection():
     assert np.array_equal(g['x_iterates'][0], bay['x_iterates'][0])
     g2 = OS.one_stage_admm_gray(y, Phi, 1, 0.01, 'tv_gray', [2], [0], X_orig=orig, Phi_sum=Phi.sum(2))
     assert np.array_equal(g2['x'], g['x']) and len(g['psnr_all']) == 2
+
+
+def test_ddnet_dm_update_golden():
+    """DDnet's own online finetune (`args.dm_update`, packages/DDnet/DDnet_test.py:248-296): the oracle's restatement against
+    the reference run captured in tests/golden/ddnet_finetune_32x48x8.npz -- output cube after the two fresh-Adam steps, the
+    losses, the weights' change (tools/make_golden.py ddnettune asserted rel-L2 0.0 incl. every first-step gradient)"""
+    g = load_gold('ddnet_finetune_32x48x8')
+    net = ON.synth_ddnet_weights(0)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    trace = []
+    out, model = OD.ddnet_pass(OO.one_to_three_channel(T(g['mosaic'])), net, dm_update=True, dm_lr=float(g['lr']),
+                               dm_update_per_iter=int(g['steps']), trace=trace)
+    assert model is net and rel_l2(out.detach(), g['out']) == 0
+    assert np.array_equal(np.array(trace), g['losses'])
+    sd = net.state_dict()
+    for k in ('weight_tensor_in', 'weight_tensor_out', 'temp11.fusion.convblock.2.weight', 'temp2.upc1.convblock.1.weight'):
+        assert np.array_equal((sd[k] - sd0[k]).numpy(), g['delta_' + k.replace('.', '_')]), k
+    assert all(torch.equal(sd[k], sd0[k]) for k in sd if '.inc.' in k)          # unused blocks: no gradient, Adam skips them
