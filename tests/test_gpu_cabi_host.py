@@ -180,3 +180,31 @@ def test_the_ctypes_stub_of_integration_md_runs_as_written():
     th = dev(theta)
     ns['project_all'](th, dev(b), dev(Phi), dev(y), dev(Ps), 0.55, 1.0, th)         # in place, as at k = 0
     assert torch.equal(th.cpu(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,U', [((64, 64, 8), 3), ((256, 256, 8), 8)])
+def test_plain_c_host_unit_batch_equals_unit_after_unit(tmp_path, shape, U):
+    """examples/host_c/tv_units_host.c: the unit axis of the C ABI (scipnp_admm_tv_args.units, scipnp_pm_setup_units) from a plain C
+    host -- U ADMM-TV problems stepped by ONE call per iteration on the [B][U][4][M][N] layout against U calls on per-unit
+    states: bit-identical (checked by the host itself), and equal to the Python solver's result"""
+    import io
+    import numpy as np
+    from adaptivepnp_sci_amd import admm_denoise_bayer_demosaic_pre, synth
+    H, W, B = shape
+    iters = 7
+    blob, out = str(tmp_path / 'units.bin'), str(tmp_path / 'units_out.bin')
+    pr = [synth.make_problem(H, W, B, seed=40 + u) for u in range(U)]
+    with open(blob, 'wb') as f:
+        np.array([H, W, B, U, iters], np.int32).tofile(f)
+        for y, Phi, _o in pr:
+            y.astype(np.float32).tofile(f)
+            np.ascontiguousarray(Phi, np.float32).tofile(f)
+    exe = str(tmp_path / 'tv_units_host')
+    _build(os.path.join(ROOT, 'examples', 'host_c', 'tv_units_host.c'), exe)
+    r = subprocess.run([exe, blob, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'bit-identical' in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(out, np.float32).reshape(U, H, W, B)
+    for u, (y, Phi, _o) in enumerate(pr):
+        ref = admm_denoise_bayer_demosaic_pre(y, Phi, 1, 0.01, 'tv', [iters], False, [0], logf=io.StringIO())[0]
+        assert np.array_equal(got[u], ref), u
