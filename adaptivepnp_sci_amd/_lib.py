@@ -58,6 +58,8 @@ SIGNATURES = {
     'scipnp_conv3x3_wgrad': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_wgrad_wino_workspace_floats': (_sz, [_int, _int, _int]),
     'scipnp_conv3x3_wgrad_wino': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_wgrad_wino4_workspace_floats': (_sz, [_int, _int, _int]),
+    'scipnp_conv3x3_wgrad_wino4': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv_bias_grad': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'scipnp_adam_step': (_int, [_vp, _vp, _vp, _vp, _sz, C.c_double, C.c_double, C.c_double, C.c_double, _int, _vp]),
     'scipnp_pack_conv3x3_device': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),

@@ -12,6 +12,7 @@ A fresh Adam state is created per call, like the reference (`torch.optim.Adam(mo
 module's parameters are updated in place and the engine continues on the device-packed updated weights.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -51,6 +52,19 @@ def _wino_slabs(cin):
     """persistent workgroups of the fp32 Winograd weight-gradient kernel (csrc/wgrad_wino.hip) = slabs x (Cin/32 blocks):
     one 16-wave workgroup per CU"""
     return max(1, 255 // ((cin + 31) // 32))
+
+
+def _wino4_slabs(cin, cout):
+    """persistent workgroups of the F(4x4)-domain weight-gradient kernel (csrc/wgrad_wino4.hip) = slabs x (Cout/32 x Cin/32
+    blocks), one 12-wave workgroup per CU"""
+    return max(1, 255 // (((cin + 31) // 32) * ((cout + 31) // 32)))
+
+
+def wgrad_f4_enabled():
+    """SCIPNP_F32_WGRAD=f4: the fp32 FFDNet trainer takes the weight gradients of its 32-multiple layers in the Winograd
+    F(4x4) domain (396 us against 439 us at 96 -> 96 on 8 x 256 x 256, rounding 7e-6 against 1.5e-6 of the gradient's norm:
+    DESIGN.md section 5); default: the F(2x2) form"""
+    return os.environ.get('SCIPNP_F32_WGRAD', 'f2').lower() == 'f4'
 
 
 def _wino_wgrad_fits(n, cin, cout, h, w):
@@ -175,6 +189,10 @@ class _FFDNetTrainer:
         if self.wino:        # fp32: weight gradients in the Winograd domain too (16 positions per slab instead of 9 taps)
             ws = max([ws] + [lib.scipnp_conv3x3_wgrad_wino_workspace_floats(ci, co, _wino_slabs(ci))
                              for ci, co in zip(self.cin, self.cout)])
+        self.wino4 = self.wino and wgrad_f4_enabled()
+        if self.wino4:
+            ws = max([ws] + [lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(ci, co, _wino4_slabs(ci, co))
+                             for ci, co in zip(self.cin, self.cout)])
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty((nc // 8) * 64 * 8, dtype=F32, device=dev)
         nb_ = C.c_int(0)
@@ -258,7 +276,12 @@ class _FFDNetTrainer:
         for l in range(self.nb - 1, -1, -1):
             a_in = eng.in_c8 if l == 0 else self.acts[l - 1]
             ci_r, co_r = self._real(l)
-            if self.wino and _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
+            if self.wino4 and self.cin[l] % 32 == 0 and self.cout[l] % 32 == 0 and \
+                    _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
+                _lib.check(self.lib.scipnp_conv3x3_wgrad_wino4(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws),
+                                                               _wino4_slabs(self.cin[l], self.cout[l]), B, ci_r, co_r,
+                                                               self.cin[l], self.cout[l], M, N, _s()), 'wgrad wino4')
+            elif self.wino and _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
                 _lib.check(self.lib.scipnp_conv3x3_wgrad_wino(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws),
                                                               _wino_slabs(self.cin[l]), B, ci_r, co_r, self.cin[l],
                                                               self.cout[l], M, N, _s()), 'wgrad wino')

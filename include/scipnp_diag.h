@@ -72,6 +72,13 @@ int scipnp_bench_mfma_dep(float* out, unsigned long long* cycles, int blocks, in
 int scipnp_bench_mfma_bank(float* out, unsigned long long* cycles, int blocks, int iters, int var, scipnp_stream_t s);
 int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s);
 
+/* csrc/wgrad_wino4.hip, laboratory instantiation: the F(4x4)-domain weight-gradient kernel of scipnp_conv3x3_wgrad_wino4 with its
+ * timing-only ablation switches -- dbg bits: 1 no MFMAs, 2 no raw loads / LDS stores of them, 4 no transform, 8 placement probe
+ * (every wave writes its HW_ID register to workspace[12 * workgroup + wave] and returns), 32 loads without the LDS stores,
+ * 64 LDS stores without the loads.  Results are meaningless unless dbg == 0.  Workspace: the product entry's size. */
+int scipnp_diag_conv3x3_wgrad_wino4(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
+                                    int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, int dbg, scipnp_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -817,6 +817,42 @@ def test_winograd_wgrad_vs_autograd(ops):
         assert torch.equal(dW, dW3)
 
 
+def test_winograd_f4_wgrad_vs_autograd(ops):
+    """the fp32 weight gradient in the Winograd F(4x4) domain (csrc/wgrad_wino4.hip: 36 positions, 32 x 32 channel blocks per
+    workgroup, 8 waves with producer / consumer roles) against PyTorch autograd in float64 and the F(2x2) form: full, head-like,
+    tail-like, wide and ragged shapes (heights / widths that are no multiples of 4, fewer tiles than one chunk, several images,
+    slab counts with and without the XCD placement, more slabs than chunks)"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(14)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    cases = ((2, 96, 96, 96, 96, 10, 37, 16), (2, 13, 96, 16, 96, 9, 5, 3), (3, 96, 12, 96, 16, 7, 33, 5),
+             (1, 64, 128, 64, 128, 16, 16, 8), (2, 32, 64, 32, 64, 2, 2, 1), (1, 128, 256, 128, 256, 6, 20, 4),
+             (4, 24, 40, 24, 40, 12, 18, 64), (1, 96, 96, 96, 96, 64, 96, 24), (2, 32, 32, 32, 32, 33, 70, 7))
+    for n, ci_r, co_r, ci, co, h, w, nslab in cases:
+        x = torch.relu(torch.randn(n, ci_r, h, w, generator=g))
+        wt = (torch.randn(co_r, ci_r, 3, 3, generator=g) * 0.05).double().requires_grad_()
+        dz = torch.randn(n, co_r, h, w, generator=g)
+        torch.nn.functional.conv2d(x.double(), wt, None, padding=1).backward(dz.double())
+        x8, dz8 = ops.to_c8(x.cuda()), ops.to_c8(dz.cuda())
+        ws = torch.full((lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(ci, co, nslab),), float('nan'), device='cuda')
+        dW = torch.full((co_r, ci_r, 3, 3), float('nan'), device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), p(dW), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, s), 'wgrad wino4')
+        err = rel_l2(dW.cpu().numpy(), wt.grad.numpy())
+        assert err < 1e-5, (n, ci_r, co_r, h, w, nslab, err)
+        ws2 = torch.empty(lib.scipnp_conv3x3_wgrad_wino_workspace_floats(ci, co, 16), device='cuda')
+        dW2 = torch.empty(co_r, ci_r, 3, 3, device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino(p(x8), p(dz8), p(dW2), p(ws2), 16, n, ci_r, co_r, ci, co, h, w, s), 'wgrad wino')
+        assert rel_l2(dW.cpu().numpy(), dW2.cpu().numpy()) < 1e-5
+        # deterministic: fixed-order slab reduction, no atomics
+        dW3 = torch.empty_like(dW)
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), p(dW3), p(ws), nslab, n, ci_r, co_r, ci, co, h, w, s), 'wgrad wino4')
+        assert torch.equal(dW, dW3)
+    assert lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), p(dW), p(ws), 0, n, ci_r, co_r, ci, co, h, w, s) != 0
+
+
 def test_split_wgrad_bgrad_backward_data_vs_autograd(ops):
     """the finetune's split-fp16 kernels: weight / bias gradients from c8s operands (transposing LDS reads, pre-scaled
     dZ) and the backward-data conv with the ReLU-mask epilogue, against PyTorch autograd in float64"""

@@ -46,6 +46,24 @@ for _ in range(5):
 us = sorted(ts)[2]
 print(f'fp32 Winograd wgrad 96->96 ({nsw} slabs): {us:.1f} us  {flop / us / 1e6:.1f} TFLOP/s algorithmic = {flop / us / 1e6 / 157.3:.2f} of the fp32 MFMA peak; '
       f'rel-L2 vs direct {float((dWw - dW).norm() / dW.norm()):.2e}')
+ns4 = int(os.environ.get('WW4_SLABS', 28))
+ws4 = torch.empty(lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(c, c, ns4), device='cuda')
+dW4 = torch.empty(c, c, 3, 3, device='cuda')
+f4 = lambda: _lib.check(lib.scipnp_conv3x3_wgrad_wino4(p(act), p(dz), p(dW4), p(ws4), ns4, n, c, c, c, c, h, w, _lib.stream_ptr()), 'wgrad wino4')  # noqa: E731
+for _ in range(3):
+    f4()
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f4()
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+us = sorted(ts)[2]
+print(f'fp32 Winograd F(4x4) wgrad 96->96 ({ns4} slabs): {us:.1f} us  {flop / us / 1e6:.1f} TFLOP/s algorithmic = {flop / us / 1e6 / 157.3:.2f} of the fp32 MFMA peak; '
+      f'rel-L2 vs direct {float((dW4 - dW).norm() / dW.norm()):.2e}')
 # fp64 reference on a small problem
 n2, c2, h2, w2 = 2, 40, 19, 23
 a = torch.randn(n2, c2, h2, w2, dtype=torch.float64, requires_grad=False)
