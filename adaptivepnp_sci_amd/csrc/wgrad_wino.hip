@@ -97,17 +97,22 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
             __syncthreads();                                    // the producers have filled the other buffer meanwhile
             cur ^= 1;
         }
-        // C[row = co_local][col = ci_local]: row = (r&3) + 8*(r>>2) + 4*lh, col = li
+        // C[row = co_local][col = ci_local]: row = 32 cb + (r&3) + 8*(r>>2) + 4*lh, col = li.  A running pointer (rows +1 +1 +1 +5,
+        // also across cb): the row offsets held at once would spill
+        {
+            float* out = slabs + (((size_t)blockIdx.x * 16 + p0) * coP + 4 * lh) * ciP + cib * 32 + li;
+            const size_t pos_stride = (size_t)coP * ciP - (size_t)(32 * COB) * ciP;      // the +5 behind a position's last row overshoots to row 32 COB
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float* slab = slabs + ((size_t)blockIdx.x * 16 + p0 + i) * coP * ciP;
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb)
+                for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    slab[(size_t)co * ciP + cib * 32 + li] = acc[i][cb][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        *out = acc[i][cb][r];
+                        out += ((r & 3) == 3 ? (size_t)5 * ciP : (size_t)ciP);
+                    }
+                out += pos_stride;
+            }
         }
         return;
     }
@@ -129,30 +134,29 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
         const bool ch_on = DZ ? (cg0 + cgl < CGout) : (cib * 4 + cgl < CGin);
         const int w_off = DZ ? (tl * Cfg::COP + VW * q) : (Cfg::M_FLOATS + tl * 32 + VW * q);
         constexpr int w_step = DZ ? WW_T * Cfg::COP : WW_T * 32;
-        // per-load byte offsets from the chunk origin (input: from the origin shifted by (-1, -1), carried by the descriptor's
-        // base) and the loads that fall off the image when the chunk is in the first / last tile row / chunk column
-        unsigned voff[NLD];
-        unsigned mT = 0, mB = 0, mL = 0, mR = 0;
-        {
-            const size_t chan = (size_t)(DZ ? (cg0 + cgl) : (cib * 4 + cgl)) * HW * 32 + 4 * ((q * VW) & 7);
-            const int ty_last = tiles_y - 1, cx_last = chunks_x - 1;
-            constexpr int sh = DZ ? 0 : -1;
+        // a load = (lane offset: channel pair + tile column) + (immediate: dx) + (scalar: chunk origin + row dy); the input's
+        // origin is shifted by (-1, -1) through the descriptor's base.  Loads that fall off the image (first / last tile row,
+        // first / last chunk column) get an out-of-range lane offset and return 0.
+        constexpr unsigned OOB = 0x80000000u;                      // >= num_records, and stays so with an immediate added
+        constexpr int sh = DZ ? 0 : -1;
+        constexpr int ROWS = DZ ? 2 : 4;                           // 2x2 tile / 4x4 patch
+        const unsigned lane_base = ch_on ? (unsigned)((size_t)(DZ ? (cg0 + cgl) : (cib * 4 + cgl)) * HW * 32 + 4 * ((q * VW) & 7) +
+                                                      2 * tl * 32) : OOB;
+        unsigned colL = 0, colR = 0, rowB = 0;                     // bit dx / dy: off the image in the first / last chunk column / row
+        constexpr unsigned rowT = DZ ? 0u : 1u;
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int dy = DZ ? (k >> 1) : (k >> 2), dx = (DZ ? (k & 1) : (k & 3)) + 2 * tl;
-                voff[k] = ch_on ? (unsigned)(chan + ((size_t)dy * W + dx) * 32) : 0xFFFFFFFFu;
-                if (dy + sh < 0) mT |= 1u << k;                                    // ty == 0
-                if (2 * ty_last + dy + sh >= H) mB |= 1u << k;                     // ty == ty_last
-                if (dx + sh < 0) mL |= 1u << k;                                    // cx == 0
-                if (2 * WW_T * cx_last + dx + sh >= W) mR |= 1u << k;              // cx == cx_last
-            }
+        for (int d = 0; d < ROWS; ++d) {
+            if (2 * tl + d + sh < 0) colL |= 1u << d;
+            if (2 * WW_T * (chunks_x - 1) + 2 * tl + d + sh >= W) colR |= 1u << d;
+            if (2 * (tiles_y - 1) + d + sh >= H) rowB |= 1u << d;
         }
         // the bytes in front of the input tensor are only ever addressed by loads of the first tile row / chunk column of
         // image 0, which are masked (offset out of range)
         const auto rs = DZ ? __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, dz_bytes, 0x00020000)
                            : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)act - ((size_t)W + 1) * 32), 0,
                                                                act_bytes + (unsigned)((W + 1) * 32), 0x00020000);
-        vec_t raw[NLD];
+        vec_t raw[NLD];                                            // (a second set, requested two chunks ahead, changes nothing:
+                                                                   //  446 against 441 us -- the loads' latency is not what the kernel waits for)
         auto load1 = [&](unsigned vo, unsigned so) {
             return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0));
         };
@@ -171,22 +175,30 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
             if (w_ty >= tiles_y) { w_ty -= tiles_y; ++w_n; }
             w_n += d_n;
         };
-        auto fetch = [&]() {                                       // the walker's chunk (clamped: past the end, the last one again)
+        auto fetch = [&](vec_t* raw) {                             // the walker's chunk (clamped: past the end, the last one again)
             const int cx = w_cx, ty = w_ty, n = w_n;
             const bool edge = ty == 0 || ty == tiles_y - 1 || cx == 0 || cx == chunks_x - 1;        // wave-uniform
-            const long long so = (long long)n * (DZ ? CGout : CGin) * (long long)HW * 32 +
-                                 ((long long)2 * ty * W + (long long)2 * WW_T * cx) * 32;
+            const unsigned so = (unsigned)((long long)n * (DZ ? CGout : CGin) * (long long)HW * 32 +
+                                           ((long long)2 * ty * W + (long long)2 * WW_T * cx) * 32);
             if (edge) {
-                const unsigned m = (ty == 0 ? mT : 0u) | (ty == tiles_y - 1 ? mB : 0u) | (cx == 0 ? mL : 0u) |
-                                   (cx == chunks_x - 1 ? mR : 0u);
+                const unsigned rows = (ty == 0 ? rowT : 0u) | (ty == tiles_y - 1 ? rowB : 0u);          // scalar
+                const unsigned cols = (cx == 0 ? colL : 0u) | (cx == chunks_x - 1 ? colR : 0u);         // per lane
 #pragma unroll
-                for (int k = 0; k < NLD; ++k) raw[k] = load1(((m >> k) & 1u) ? 0xFFFFFFFFu : voff[k], (unsigned)so);
+                for (int dy = 0; dy < ROWS; ++dy) {
+                    const unsigned row_base = ((rows >> dy) & 1u) ? OOB : lane_base;
+#pragma unroll
+                    for (int dx = 0; dx < ROWS; ++dx)
+                        raw[dy * ROWS + dx] = load1((((cols >> dx) & 1u) ? OOB : row_base) + dx * 32, so + (unsigned)(dy * W * 32));
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < NLD; ++k) raw[k] = load1(voff[k], (unsigned)so);
+                for (int dy = 0; dy < ROWS; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < ROWS; ++dx)
+                        raw[dy * ROWS + dx] = load1(lane_base + dx * 32, so + (unsigned)(dy * W * 32));
             }
         };
-        auto transform_store = [&](float* buf) {
+        auto transform_store = [&](float* buf, const vec_t* raw) {
             float* dst = buf + w_off;
             if constexpr (DZ) {     // A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
                 vec_t rr[4][2];
@@ -220,18 +232,18 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ act, const float* __restrict
             }
         };
         if (first >= chunks) return;
-        fetch();                                                   // chunk `first`
-        transform_store(smem_ww);
+        fetch(raw);                                                // chunk `first`
+        transform_store(smem_ww, raw);
         if (w_chunk + step < chunks) advance();                    // (past the end the last chunk is fetched again: no branch
-        fetch();                                                   //  around loads, nothing selected behind them)
+        fetch(raw);                                                //  around loads, nothing selected behind them)
         __syncthreads();
         int cur = 0;
         for (int chunk = first; chunk < chunks; chunk += step) {
             // chunk + step goes to the other buffer (last read by the consumers before the previous barrier) while they
             // multiply `chunk`; its raw values were requested a whole chunk ago
-            transform_store(smem_ww + (cur ^ 1) * Cfg::BUF_FLOATS);
+            transform_store(smem_ww + (cur ^ 1) * Cfg::BUF_FLOATS, raw);
             if (w_chunk + step < chunks) advance();
-            fetch();
+            fetch(raw);
             __syncthreads();
             cur ^= 1;
         }
