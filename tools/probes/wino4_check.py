@@ -35,8 +35,10 @@ for name, n, cin, cout, h, w in (('FFDNet body', 8, 96, 96, 256, 256), ('FastDVD
     p4, p2 = ops.pack_conv3x3_wino4(pk, cin, cout), ops.pack_conv3x3_wino(pk, cin, cout)
     o4 = torch.empty(n, cout // 8, h, w, 8, device='cuda')
     o2 = torch.empty_like(o4)
+    od = torch.empty_like(o4)
     variants = {'F(2x2)': lambda: ops.conv3x3_c8w(x8, p2, cout, relu=True, out=o2),
-                'F(4x4)': lambda: ops.conv3x3_c8w4(x8, p4, cout, relu=True, out=o4)}
+                'F(4x4)': lambda: ops.conv3x3_c8w4(x8, p4, cout, relu=True, out=o4),
+                'direct': lambda: ops.conv3x3_c8(x8, pk, cout, relu=True, out=od)}
     for f in variants.values():
         for _ in range(3):
             f()
@@ -53,6 +55,8 @@ for name, n, cin, cout, h, w in (('FFDNet body', 8, 96, 96, 256, 256), ('FastDVD
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 20 * 1e3)
         us = sorted(ts)[2]
-        mf = (36 if k == 'F(4x4)' else 64) / 16.0 * 2 * cin * ((cout + 31) // 32 * 32) * h * w * n / 4 * (1 if k == 'F(4x4)' else 1)
+        mf = (36 if k == 'F(4x4)' else 64 if k == 'F(2x2)' else 576) / 16.0 * 2 * cin * ((cout + 31) // 32 * 32) * h * w * n / 4
         out.append(f'{k} {us:7.1f} us (matrix-pipe duty {mf / us / 1e6 / 157.3:4.2f})')
+    out.append(f'tensors {4e-6 * n * h * w * (cin + cout):.0f} MB = {4e-6 * n * h * w * (cin + cout) / us:.2f} TB/s at the fastest' if False else
+               f'in + out {4e-6 * n * h * w * (cin + cout):.0f} MB')
     print('   '.join(out), flush=True)
