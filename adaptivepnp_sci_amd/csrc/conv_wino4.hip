@@ -328,6 +328,14 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             const bool ok = (u < W4_UNITS) & (sl - 17 * g17 != 16) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
             const unsigned off = (unsigned)((gy * W + gx) * 32 + 16 * hf);
             in_off[k] = ok ? off : 0xFFFFFF00u;
+            if constexpr ((DIAG & 256) != 0) {
+                // timing only (WRONG results): every piece = both halves of 32 consecutive pixels of a row, 1 KB contiguous (8
+                // cache lines instead of 16) -- what a request costs as a function of the lines it touches
+                const int row = pc >> 1, px = (pc & 1) * 32 + (lane >> 1);
+                const int gy2 = y0 - 1 + (row < W4_THP ? row : 0), gx2 = x0 - 1 + px;
+                const bool ok2 = ((unsigned)gy2 < (unsigned)H) & ((unsigned)gx2 < (unsigned)W);
+                in_off[k] = ok2 ? (unsigned)((gy2 * W + gx2) * 32 + 16 * (lane & 1)) : 0xFFFFFF00u;
+            }
         }
         in_g = a.in + (size_t)n * a.CGin * HW * 8;
         issue_raw(raw_lds, a.CGin <= 1);
@@ -335,6 +343,11 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     };
 
     f32x4 acc[3][6][2];                                 // [own row xi - 3 xh][nu][co half]; zeroed behind the first requests
+    // DIAG bit 7 (timing only, WRONG results): the same accumulator registers as nine 32x32 blocks, multiplied by
+    // v_mfma_f32_32x32x2_f32 -- half as many matrix instructions of twice the length, half the U operands
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc16[3][3];
+    (void)acc16;
 
     // per-lane LDS offsets (floats): patch of tile (tg, tn), channel pair q (half-pixel plane q >> 1, 8 bytes (q & 1) of the
     // unit); U vectors of half xh
@@ -373,6 +386,18 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         auto op = [&](auto Q, auto I) { ops(Q, I); };
         using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
         using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+        if constexpr ((DIAG & 128) != 0) {
+            f32x16& a16 = acc16[pos % 3][pos / 3 % 3];
+            a16 = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0], b0, a16, 0, 0, 0);
+            dma(P);
+            op(P, C0{}); op(P, C1{});
+            a16 = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2], b1, a16, 0, 0, 0);
+            op(P, C2{}); op(P, C3{});
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            return;
+        }
         if (!(DIAG & 16)) ac[2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b0, ac[2 * np][0], 0, 0, 0);
         dma(P);                                            // (this vector's share of the k-step's LDS-DMA requests)
         if constexpr (W4_VBLK == 1) op(P, C0{});
@@ -443,6 +468,14 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                 for (int nu = 0; nu < 6; ++nu)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) acc[x][nu][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr ((DIAG & 128) != 0) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc16[x][y][r] = 0.f;
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -547,6 +580,14 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         if (xh == 0) k_loop(std::true_type{}, stores_behind);
         else k_loop(std::false_type{}, stores_behind);
         W4_STAMP(3);
+        if constexpr ((DIAG & 128) != 0) {                  // (keeps the blocks alive into the output transform)
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][2 * y + (r >> 3)][(r >> 2) & 1][r & 3] = acc16[x][y][r];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetched last slab must not land in the exchange buffer)
         __syncthreads();
 
@@ -923,7 +964,8 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
 
 /* diagnostic: the same kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
  * diag: bit0 no input transform, bit1 no raw-tile staging, bit2 no U LDS-DMA, bit3 no barriers in the K loop, bit4 no MFMAs,
- * bit5 no output transform / stores */
+ * bit5 no output transform / stores, bit7 the matrix work as v_mfma_f32_32x32x2_f32 on the same registers (half the instructions,
+ * twice their length, half the U operands), bit8 every raw-tile request fetches 1 KB of contiguous memory */
 int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && packed_wino4 && out, "null pointer");
@@ -951,6 +993,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
         W4_DIAG_CASE(1) W4_DIAG_CASE(2) W4_DIAG_CASE(4) W4_DIAG_CASE(8) W4_DIAG_CASE(16) W4_DIAG_CASE(32) W4_DIAG_CASE(6)
         W4_DIAG_CASE(7) W4_DIAG_CASE(15) W4_DIAG_CASE(39) W4_DIAG_CASE(47) W4_DIAG_CASE(48) W4_DIAG_CASE(49) W4_DIAG_CASE(55)
         W4_DIAG_CASE(63) W4_DIAG_CASE(3) W4_DIAG_CASE(5) W4_DIAG_CASE(9) W4_DIAG_CASE(10) W4_DIAG_CASE(12) W4_DIAG_CASE(14)
+        W4_DIAG_CASE(128) W4_DIAG_CASE(256)
         default: SCIPNP_REQUIRE(false, "diag mask %d has no instantiation", diag);
     }
 #undef W4_DIAG_CASE

@@ -15,7 +15,8 @@ pk = ops.pack_conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.randn(c
 p4, p2 = ops.pack_conv3x3_wino4(pk, c, c), ops.pack_conv3x3_wino(pk, c, c)
 out = torch.empty_like(x8)
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-NAMES = {1: 'no transform', 2: 'no raw staging', 4: 'no U LDS-DMA', 8: 'no barriers', 16: 'no MFMAs', 32: 'no epilogue'}
+NAMES = {1: 'no transform', 2: 'no raw staging', 4: 'no U LDS-DMA', 8: 'no barriers', 16: 'no MFMAs', 32: 'no epilogue',
+         128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory'}
 
 
 def run(diag):
@@ -39,6 +40,8 @@ def timed(fn, reps=5, inner=20):
 
 print(f'F(2x2) kernel               {timed(lambda: ops.conv3x3_c8w(x8, p2, c, relu=True, out=out)):7.1f} us')
 print(f'F(4x4) kernel (product)     {timed(lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=out)):7.1f} us')
-for d in (1, 2, 4, 8, 16, 32, 3, 5, 9, 10, 12, 14, 6, 7, 15, 39, 47, 48, 49, 55, 63):
+MASKS = [int(v) for v in os.environ['W4_MASKS'].split(',')] if os.environ.get('W4_MASKS') else \
+    (1, 2, 4, 8, 16, 32, 3, 5, 9, 10, 12, 14, 6, 7, 15, 39, 47, 48, 49, 55, 63, 128)
+for d in MASKS:
     name = ' + '.join(NAMES[b] for b in NAMES if d & b)
     print(f'diag {d:2d}: {timed(lambda: run(d)):7.1f} us   {name}', flush=True)
