@@ -61,10 +61,13 @@ def _wino4_slabs(cin, cout):
 
 
 def wgrad_f4_enabled():
-    """SCIPNP_F32_WGRAD=f4: the fp32 FFDNet trainer takes the weight gradients of its 32-multiple layers in the Winograd
-    F(4x4) domain (396 us against 439 us at 96 -> 96 on 8 x 256 x 256, rounding 7e-6 against 1.5e-6 of the gradient's norm:
-    DESIGN.md section 5); default: the F(2x2) form"""
-    return os.environ.get('SCIPNP_F32_WGRAD', 'f2').lower() == 'f4'
+    """the fp32 FFDNet trainer takes the weight gradients of its 32-multiple layers in the Winograd F(4x4) domain
+    (csrc/wgrad_wino4.hip: 382 us against 441 us of the F(2x2) form at 96 -> 96 on 8 x 256 x 256, rounding 4.9e-6 against
+    1.5e-6 of the gradient's norm, gate 1e-4: DESIGN.md section 5); SCIPNP_F32_WGRAD=f2 keeps the F(2x2) form"""
+    v = os.environ.get('SCIPNP_F32_WGRAD', 'f4').lower()
+    if v not in ('f2', 'f4'):
+        raise ValueError("SCIPNP_F32_WGRAD must be 'f2' or 'f4'")
+    return v == 'f4'
 
 
 def _wino_wgrad_fits(n, cin, cout, h, w):

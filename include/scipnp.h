@@ -323,7 +323,7 @@ int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW
  * (2.25 per output instead of 4 / 9), transforms with factors up to 8: rel-L2 ~3e-6 against float64 where the F(2x2) form gives
  * ~5e-7 (tests/test_gpu_ops.py gates 1e-5).  One slab = 36 positions x roundup(Cout, 32) x roundup(Cin, 32) floats; nslab x
  * (Cout/32 x Cin/32 blocks) persistent workgroups, one per CU (nslab ~ 255 / blocks), whole slabs placed on one XCD.  382 us
- * against 441 us of the F(2x2) form at 96 -> 96 on 8 x 256 x 256; the fp32 FFDNet trainer uses it with SCIPNP_F32_WGRAD=f4. */
+ * against 441 us of the F(2x2) form at 96 -> 96 on 8 x 256 x 256; the fp32 FFDNet trainer uses it unless SCIPNP_F32_WGRAD=f2. */
 size_t scipnp_conv3x3_wgrad_wino4_workspace_floats(int Cin, int Cout, int nslab);
 int scipnp_conv3x3_wgrad_wino4(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
                                int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s);

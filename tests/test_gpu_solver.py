@@ -180,11 +180,15 @@ def test_two_stage_fastdvdnet_iterates(solver, precision, monkeypatch):
     assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL
 
 
-@pytest.mark.parametrize('precision', ['f32', 'f16x3', 'f32+wgrad-f4'])
+@pytest.mark.parametrize('precision', ['f32', 'f16x3', 'f32+wgrad-f2'])
 def test_ffdnet_online_finetune_matches_reference(solver, ffdnet_state_dict, precision, monkeypatch):
-    # fp32 MFMA vs error-compensated split-fp16 MFMA vs fp32 with the weight gradients in the F(4x4) domain (csrc/wgrad_wino4.hip)
+    # fp32 MFMA (weight gradients in the F(4x4) domain, csrc/wgrad_wino4.hip: the default) vs error-compensated split-fp16 MFMA vs
+    # fp32 with the weight gradients in the F(2x2) domain (csrc/wgrad_wino.hip)
     monkeypatch.setenv('SCIPNP_FFDNET_PRECISION', precision.split('+')[0])
-    monkeypatch.setenv('SCIPNP_F32_WGRAD', 'f4' if precision.endswith('wgrad-f4') else 'f2')
+    if precision.endswith('wgrad-f2'):
+        monkeypatch.setenv('SCIPNP_F32_WGRAD', 'f2')
+    else:
+        monkeypatch.delenv('SCIPNP_F32_WGRAD', raising=False)
     """update_=True, lr 2e-6, update_per_iter 2 (the reference driver's values), gate at k = 2: hand-written
     backward (loss grad, backward-data convs, MFMA weight gradients, Adam) vs the reference's autograd run."""
     from adaptivepnp_sci_amd import finetune
