@@ -118,6 +118,11 @@ def _carve(flat, like):
 
 def _repack_wino(packed_f32, wp):
     """Winograd-domain weights of a trainer layer (ops.WinoPacked with preallocated buffers) from its fp32 direct packing"""
+    if wp.f4 is not None and ops.wino_f4_enabled():
+        # ops.conv3x3_c8w runs such a layer on the F(4x4) kernel: its F(2x2) packing would never be read (the trainers' launches
+        # only; the engine re-derives both forms when it adopts the updated weights)
+        ops.pack_conv3x3_wino4(packed_f32, wp.cin, wp.cout, out=wp.f4)
+        return
     ops.pack_conv3x3_wino(packed_f32, wp.cin, wp.cout, out=wp.w)
     if wp.f4 is not None:
         ops.pack_conv3x3_wino4(packed_f32, wp.cin, wp.cout, out=wp.f4)
