@@ -120,6 +120,7 @@ SIGNATURES = {
     'scipnp_conv3x3_wino4_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino4': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w4': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w6': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_negate': (_int, [_vp, _vp, _sz, _vp]),
     'scipnp_fastdvd_noisy_input': (_int, [_vp, _vp, _vp, _sz, _vp]),
     'scipnp_sum_rows_f64': (_int, [_vp, _vp, _int, _int, _vp]),

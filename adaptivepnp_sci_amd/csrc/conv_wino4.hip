@@ -33,181 +33,13 @@
 //     k-step ahead.
 // One barrier per k-step (36 MFMAs per wave): a whole group's slab pair double-buffered (74 KiB) plus the tiles would not leave
 // room for two workgroups per CU.
-#include "common.hpp"
+#include "wino4_common.hpp"
 #ifdef SCIPNP_DIAG_BUILD
 #include "../../include/scipnp_diag.h"
 #endif
-#include <cstdlib>
-#include <type_traits>
-#include <utility>
 
 namespace scipnp {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int W4_SLAB = 2 * 9 * 64 * 4;               // floats per k-step slab (18432 B)
-constexpr int W4_PIECES = W4_SLAB / 256;              // 1 KiB LDS-DMA pieces per slab (18)
-constexpr int W4_TW = 64, W4_TH = 8;                  // output pixels per workgroup
-constexpr int W4_TWP = W4_TW + 2, W4_THP = W4_TH + 2; // halo tile
-constexpr int W4_THREADS = 256;
-constexpr int W4_RSL = W4_TWP + W4_TWP / 16;          // slots per halo row: pixel x sits in slot x + (x >> 4) (one padding slot per 16)
-constexpr int W4_UNITS = W4_THP * W4_RSL * 2;         // 16-byte units (4 channels of a pixel) of the halo tile: [hf][row][slot]
-constexpr int W4_RAW_PIECES = (W4_UNITS + 63) / 64;   // 1 KiB LDS-DMA pieces per raw tile (21; the last one partly padding)
-constexpr int W4_RAW = W4_RAW_PIECES * 256;           // floats per raw buffer
-constexpr int W4_IN_ITERS = (W4_RAW_PIECES + 3) / 4;  // raw pieces per wave and group (waves 1..3 fetch their fifth piece twice)
-constexpr int W4_DMA_ITERS = (W4_PIECES + 3) / 4;     // U pieces per wave and slab (waves 2, 3 fetch their fourth piece twice)
-constexpr size_t W4_LDS_BYTES = (2 * (size_t)W4_RAW + 2 * (size_t)W4_SLAB) * sizeof(float);
-static_assert(W4_LDS_BYTES >= 4 * 16 * 64 * 16, "the epilogue's exchange buffer lives in the loop's LDS");
-static_assert(2 * W4_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-
-struct Wino4Args {
-    const float* in;
-    const float* wpk;        // [2*CGin k-steps][CoutP/32][4608] + bias[CoutP]
-    float* out;
-    const float* residual;
-    const float* mask_src;
-    int CGin, CGout, NCB;    // NCB = CoutP / 32
-    int H, W;
-    int ntx, nty;
-    unsigned m_ncb, m_ntx, m_nty;   // floor(2^32 / d) of the three divisors of the block index (w4_div below), set by w4_geometry
-    unsigned total_units;           // (tile, output-channel block) units of the launch; the grid of the classic form, walked by the persistent one
-    int flags;
-    unsigned long long* dbg; // STAMP instantiation (DIAG bit6) only: 128 words per workgroup, see scipnp_conv3x3_c8w4_stamped
-};
-
-// (host pass: only parsed -- the kernel body never runs there)
-__host__ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    return a * b + c;
-#endif
-}
-__host__ __device__ __forceinline__ f32x4 pk_fma(f32x4 a, f32x4 b, f32x4 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    return a * b + c;
-#endif
-}
-// a - b on a float2 as ONE v_pk_add_f32 (see conv_wino.hip: the compiler selects two v_sub_f32)
-__host__ __device__ __forceinline__ f32x2 psub4(f32x2 a, f32x2 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a - b;
-#endif
-}
-// c * x + y on a float2 as ONE v_pk_fma_f32, c an inline constant (the compiler scalarises a <2 x float> fma whose result is
-// only ever read element by element -- the MFMA operands -- into two v_fma_f32, and every vector instruction is matrix time)
-#define W4_PK_FMA_CONST(NAME, LIT)                                                                     \
-    __host__ __device__ __forceinline__ f32x2 NAME(f32x2 x, f32x2 y) {                                 \
-        f32x2 r = x * (float)(LIT) + y;                                                                \
-        W4_DEVICE_ASM("v_pk_fma_f32 %0, %1, " #LIT ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y)); \
-        return r;                                                                                      \
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-#define W4_DEVICE_ASM(...) asm(__VA_ARGS__)
-#else
-#define W4_DEVICE_ASM(...) (void)0
-#endif
-W4_PK_FMA_CONST(fma_p4, 4.0)
-W4_PK_FMA_CONST(fma_m4, -4.0)
-W4_PK_FMA_CONST(fma_p2, 2.0)
-W4_PK_FMA_CONST(fma_m2, -2.0)
-// k * x + y with k (both halves the same value) in a scalar register pair: -5 is not an inline constant
-__host__ __device__ __forceinline__ f32x2 fma_k(f32x2 x, f32x2 y, f32x2 k) {
-    f32x2 r = x * k + y;
-    W4_DEVICE_ASM("v_pk_fma_f32 %0, %1, %3, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y), "s"(k));
-    return r;
-}
-__host__ __device__ __forceinline__ f32x2 padd(f32x2 a, f32x2 b) {
-    f32x2 r = a + b;
-    W4_DEVICE_ASM("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// a - b on a float4 as two v_pk_add_f32
-__host__ __device__ __forceinline__ f32x4 psub4(f32x4 a, f32x4 b) {
-    const f32x2 lo = psub4(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = psub4(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
-template <typename T>
-__host__ __device__ __forceinline__ T splat(float v);
-template <>
-__host__ __device__ __forceinline__ f32x2 splat<f32x2>(float v) { return f32x2{v, v}; }
-template <>
-__host__ __device__ __forceinline__ f32x4 splat<f32x4>(float v) { return f32x4{v, v, v, v}; }
-
-// one clock stamp of wave 0, written with a SCALAR store (no vmcnt traffic: the K loop's waits count vector memory operations)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define W4_STAMP(slot)                                                                                              \
-    do {                                                                                                            \
-        if constexpr ((DIAG & 64) != 0) {                                                                           \
-            if (wvu == 0) {                                                                                         \
-                unsigned long long t_;                                                                              \
-                const unsigned long long* p_ = stamp_base + (slot);                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                  \
-                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t_) : "s"(p_) : "memory"); \
-                __builtin_amdgcn_sched_barrier(0);                                                                  \
-            }                                                                                                       \
-        }                                                                                                           \
-    } while (0)
-#else
-#define W4_STAMP(slot) (void)0
-#endif
-
-template <int... I, typename F>
-__host__ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__host__ __device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-// ONE packed operation (K = 0..5) of half a 1-D input transform: LO: rows 0..2 of B^T x from (x0..x4) = i0..i4; else rows 3..5
-// from (x1..x5) = i0..i4.  ta, tb carry the two intermediates between the operations of one half.
-template <bool LO, int K>
-__host__ __device__ __forceinline__ void half_op(const f32x2 i0, const f32x2 i1, const f32x2 i2, const f32x2 i3, const f32x2 i4,
-                                                 f32x2& o0, f32x2& o1, f32x2& o2, f32x2& ta, f32x2& tb, const f32x2 m5) {
-    if constexpr (LO) {                 // 4x0 - 5x2 + x4 | (x4 - 4x2) + (x3 - 4x1) | (x4 - 4x2) - (x3 - 4x1)
-        if constexpr (K == 0) ta = fma_k(i2, i4, m5);
-        if constexpr (K == 1) o0 = fma_p4(i0, ta);
-        if constexpr (K == 2) ta = fma_m4(i2, i4);
-        if constexpr (K == 3) tb = fma_m4(i1, i3);
-        if constexpr (K == 4) o1 = padd(ta, tb);
-        if constexpr (K == 5) o2 = psub4(ta, tb);
-    } else {                            // (x4 - x2) + 2(x3 - x1) | (x4 - x2) - 2(x3 - x1) | 4x1 - 5x3 + x5
-        if constexpr (K == 0) ta = psub4(i3, i1);
-        if constexpr (K == 1) tb = psub4(i2, i0);
-        if constexpr (K == 2) o0 = fma_p2(tb, ta);
-        if constexpr (K == 3) o1 = fma_m2(tb, ta);
-        if constexpr (K == 4) ta = fma_k(i2, i4, m5);
-        if constexpr (K == 5) o2 = fma_p4(i0, ta);
-    }
-}
-
-// x / d and x % d by a host-made reciprocal m = floor(2^32 / d) (0xFFFFFFFF for d = 1): q = mulhi(x, m) is the quotient or one
-// short of it, one correction makes it exact for every 32-bit x -- six scalar instructions where the compiler's division by a
-// run-time value takes some thirty-five (three of them open every workgroup's life)
-__host__ __device__ __forceinline__ unsigned w4_div(unsigned x, unsigned d, unsigned m, unsigned& rem) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned q = __umulhi(x, m);
-#else
-    unsigned q = (unsigned)(((unsigned long long)x * m) >> 32);
-#endif
-    unsigned r = x - q * d;
-    if (r >= d) { ++q; r -= d; }
-    rem = r;
-    return q;
-}
-static inline unsigned w4_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)d); }
 
 // DIAG (timing experiments only, wrong results): bit0 no transform, 1 no raw staging, 2 no U DMA, 3 no barriers, 4 no MFMAs, 5 no epilogue
 // PERSIST (round 4 experiment, NOT instantiated by the library): a grid of two workgroups per CU, each walking the units
@@ -220,7 +52,10 @@ static inline unsigned w4_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned
 // own vmcnt(0) in front of a spill at the head of the K loop waits for every request in flight), and the two workgroups of a CU
 // run in phase.  Same wall as round 3's persistent form; the classic form (one unit per workgroup: the loop below runs once) is
 // the product.
-template <int TAG, int DIAG = 0, bool SHUF = false, bool PERSIST = false>
+// LINES (round 5, the product's plain-store epilogue): the partial tiles of both waves of a tile row go through LDS as a tile IMAGE
+// and leave in whole 128-byte lines -- the per-lane stores of the classic epilogue (LINES = false) touch 64 lines with 16 bytes
+// each per instruction and cost the layer 15 us (profiles/r05b_wino4_store_ablate.txt).
+template <int TAG, int DIAG = 0, bool SHUF = false, bool PERSIST = false, bool LINES = (!SHUF && !PERSIST)>
 __global__ void __launch_bounds__(W4_THREADS, 2)
 conv3x3_c8w4_kernel(const Wino4Args a) {
     static_assert(!(PERSIST && SHUF), "the PixelShuffle epilogue assembles its tile in LDS: no requests may be in flight there");
@@ -595,6 +430,99 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         // wave xh finishes the output rows 2xh, 2xh+1 and hands the other two to its partner through LDS.
         // lane: tile (tg, tn), channels 32*split + 16*h + 4*q + r.
         if (DIAG & 32) return;
+        if constexpr (LINES) {
+            // image [xh 2][grp 2][row 8][tile 16][36 floats: 4 pixels x 8 channels + 4 of padding (conflict-free 16-byte writes)]: per
+            // output-channel half h one round -- every wave writes its partial tile P[0..3][j] (all four output rows), then thread
+            // (unit = (grp, row, tile), chunk c of 8) adds the two waves' partials, bias, residual / ReLU / mask, and stores 16 bytes:
+            // eight consecutive lanes cover one 128-byte line = 4 pixels x 8 channels, a store instruction eight whole lines.
+            // (keep + other) of the classic epilogue is LO + HI for the rows 0, 1 and HI + LO for 2, 3: the same sums.
+            constexpr int TILE_F = 36, IMG_F = 2 * 8 * 16 * TILE_F;
+            static_assert((size_t)2 * IMG_F * 4 <= W4_LDS_BYTES, "two images in the loop's LDS");
+            float* const img = smem_w4;
+            const float* bias = a.wpk + (size_t)2 * a.CGin * w_step;
+            const bool relu = a.flags & 1, add_res = (a.flags & 2) && a.residual, mask = (a.flags & 16) && a.mask_src;
+            (void)relu; (void)add_res; (void)mask; (void)bias;
+            bool wrote = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cog0 = split * 4 + h * 2;
+                if (cog0 >= a.CGout) continue;                       // workgroup-uniform
+                if (wrote) __syncthreads();                          // the previous round's reads are done
+                wrote = true;
+                f32x4 R[3][4];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const f32x4 m0 = acc[x][0][h], m1 = acc[x][1][h], m2 = acc[x][2][h], m3 = acc[x][3][h], m4 = acc[x][4][h], m5 = acc[x][5][h];
+                    const f32x4 s1 = m1 + m2, d1 = psub4(m1, m2), s2 = m3 + m4, d2 = psub4(m3, m4);
+                    R[x][0] = (m0 + s1) + s2;
+                    R[x][1] = pk_fma(splat<f32x4>(2.f), d2, d1);
+                    R[x][2] = pk_fma(splat<f32x4>(4.f), s2, s1);
+                    R[x][3] = pk_fma(splat<f32x4>(8.f), d2, d1) + m5;
+                }
+                float* const dst = img + xh * IMG_F + (((q >> 1) * 8 + 4 * tg) * 16 + tn) * TILE_F + 4 * (q & 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 P[4];
+                    if (xh == 0) {
+                        const f32x4 s = R[1][j] + R[2][j], d = psub4(R[1][j], R[2][j]);
+                        P[0] = R[0][j] + s; P[1] = d; P[2] = s; P[3] = d;
+                    } else {
+                        const f32x4 s = R[0][j] + R[1][j], d = psub4(R[0][j], R[1][j]);
+                        P[0] = s; P[1] = d * 2.f; P[2] = s * 4.f; P[3] = pk_fma(splat<f32x4>(8.f), d, R[2][j]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *(f32x4*)(dst + i * (16 * TILE_F) + j * 8) = P[i];
+                }
+                __syncthreads();
+                if (h == 0) W4_STAMP(4);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int gr = 0; gr < 2; ++gr) {
+                    const int cog = cog0 + gr;
+                    if (cog >= a.CGout) continue;                    // workgroup-uniform
+                    const int c = tid & 7;
+                    const f32x4 bs = *(const f32x4*)(bias + cog * 8 + 4 * (c & 1));
+                    const size_t plane = ((size_t)n * a.CGout + cog) * HW * 8;
+                    auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, plane_bytes, 0x00020000);
+                    f32x4 v[4];
+                    unsigned off[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int unit = (tid >> 3) + 32 * it, tile = unit & 15, row = unit >> 4;   // row 0..7
+                        const float* src = img + ((gr * 8 + row) * 16 + tile) * TILE_F + 4 * c;
+                        v[it] = (*(const f32x4*)src + *(const f32x4*)(src + IMG_F)) + bs;
+                        const int y = y0 + row, x = x0 + 4 * tile + (c >> 1);
+                        off[it] = (y < H && x < W) ? (unsigned)((y * W + x) * 32 + 16 * (c & 1)) : 0x80000000u;
+                    }
+                    if (add_res) {
+                        auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + plane), 0, plane_bytes, 0x00020000);
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+                            v[it] = v[it] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[it], 0, 0));
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+                    }
+                    if (mask) {
+                        auto r_m = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_src + plane), 0, plane_bytes, 0x00020000);
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const f32x4 fw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_m, off[it], 0, 0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[it][e] = (fw[e] > 0.f) ? v[it][e] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, 0);
+                }
+#endif
+            }
+            break;                                                   // (LINES excludes the persistent form: one unit per workgroup)
+        }
         float* const xbuf = smem_w4;                        // [wave 4][slot 16][lane 64][4]
         f32x4 keep[2][4][2];                                // [row 2xh + il][j][h]
     #pragma unroll
@@ -733,6 +661,8 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                     off[h][il][j] = (lane_ok && y < H && x < W)
                                         ? (unsigned)((y * W + x) * 32 + 16 * (q & 1)) + (unsigned)(q >> 1) * plane_bytes
                                         : 0x80000000u;
+                    if constexpr ((DIAG & 512) != 0)    // timing only (WRONG results): every store instruction writes 1 KB of contiguous memory
+                        off[h][il][j] = (unsigned)(((y0 + 4 * tg + 2 * xh + il) * W + x0) * 32 + j * 1024 + 16 * lane) % (2 * plane_bytes - 16);
                 }
 #if defined(__HIP_DEVICE_COMPILE__)
             const size_t half0 = ((size_t)n * a.CGout + cog0) * HW * 8;                            // floats
@@ -965,7 +895,7 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
 /* diagnostic: the same kernel with parts switched off (timing only, WRONG results) -- tools/probes/wino4_ablate.py.
  * diag: bit0 no input transform, bit1 no raw-tile staging, bit2 no U LDS-DMA, bit3 no barriers in the K loop, bit4 no MFMAs,
  * bit5 no output transform / stores, bit7 the matrix work as v_mfma_f32_32x32x2_f32 on the same registers (half the instructions,
- * twice their length, half the U operands), bit8 every raw-tile request fetches 1 KB of contiguous memory */
+ * twice their length, half the U operands), bit8 every raw-tile request fetches 1 KB of contiguous memory, bit9 every output store instruction writes 1 KB of contiguous memory */
 int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && packed_wino4 && out, "null pointer");
@@ -989,11 +919,17 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
         hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, D>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);                     \
         break;                                                                                                             \
     }
+    if (diag == 1024) {                                     // the classic per-lane store epilogue (LINES = false), results unchanged
+        static LdsAttrOnce attr;
+        if (int rc = attr.ensure((const void*)conv3x3_c8w4_kernel<0, 0, false, false, false>, W4_LDS_BYTES, "conv3x3_c8w4 classic stores")) return rc;
+        hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 0, false, false, false>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
+        return launch_status("conv3x3_c8w4_kernel<classic stores>");
+    }
     switch (diag) {
         W4_DIAG_CASE(1) W4_DIAG_CASE(2) W4_DIAG_CASE(4) W4_DIAG_CASE(8) W4_DIAG_CASE(16) W4_DIAG_CASE(32) W4_DIAG_CASE(6)
         W4_DIAG_CASE(7) W4_DIAG_CASE(15) W4_DIAG_CASE(39) W4_DIAG_CASE(47) W4_DIAG_CASE(48) W4_DIAG_CASE(49) W4_DIAG_CASE(55)
         W4_DIAG_CASE(63) W4_DIAG_CASE(3) W4_DIAG_CASE(5) W4_DIAG_CASE(9) W4_DIAG_CASE(10) W4_DIAG_CASE(12) W4_DIAG_CASE(14)
-        W4_DIAG_CASE(128) W4_DIAG_CASE(256)
+        W4_DIAG_CASE(128) W4_DIAG_CASE(256) W4_DIAG_CASE(512)
         default: SCIPNP_REQUIRE(false, "diag mask %d has no instantiation", diag);
     }
 #undef W4_DIAG_CASE

@@ -386,6 +386,19 @@ def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None
     return out
 
 
+def conv3x3_c8w6(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+    """conv3x3_c8w4's convolution on the three-waves-per-SIMD kernel (csrc/conv_wino4x.hip: 6-wave workgroups, the tile's 36
+    positions split over three waves): same packing, bit-identical results; no PixelShuffle store."""
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
+    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0))
+    _timed_call('conv3x3_c8w6_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w6', _p(x, 'x'),
+                _p(packed_wino4, 'packed_wino4'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
+                Cout, h, w, flags, _stream())
+    return out
+
+
 class WinoPacked:
     """Winograd-domain weights of one layer for conv3x3_c8w: `w` = the scipnp_pack_conv3x3_wino packing (every shape and
     epilogue), `f4` = the F(4x4,3x3) packing of scipnp_conv3x3_c8w4 for the layer shapes that kernel is used for, else None.

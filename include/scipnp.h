@@ -381,6 +381,14 @@ int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int 
 int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, const float* residual,
                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
+/* The same convolution with the 36 positions of a tile split over THREE waves (csrc/conv_wino4x.hip, round 5): 6-wave workgroups,
+ * 96 accumulator registers per wave, three waves per SIMD instead of two -- the same packed_wino4 buffer, the same products and
+ * summation orders, results BIT-IDENTICAL to scipnp_conv3x3_c8w4.  flags: bit0 ReLU, bit1 residual, bit4 ReLU-backward mask, bit8
+ * head-layer tag (no PixelShuffle store: bit3 is refused -- those layers stay on scipnp_conv3x3_c8w4).
+ * -- same nn.Conv2d(..., 3, 1, 1) call sites (network_ffdnet.py:54-69, models.py:16-253). */
+int scipnp_conv3x3_c8w6(const float* in, const float* packed_wino4, float* out, const float* residual,
+                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+
 /* The whole FFDNet-colour pass as ONE call with mixed Winograd forms: layer l runs on scipnp_conv3x3_c8w4 when
  * packed_wino4 != NULL and packed_wino4[l] != NULL (the 96 -> 96 body layers, packed by scipnp_pack_conv3x3_wino4), else on
  * scipnp_conv3x3_c8w with packed_wino[l]; other arguments as scipnp_ffdnet_forward_c8w. */

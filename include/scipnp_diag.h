@@ -27,6 +27,13 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
 int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s);
 
+/* the same two laboratory entries for the three-waves-per-SIMD form (csrc/conv_wino4x.hip, scipnp_conv3x3_c8w6): stamp slots as
+ * above (wave 0 = tile row 0, third A); stamped builds exist for the masks 0, 1, 6, 7 (flags bits 12..14) */
+int scipnp_conv3x3_c8w6_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                                int flags, unsigned long long* stamps, scipnp_stream_t s);
+int scipnp_conv3x3_c8w6_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                             int flags, int diag, scipnp_stream_t s);
+
 /* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
  * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
  * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of

@@ -23,6 +23,8 @@ SIGNATURES = {
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w6_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    'scipnp_conv3x3_c8w6_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
     'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),

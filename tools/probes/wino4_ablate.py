@@ -16,11 +16,15 @@ p4, p2 = ops.pack_conv3x3_wino4(pk, c, c), ops.pack_conv3x3_wino(pk, c, c)
 out = torch.empty_like(x8)
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 NAMES = {1: 'no transform', 2: 'no raw staging', 4: 'no U LDS-DMA', 8: 'no barriers', 16: 'no MFMAs', 32: 'no epilogue',
-         128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory'}
+         128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory', 512: 'output stores of 1 KB contiguous memory', 1024: 'classic per-lane store epilogue (correct results)'}
+
+
+KER = os.environ.get('W4_KERNEL', '4')     # '6': scipnp_conv3x3_c8w6_diag (masks 1, 2, 4, 8, 16, 6, 7, 15, 48, 49)
+diag_fn = lib.scipnp_conv3x3_c8w6_diag if KER == '6' else lib.scipnp_conv3x3_c8w4_diag
 
 
 def run(diag):
-    _lib.check(lib.scipnp_conv3x3_c8w4_diag(P(x8), P(p4), P(out), n, c, c, h, w, 1, diag, _lib.stream_ptr()), 'diag')
+    _lib.check(diag_fn(P(x8), P(p4), P(out), n, c, c, h, w, 1, diag, _lib.stream_ptr()), 'diag')
 
 
 def timed(fn, reps=5, inner=20):
@@ -40,6 +44,8 @@ def timed(fn, reps=5, inner=20):
 
 print(f'F(2x2) kernel               {timed(lambda: ops.conv3x3_c8w(x8, p2, c, relu=True, out=out)):7.1f} us')
 print(f'F(4x4) kernel (product)     {timed(lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=out)):7.1f} us')
+print(f'F(4x4) three waves per SIMD {timed(lambda: ops.conv3x3_c8w6(x8, p4, c, relu=True, out=out)):7.1f} us')
+print('ablations of scipnp_conv3x3_c8w' + KER)
 MASKS = [int(v) for v in os.environ['W4_MASKS'].split(',')] if os.environ.get('W4_MASKS') else \
     (1, 2, 4, 8, 16, 32, 3, 5, 9, 10, 12, 14, 6, 7, 15, 39, 47, 48, 49, 55, 63, 128)
 for d in MASKS:
