@@ -92,6 +92,8 @@ SIGNATURES = {
     'scipnp_c8_scale_to_c8s': (_int, [_vp, _vp, _flt, _int, _int, _int, _int, _vp]),
     'scipnp_fastdvd_pack_triplets_c8s': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_pack_triplets': (_int, [_vp, _vp, _int, _int, _int, _flt, _vp]),
+    'scipnp_fastdvd_pack_triplets_units': (_int, [_vp, _vp, _int, _int, _int, _int, _flt, _vp]),
+    'scipnp_fastdvd_pack_triplets_c8s_units': (_int, [_vp, _vp, _int, _int, _int, _int, _flt, _vp]),
     'scipnp_fastdvd_finish': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     'scipnp_frame_metrics': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, C.c_double, C.POINTER(_int), _vp]),
     'scipnp_pm_pre_rgb': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _flt, _flt, _vp]),
@@ -120,7 +122,6 @@ SIGNATURES = {
     'scipnp_conv3x3_wino4_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_wino4': (_int, [_vp, _vp, _int, _int, _vp]),
     'scipnp_conv3x3_c8w4': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8w6': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_negate': (_int, [_vp, _vp, _sz, _vp]),
     'scipnp_fastdvd_noisy_input': (_int, [_vp, _vp, _vp, _sz, _vp]),
     'scipnp_sum_rows_f64': (_int, [_vp, _vp, _int, _int, _vp]),

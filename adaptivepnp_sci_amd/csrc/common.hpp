@@ -259,7 +259,7 @@ __device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc,
 // of the candidate form itself (cd != nullptr; weight / eps of the TV step as doubles)
 int pm_dual_update_sel(const float* theta_raw, const int32_t* sel, const float* x, float* theta, float* b, const float* orig,
                        double* sse_part, int which, float sign, int M, int N, int B, int* nblocks, hipStream_t st, int units = 1);
-void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid);
+void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid, int units = 1);
 int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cd, double tv_weight, double tv_eps, float* x, float* theta,
                         float* b, const float* Phi, const float* y, const float* Phisum, const float* orig, double* sse_part,
                         int nfill, int M, int N, int B, int mode, float c0, float c1, hipStream_t st, int units = 1);

@@ -19,7 +19,7 @@
 //
 // Every product, every accumulation order and every rounding of the two-wave kernel is kept (same column / row operations, same
 // group and k-step order, the output transform's sums associated the same way), so the results are BIT-IDENTICAL to
-// scipnp_conv3x3_c8w4 -- tests/test_gpu_ops.py compares them with torch.equal.
+// scipnp_conv3x3_c8w4 -- tests/test_gpu_ops.py compares them with torch.equal.  LABORATORY code: built into libscipnp_diag.so only.
 //
 // Output transform: rows xi own to a wave give R[xi][j] (the row pass of the output transform), and the column pass needs only
 //     sA = R1 + R2, dA = R1 - R2      sB = R3 + R4, dB = R3 - R4      R0, R5
@@ -510,7 +510,7 @@ using namespace scipnp;
 
 extern "C" {
 
-#ifndef SCIPNP_DIAG_BUILD   /* ---- product entry (libscipnp.so) */
+#ifdef SCIPNP_DIAG_BUILD   /* ---- laboratory entries only (libscipnp_diag.so, include/scipnp_diag.h): measured slower than the product's conv_wino4.hip */
 
 int scipnp_conv3x3_c8w6(const float* in, const float* packed_wino4, float* out, const float* residual, const float* mask_src,
                         int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s) {
@@ -526,7 +526,6 @@ int scipnp_conv3x3_c8w6(const float* in, const float* packed_wino4, float* out, 
     return launch_status("conv3x3_c8w6_kernel");
 }
 
-#else   /* ---- SCIPNP_DIAG_BUILD: the laboratory entries (libscipnp_diag.so) */
 
 /* stamped instantiation: the slots of scipnp_conv3x3_c8w4_stamped (tools/probes/wino4_stamps.py reads both) */
 int scipnp_conv3x3_c8w6_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,

@@ -9,11 +9,12 @@ namespace scipnp {
 // out c8 [B][2][H][W][8]: group 0 = (f0.rgb, sigma, f1.rgb, sigma), group 1 = (f2.rgb, sigma, 0,0,0,0)
 // with f0,f1,f2 = frames (n-1, n, n+1) mod B of the planar input [B][3][H][W].
 __global__ void __launch_bounds__(256)
-fastdvd_pack_kernel(const float* __restrict__ frames, float* __restrict__ out, int B, size_t HW, float sigma) {
+fastdvd_pack_kernel(const float* __restrict__ frames, float* __restrict__ out, int B, int U, size_t HW, float sigma) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = blockIdx.y;
+    const int n = blockIdx.y;                               // frame t U + u of a unit batch [B][U] (U = 1: frame t)
     if (p >= HW) return;
-    const int f0 = (n + B - 1) % B, f2 = (n + 1) % B;
+    const int t = n / U, u = n - t * U;
+    const int f0 = ((t + B - 1) % B) * U + u, f2 = ((t + 1) % B) * U + u;
     const float* a = frames + (size_t)f0 * 3 * HW + p;
     const float* b = frames + (size_t)n * 3 * HW + p;
     const float* c = frames + (size_t)f2 * 3 * HW + p;
@@ -27,11 +28,12 @@ fastdvd_pack_kernel(const float* __restrict__ frames, float* __restrict__ out, i
 
 // same, written in the split-fp16 c8s layout [B][2][2 planes][HW][8 fp16] of conv_split.hip
 __global__ void __launch_bounds__(256)
-fastdvd_pack_c8s_kernel(const float* __restrict__ frames, char* __restrict__ out, int B, size_t HW, float sigma) {
+fastdvd_pack_c8s_kernel(const float* __restrict__ frames, char* __restrict__ out, int B, int U, size_t HW, float sigma) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.y;
     if (p >= HW) return;
-    const int f0 = (n + B - 1) % B, f2 = (n + 1) % B;
+    const int t = n / U, u = n - t * U;
+    const int f0 = ((t + B - 1) % B) * U + u, f2 = ((t + 1) % B) * U + u;
     const float* a = frames + (size_t)f0 * 3 * HW + p;
     const float* b = frames + (size_t)n * 3 * HW + p;
     const float* c = frames + (size_t)f2 * 3 * HW + p;
@@ -210,24 +212,32 @@ using namespace scipnp;
 
 extern "C" {
 
-int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int H, int W, float sigma,
-                                 scipnp_stream_t s) {
-    SCIPNP_REQUIRE(frames && out_c8 && B > 0 && B <= 65535 && H > 0 && W > 0, "bad arguments");
+int scipnp_fastdvd_pack_triplets_units(const float* frames, float* out_c8, int B, int units, int H, int W, float sigma,
+                                       scipnp_stream_t s) {
+    SCIPNP_REQUIRE(frames && out_c8 && B > 0 && units > 0 && (long long)B * units <= 65535 && H > 0 && W > 0, "bad arguments");
     SCIPNP_ALIGNED(out_c8);
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(fastdvd_pack_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, frames,
-                       out_c8, B, HW, sigma);
+    hipLaunchKernelGGL(fastdvd_pack_kernel, dim3((unsigned)((HW + 255) / 256), B * units), dim3(256), 0, (hipStream_t)s, frames,
+                       out_c8, B, units, HW, sigma);
     return launch_status("fastdvd_pack_kernel");
 }
 
-int scipnp_fastdvd_pack_triplets_c8s(const float* frames, void* out_c8s, int B, int H, int W, float sigma,
-                                     scipnp_stream_t s) {
-    SCIPNP_REQUIRE(frames && out_c8s && B > 0 && B <= 65535 && H > 0 && W > 0, "bad arguments");
+int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int H, int W, float sigma, scipnp_stream_t s) {
+    return scipnp_fastdvd_pack_triplets_units(frames, out_c8, B, 1, H, W, sigma, s);
+}
+
+int scipnp_fastdvd_pack_triplets_c8s_units(const float* frames, void* out_c8s, int B, int units, int H, int W, float sigma,
+                                           scipnp_stream_t s) {
+    SCIPNP_REQUIRE(frames && out_c8s && B > 0 && units > 0 && (long long)B * units <= 65535 && H > 0 && W > 0, "bad arguments");
     SCIPNP_ALIGNED(out_c8s);
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(fastdvd_pack_c8s_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)s, frames,
-                       (char*)out_c8s, B, HW, sigma);
+    hipLaunchKernelGGL(fastdvd_pack_c8s_kernel, dim3((unsigned)((HW + 255) / 256), B * units), dim3(256), 0, (hipStream_t)s, frames,
+                       (char*)out_c8s, B, units, HW, sigma);
     return launch_status("fastdvd_pack_c8s_kernel");
+}
+
+int scipnp_fastdvd_pack_triplets_c8s(const float* frames, void* out_c8s, int B, int H, int W, float sigma, scipnp_stream_t s) {
+    return scipnp_fastdvd_pack_triplets_c8s_units(frames, out_c8s, B, 1, H, W, sigma, s);
 }
 
 int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,

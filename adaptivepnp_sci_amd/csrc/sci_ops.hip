@@ -623,12 +623,15 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
 
 // launch shape of pm_dual_project_kernel: pixels per thread, chunks per workgroup (more than one only where one workgroup per
 // chunk would be more squared-error partials than the caller's nfill entries), workgroups
-void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid) {
+void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid, int units) {
     const int threads = 256;
     const bool wide = Q / 4 >= 512LL * threads;               // (as launch_pm_project: small states take one pixel per thread)
     const int v = (vec_ok && wide) ? (B <= 16 ? 4 : 2) : 1;
     const long long nchunks = (Q / v + threads - 1) / threads;
-    const int ch = nfill > 0 ? (int)((nchunks + nfill - 1) / nfill) : 1;
+    int ch = nfill > 0 ? (int)((nchunks + nfill - 1) / nfill) : 1;
+    // unit batches cut the squared-error partials at unit boundaries: a workgroup must not straddle two units, so its pixel
+    // count (ch * 256 * v) is kept a power of two (B = 3 gave ch = 3: 768 pixels against units of 2048 k pixels)
+    if (units > 1) { int p2 = 1; while (p2 < ch) p2 <<= 1; ch = p2; }
     *VEC = v;
     *CH = ch;
     *grid = (unsigned)((nchunks + ch - 1) / ch);
@@ -844,7 +847,7 @@ int scipnp_pm_dual_project_blocks(int M, int N, int B, int units, int nfill) {
     if (M <= 0 || N <= 0 || B <= 0 || B > 32 || units < 1) return 0;
     int vec, ch;
     unsigned grid;
-    scipnp::dual_project_shape(4LL * M * N * units, B, nfill, (long long)M * N % 4 == 0, &vec, &ch, &grid);
+    scipnp::dual_project_shape(4LL * M * N * units, B, nfill, (long long)M * N % 4 == 0, &vec, &ch, &grid, units);
     return (int)grid;
 }
 
@@ -877,7 +880,7 @@ int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double 
     const int threads = 256;
     int VECs, CH;
     unsigned grid;
-    dual_project_shape(Q, B, sse_part ? nfill : 0, vec, &VECs, &CH, &grid);
+    dual_project_shape(Q, B, sse_part ? nfill : 0, vec, &VECs, &CH, &grid, units);
     SCIPNP_REQUIRE(sse_part == nullptr || nfill > 0, "sse_part needs nfill > 0");
     // the candidate form keeps the stop iteration of at most 4 planes per workgroup (always true for one unit)
     SCIPNP_REQUIRE(!use_cd || units == 1 || ((long long)CH * threads * VECs - 1) / MN + 2 <= 4,

@@ -454,7 +454,9 @@ static int w4g_launch(const float* act_c8, const float* dz_c8, float* dW, float*
     SCIPNP_REQUIRE(act_c8 && dz_c8 && dW && workspace, "null pointer");
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 &&
                    Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout && nslab > 0, "bad shape");
-    SCIPNP_REQUIRE((long long)n * Cin * h * w * 4 < (1ll << 31) && (long long)n * Cout * h * w * 4 < (1ll << 31),
+    // (the input descriptor spans the tensor plus (w + 1) pixels: masked lanes carry the offset 0x80000000, which must stay
+    // past its range)
+    SCIPNP_REQUIRE((long long)n * Cin * h * w * 4 + (long long)(w + 1) * 32 <= (1ll << 31) && (long long)n * Cout * h * w * 4 < (1ll << 31),
                    "tensors of 2 GiB or more: use scipnp_conv3x3_wgrad");
     SCIPNP_ALIGNED(act_c8); SCIPNP_ALIGNED(dz_c8);
     const int ciP = w4g_round_up(Cin, 32), coP = w4g_round_up(Cout, 32);

@@ -216,8 +216,13 @@ def _unet_convs(pk, b, split, pkw=None):
 
 
 class DDnetEngine:
-    def __init__(self, model, B, H, W, device, precision=None):
+    def __init__(self, model, B, H, W, device, precision=None, units=1):
+        """B frames in all; units > 1: a unit batch of `units` sequences of B / units frames (frame t of unit u at t * units + u):
+        the temporal windows of stage 1 stay inside a unit -- only the gather tables change"""
         from .nets import default_precision
+        if B % units:
+            raise ValueError(f'{B} frames do not split into {units} units')
+        self.units = units
         if H % 8 or W % 8:
             raise ValueError('DDnet on the HIP path needs H and W to be multiples of 8 (half-resolution U-Net)')
         self.B, self.H, self.W, self.device = B, H, W, device
@@ -228,7 +233,9 @@ class DDnetEngine:
         n = torch.arange(B)
         # stage 1: evaluation e = j*B + n uses frames (n - 2 + j + i) mod B, i = 0..2  (DDnet_test.py:177-179 window,
         # network_demosaicking.py:441-449 triplets)
-        idx1 = torch.stack([torch.stack([(n - 2 + j + i) % B for i in range(3)], 1) for j in range(3)]).reshape(E, 3)
+        Bu = B // units
+        tt, uu = n // units, n % units
+        idx1 = torch.stack([torch.stack([((tt - 2 + j + i) % Bu) * units + uu for i in range(3)], 1) for j in range(3)]).reshape(E, 3)
         # stage 2: evaluation n (branch a) / B + n (branch b) uses stage-1 outputs j*B + n of its branch
         idx2 = torch.cat([torch.stack([j * B + n for j in range(3)], 1) + br * E for br in range(2)])
         self.idx1 = idx1.to(torch.int32).contiguous().to(device)

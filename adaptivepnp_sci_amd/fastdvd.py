@@ -158,7 +158,7 @@ def wino_packs(packed):
             for i, (_k, _bn, cin, cout, _relu, s2, _shuf) in enumerate(_LAYERS)]
 
 
-def denblock_forward(pk, frames, sigma, out, b, pkw=None):
+def denblock_forward(pk, frames, sigma, out, b, pkw=None, units=1):
     """out[n] = DenBlock(frames[n-1], frames[n], frames[n+1]) for all n (circular); pk = 16 packed layers,
     b = buffers from alloc_denblock_buffers; pkw = wino_packs(pk) to run the stride-1 layers as fp32 Winograd.
     reference packages/fastdvdnet/models.py:179-198."""
@@ -172,7 +172,7 @@ def denblock_forward(pk, frames, sigma, out, b, pkw=None):
             return ops.conv3x3_c8w(x, pkw[i], cout, **kw)
     else:
         c = ops.conv3x3_c8
-    ops.fastdvd_pack_triplets(frames, sigma, b['t_in'])
+    ops.fastdvd_pack_triplets(frames, sigma, b['t_in'], units=units)
 
     def convs(b):
         c(b['t_in'], pk[0], 96, relu=True, out=b['t96'], head=True)
@@ -237,18 +237,23 @@ def _denblock_convs_split(pk, b):
     c(b['o32'], pk[15], 8, out=b['x8'], f32_out=True)
 
 
-def denblock_forward_split(pk, frames, sigma, out, b):
+def denblock_forward_split(pk, frames, sigma, out, b, units=1):
     """denblock_forward on the split-fp16 kernels: c8s activations; the two UpBlock convs store their PixelShuffle-d
     result plus the skip tensor straight into c8s (epilogue flag bit6).  The 16 convolutions run as two half-batches of
     frames on two HIP streams (SCIPNP_STREAMS=1 keeps one): the quarter- and half-resolution layers are grids of 1.3 - 2.7
     generations of workgroups, and the second stream's launches fill the CUs the first one's last generation leaves idle."""
-    ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'])
+    ops.fastdvd_pack_triplets_c8s(frames, sigma, b['t_in'], units=units)
     ops.on_side_streams(b['t_in'].shape[0], lambda sl: _denblock_convs_split(pk, {k: v[sl] for k, v in b.items()}))
     return ops.fastdvd_finish(frames, b['x8'], out)
 
 
 class FastDVDEngine:
-    def __init__(self, model, B, H, W, device, precision=None):
+    def __init__(self, model, B, H, W, device, precision=None, units=1):
+        """B frames in all; units > 1: a unit batch of `units` sequences of B / units frames, frame t of unit u at t * units + u --
+        the temporal windows stay inside a unit (scipnp_fastdvd_pack_triplets_units), everything else is per frame"""
+        if B % units:
+            raise ValueError(f'{B} frames do not split into {units} units')
+        self.units = units
         if H % 4 or W % 4:
             raise ValueError('FastDVDnet needs H and W to be multiples of 4 (the reference reflect-pads otherwise; '
                              'its padding of the noise map breaks for more than one frame, fastdvdnet.py:126)')
@@ -277,8 +282,8 @@ class FastDVDEngine:
     def forward(self, frames, sigma):
         """frames planar (B,3,H,W) -> denoised planar (B,3,H,W) (owned by the engine, overwritten per call)."""
         if self.precision == 'f16x3':
-            denblock_forward_split(self.packed['temp1'], frames, sigma, self.s1, self.bufs)
-            return denblock_forward_split(self.packed['temp2'], self.s1, sigma, self.out, self.bufs)
+            denblock_forward_split(self.packed['temp1'], frames, sigma, self.s1, self.bufs, units=self.units)
+            return denblock_forward_split(self.packed['temp2'], self.s1, sigma, self.out, self.bufs, units=self.units)
         w = self.packed_wino or {'temp1': None, 'temp2': None}
-        denblock_forward(self.packed['temp1'], frames, sigma, self.s1, self.bufs, w['temp1'])
-        return denblock_forward(self.packed['temp2'], self.s1, sigma, self.out, self.bufs, w['temp2'])
+        denblock_forward(self.packed['temp1'], frames, sigma, self.s1, self.bufs, w['temp1'], units=self.units)
+        return denblock_forward(self.packed['temp2'], self.s1, sigma, self.out, self.bufs, w['temp2'], units=self.units)

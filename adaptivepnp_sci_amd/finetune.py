@@ -71,8 +71,9 @@ def wgrad_f4_enabled():
 
 
 def _wino_wgrad_fits(n, cin, cout, h, w):
-    """csrc/wgrad_wino.hip addresses both tensors through 32-bit buffer offsets: each must stay below 2 GiB"""
-    return n * max(cin, cout) * h * w * 4 < (1 << 31)
+    """csrc/wgrad_wino.hip / wgrad_wino4.hip address both tensors through 32-bit buffer offsets: each must stay below 2 GiB
+    (the F(4x4) kernel's input descriptor spans w + 1 pixels more, and its masked lanes carry the offset 2^31)"""
+    return n * max(cin, cout) * h * w * 4 + (w + 1) * 32 <= (1 << 31)
 
 
 def _upload_flat(flat_dev, srcs):
@@ -118,9 +119,9 @@ def _carve(flat, like):
 
 def _repack_wino(packed_f32, wp):
     """Winograd-domain weights of a trainer layer (ops.WinoPacked with preallocated buffers) from its fp32 direct packing"""
-    if wp.f4 is not None and ops.wino_f4_enabled():
-        # ops.conv3x3_c8w runs such a layer on the F(4x4) kernel: its F(2x2) packing would never be read (the trainers' launches
-        # only; the engine re-derives both forms when it adopts the updated weights)
+    if wp.f4 is not None and wp.w is None:
+        # a layer latched onto the F(4x4) kernel at construction (ops.WinoPacked with w = None: ops.conv3x3_c8w can only take
+        # its F(4x4) form, whatever SCIPNP_WINO_F4 says later): no F(2x2) packing exists to go stale
         ops.pack_conv3x3_wino4(packed_f32, wp.cin, wp.cout, out=wp.f4)
         return
     ops.pack_conv3x3_wino(packed_f32, wp.cin, wp.cout, out=wp.w)
@@ -184,7 +185,10 @@ class _FFDNetTrainer:
             def wp(ci, co):
                 f4 = (torch.empty(lib.scipnp_conv3x3_wino4_packed_floats(ci, co), dtype=F32, device=dev)
                       if (ops.wino_f4_enabled() and ops.wino_f4_shape(ci, co)) else None)
-                return ops.WinoPacked(torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev), ci, co, f4)
+                # a layer with an F(4x4) packing is LATCHED onto that kernel (w = None): no uninitialised F(2x2) buffer exists that a
+                # later toggle of SCIPNP_WINO_F4, rows16 = True or a C-entry caller's data_ptr() could reach
+                w2 = None if f4 is not None else torch.empty(lib.scipnp_conv3x3_wino_packed_floats(ci, co), dtype=F32, device=dev)
+                return ops.WinoPacked(w2, ci, co, f4)
             self.fwd_w = [wp(ci, co) for ci, co in zip(self.cin, self.cout)]
             self.bwd_w = [None] + [wp(co, ci) for ci, co in list(zip(self.cin, self.cout))[1:]]
         self.acts = [torch.empty(B, nc // 8, M, N, 8, dtype=F32, device=dev) for _ in range(self.nb - 1)]

@@ -352,9 +352,12 @@ def conv3x3_c8w(x, packed_wino, Cout, relu=False, residual=None, mask_src=None, 
     flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) |
              (0x100 if head else 0) | (0x200 if rows16 else 0) | (8 if shuffle else 0))
     if isinstance(packed_wino, WinoPacked):
-        if packed_wino.f4 is not None and not rows16 and wino_f4_enabled():
+        if packed_wino.f4 is not None and not rows16 and (packed_wino.w is None or wino_f4_enabled()):
             return conv3x3_c8w4(x, packed_wino.f4, Cout, relu=relu, residual=residual, mask_src=mask_src, out=out, head=head,
                                 shuffle=shuffle)
+        if packed_wino.w is None:
+            raise _lib.ScipnpError('this layer holds only its F(4x4,3x3) packing (latched at construction): rows16 / the F(2x2) '
+                                   'kernel cannot run it')
         packed_wino = packed_wino.w
     _timed_call('conv3x3_c8w_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w', _p(x, 'x'),
                 _p(packed_wino, 'packed_wino'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
@@ -386,19 +389,6 @@ def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None
     return out
 
 
-def conv3x3_c8w6(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
-    """conv3x3_c8w4's convolution on the three-waves-per-SIMD kernel (csrc/conv_wino4x.hip: 6-wave workgroups, the tile's 36
-    positions split over three waves): same packing, bit-identical results; no PixelShuffle store."""
-    n, cg, h, w, _ = x.shape
-    if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=F32)
-    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0))
-    _timed_call('conv3x3_c8w6_kernel', (n, cg * 8, Cout, h, w, flags), 'scipnp_conv3x3_c8w6', _p(x, 'x'),
-                _p(packed_wino4, 'packed_wino4'), _p(out, 'out'), _p(residual, 'residual'), _p(mask_src, 'mask_src'), n, cg * 8,
-                Cout, h, w, flags, _stream())
-    return out
-
-
 class WinoPacked:
     """Winograd-domain weights of one layer for conv3x3_c8w: `w` = the scipnp_pack_conv3x3_wino packing (every shape and
     epilogue), `f4` = the F(4x4,3x3) packing of scipnp_conv3x3_c8w4 for the layer shapes that kernel is used for, else None.
@@ -409,6 +399,8 @@ class WinoPacked:
         self.w, self.f4, self.cin, self.cout = w, f4, cin, cout
 
     def data_ptr(self):                                   # (C-entry callers pass the classic packing)
+        if self.w is None:
+            raise _lib.ScipnpError('this layer holds only its F(4x4,3x3) packing (latched at construction): no F(2x2) buffer')
         return self.w.data_ptr()
 
 
@@ -739,20 +731,21 @@ def c8s_to_float(x):
     return x[:, :, 0].float() + x[:, :, 1].float() / 2048.0
 
 
-def fastdvd_pack_triplets(frames, sigma, out=None):
-    B, _, H, W = frames.shape
+def fastdvd_pack_triplets(frames, sigma, out=None, units=1):
+    """frames [B*units][3][H][W] (frame t of unit u at t * units + u) -> the circular 3-frame windows of every frame, c8"""
+    BU, _, H, W = frames.shape
     if out is None:
-        out = torch.empty(B, 2, H, W, 8, device=frames.device, dtype=F32)
-    _call('scipnp_fastdvd_pack_triplets', _p(frames, 'frames'), _p(out, 'out'), B, H, W, float(np.float32(sigma)),
-          _stream())
+        out = torch.empty(BU, 2, H, W, 8, device=frames.device, dtype=F32)
+    _call('scipnp_fastdvd_pack_triplets_units', _p(frames, 'frames'), _p(out, 'out'), BU // units, units, H, W,
+          float(np.float32(sigma)), _stream())
     return out
 
 
-def fastdvd_pack_triplets_c8s(frames, sigma, out=None):
-    B, _, H, W = frames.shape
+def fastdvd_pack_triplets_c8s(frames, sigma, out=None, units=1):
+    BU, _, H, W = frames.shape
     if out is None:
-        out = torch.empty(B, 2, 2, H, W, 8, device=frames.device, dtype=torch.float16)
-    _call('scipnp_fastdvd_pack_triplets_c8s', _p(frames, 'frames'), _p(out, 'out', torch.float16), B, H, W,
+        out = torch.empty(BU, 2, 2, H, W, 8, device=frames.device, dtype=torch.float16)
+    _call('scipnp_fastdvd_pack_triplets_c8s_units', _p(frames, 'frames'), _p(out, 'out', torch.float16), BU // units, units, H, W,
           float(np.float32(sigma)), _stream())
     return out
 

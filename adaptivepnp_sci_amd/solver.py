@@ -81,7 +81,9 @@ class AdmmRun:
         problems of ONE shape that share the denoiser weights; they are stepped by ONE launch sequence (the reference loops
         its measurements one after the other, two_stage_ADMM_Online_FFD_Warm.py:241-275).  State layout [B][U][4][M][N]
         (frame f = t*U + u): the projection sees 4 M N U pixels, every other kernel B*U frames / 4*B*U planes; each unit's
-        numbers are bit-identical to its own single-unit run.  'tv' and 'ffdnet_color' (Malvar or closed-form demosaic);
+        numbers are bit-identical to its own single-unit run.  Every denoiser and demosaic: FastDVDnet's and DDnet's temporal
+        windows stay inside a unit (round 5: scipnp_fastdvd_pack_triplets_units, DDnetEngine(units=), the loop being replaced is
+        two_stage_ADMM_Online_FastDVD_Warm.py:276-310);
         a finetune event needs per-unit weights: split() the batch before the gate fires.  result_mosaic(), psnr_all() and
         final_report() then return one entry per unit."""
         if str(denoiser).lower() not in DENOISERS:
@@ -96,9 +98,8 @@ class AdmmRun:
         if units is not None:
             if U < 1 or len(y_bayer) != U or len(Phi_bayer) != U or any(v is not None and len(v) != U for v in (x0_bayer, X_orig)):
                 raise ValueError(f'units={units}: y_bayer, Phi_bayer (x0_bayer, X_orig) must be sequences of {units} problems')
-            if denoiser not in ('tv', 'ffdnet_color') or model_demosaic is not None or Phi_sum is not None:
-                raise ValueError("unit batches: denoiser 'tv' or 'ffdnet_color', Malvar / closed-form demosaic, no Phi_sum "
-                                 '(FastDVDnet and DDnet look across the frames of a unit)')
+            if Phi_sum is not None:
+                raise ValueError('unit batches: no Phi_sum (the admm_denoise / gap_denoise aliases solve one problem)')
             ys, Phis = list(y_bayer), list(Phi_bayer)
             x0s = None if x0_bayer is None else list(x0_bayer)
             origs = None if X_orig is None else list(X_orig)
@@ -151,6 +152,12 @@ class AdmmRun:
         if U > 1 and denoiser == 'tv' and self.iqa and (4 * M * N) % 2048:
             raise ValueError('unit batches with per-iteration PSNR (X_orig + show_iqa) on the TV path need H*W to be a multiple of '
                              '2048: the squared-error partials are cut at unit boundaries')
+        if U > 1 and denoiser == 'tv' and self.iqa:
+            # the fused dual-update + projection launch writes one partial per workgroup: its workgroups must tile the units
+            nblk = _lib.load().scipnp_pm_dual_project_blocks(M, N, B, U, ops.sse_nblocks(x0.numel()))
+            if nblk % U:
+                raise ValueError(f'unit batches with per-iteration PSNR on the TV path: the {nblk} workgroups of the fused launch '
+                                 f'do not tile {U} units of {H}x{W}x{B}; drop X_orig / show_iqa or solve the units one by one')
         self.sse_rows = []
         # ---- constants (reference :101-110; one-stage uses _lambda/gamma directly)
         if two_stage:
@@ -217,14 +224,14 @@ class AdmmRun:
                     self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
                 else:
                     from .fastdvd import FastDVDEngine
-                    self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision)
+                    self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision, units=U)
                     self.rgb_w = torch.empty_like(self.x_rgb)
                 self.dd = None
                 if model_demosaic is not None:   # deep demosaicking instead of Malvar (reference :192-194 / :242-244)
                     if not two_stage:
                         raise ValueError('model_demosaic is an argument of the two-stage solver only (as in the reference)')
                     from .ddnet import DDnetEngine
-                    self.dd = DDnetEngine(model_demosaic, B, H, W, self.device, precision=conv_precision)
+                    self.dd = DDnetEngine(model_demosaic, B, H, W, self.device, precision=conv_precision, units=U)
                     self.dd_planes = torch.empty_like(x0)
                     self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
 
@@ -425,6 +432,8 @@ class AdmmRun:
                     src = getattr(self, name)
                     if src is not None:
                         getattr(r, name).copy_(src.view(B, U, 3, H, W)[:, u])
+                if self.denoiser == 'fastdvd_color':        # (the closed-form update reads the engine's last denoised frames)
+                    r.eng.out.copy_(self.eng.out.view(B, U, 3, H, W)[:, u])
         return runs
 
     def _unit_state(self, t, u):

@@ -381,14 +381,6 @@ int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int 
 int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, const float* residual,
                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
-/* The same convolution with the 36 positions of a tile split over THREE waves (csrc/conv_wino4x.hip, round 5): 6-wave workgroups,
- * 96 accumulator registers per wave, three waves per SIMD instead of two -- the same packed_wino4 buffer, the same products and
- * summation orders, results BIT-IDENTICAL to scipnp_conv3x3_c8w4.  flags: bit0 ReLU, bit1 residual, bit4 ReLU-backward mask, bit8
- * head-layer tag (no PixelShuffle store: bit3 is refused -- those layers stay on scipnp_conv3x3_c8w4).
- * -- same nn.Conv2d(..., 3, 1, 1) call sites (network_ffdnet.py:54-69, models.py:16-253). */
-int scipnp_conv3x3_c8w6(const float* in, const float* packed_wino4, float* out, const float* residual,
-                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
-
 /* The whole FFDNet-colour pass as ONE call with mixed Winograd forms: layer l runs on scipnp_conv3x3_c8w4 when
  * packed_wino4 != NULL and packed_wino4[l] != NULL (the 96 -> 96 body layers, packed by scipnp_pack_conv3x3_wino4), else on
  * scipnp_conv3x3_c8w with packed_wino[l]; other arguments as scipnp_ffdnet_forward_c8w. */
@@ -418,6 +410,13 @@ int scipnp_fastdvd_pack_triplets(const float* frames, float* out_c8, int B, int 
 /* same in the split-fp16 c8s layout */
 int scipnp_fastdvd_pack_triplets_c8s(const float* frames, void* out_c8s, int B, int H, int W, float sigma,
                                      scipnp_stream_t s);
+/* the same for a unit batch of `units` sequences of B frames each, frame-major with the unit inside (frame t of unit u at index
+ * t * units + u, the layout of scipnp_pm_project_units): the window of frame (t, u) is (t-1, u), (t, u), (t+1, u), circular in t
+ * within the unit -- the units of a batch never see each other's frames. */
+int scipnp_fastdvd_pack_triplets_units(const float* frames, float* out_c8, int B, int units, int H, int W, float sigma,
+                                       scipnp_stream_t s);
+int scipnp_fastdvd_pack_triplets_c8s_units(const float* frames, void* out_c8s, int B, int units, int H, int W, float sigma,
+                                           scipnp_stream_t s);
 /* DenBlock residual: out[n][c] = center[n][c] - x_c8[n][0][..][c], c < 3  -- models.py:196 (in1 - x) */
 int scipnp_fastdvd_finish(const float* center, const float* x_c8, float* out, int B, int H, int W,
                           scipnp_stream_t s);

@@ -27,8 +27,16 @@ int scipnp_conv3x3_c8w4_stamped(const float* in, const float* packed_wino4, floa
 int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s);
 
-/* the same two laboratory entries for the three-waves-per-SIMD form (csrc/conv_wino4x.hip, scipnp_conv3x3_c8w6): stamp slots as
- * above (wave 0 = tile row 0, third A); stamped builds exist for the masks 0, 1, 6, 7 (flags bits 12..14) */
+/* ---- three waves per SIMD (csrc/conv_wino4x.hip, round 5; measured, not adopted): scipnp_conv3x3_c8w4's convolution with the 36
+ * positions of a tile split over THREE waves by rows of the transformed patch ({1,2}, {3,4}, {0,5}: four packed operations per
+ * patch column each), 96 accumulator registers per wave, 164 VGPRs; workgroup = 12 waves = 4 tile rows x 3 thirds (16 x 64 pixels x
+ * 32 channels, one per CU: a 6-wave workgroup reserves two wave slots on every SIMD and a second one does not fit).  The same
+ * packed_wino4 buffer, the same products and summation orders: results BIT-IDENTICAL to scipnp_conv3x3_c8w4.
+ * flags: bit0 ReLU, bit1 residual, bit4 ReLU-backward mask, bit8 head tag (no PixelShuffle store).  277 us against 249 us on the FFDNet
+ * body layer (profiles/r05a_*): twelve waves in lockstep through one barrier per k-step leave the matrix pipe idle at every
+ * k-step's start and end.  _stamped / _diag: stamp slots and masks as for scipnp_conv3x3_c8w4 (stamped builds: masks 0, 1, 6, 7). */
+int scipnp_conv3x3_c8w6(const float* in, const float* packed_wino4, float* out, const float* residual,
+                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 int scipnp_conv3x3_c8w6_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                                 int flags, unsigned long long* stamps, scipnp_stream_t s);
 int scipnp_conv3x3_c8w6_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,

@@ -203,6 +203,27 @@ def test_compact_line_fits_and_round_trips():
     assert head['phi_step']['frac'] > 0 and head['phi_step']['chain']['frac'] > 0
 
 
+def test_compact_line_of_an_eight_rank_job_fits():
+    """the N = 8 line the driver's scaling run produces: 8 ranks_devices entries, per-rank solve / gather lists of 8, NCCL
+    backend string -- still < 4096 bytes with every contract key"""
+    b = _bench_module('bench_mod_emit8')
+    recs = _canned_records()
+    for name in ('r03f_bench_line.json', 'r03f_bench_cubes2_line.json', 'r03f_bench_tile1024_line.json'):
+        full = dict(recs[name])
+        full.update(n_gpus=8, ranks=8, world_size=8, backend='nccl (RCCL 2.26.6, 8 ranks over xGMI)',
+                    ranks_devices=[[r, r, 0x05 + 0x10 * r] for r in range(8)], units_gathered_on_rank0=8)
+        if 'per_rank' in full or 'solve_s_per_rank' in full:
+            for k in ('solve_s_per_rank', 'gather_s_per_rank', 'units_per_rank'):
+                if k in full:
+                    full[k] = [1.2345678 + r for r in range(8)]
+        line = b.compact_line(full, 'gpurun_out/bench_detail_headline_n8.json')
+        assert len(line) < 4096, (name, len(line))
+        got = json.loads(line)
+        assert got['n_gpus'] == 8 and got['world_size'] == 8 and len(got['ranks_devices']) == 8
+        for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'scaling', 'dtype', 'config', 'roofline', 'cpu_baseline'):
+            assert k in got, (name, k)
+
+
 def test_compact_line_never_exceeds_the_limit_whatever_the_record_holds():
     b = _bench_module('bench_mod_emit2')
     full = _canned_records()['r03f_bench_line.json']

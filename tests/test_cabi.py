@@ -53,16 +53,17 @@ def test_the_laboratory_is_a_separate_library(lib):
     from adaptivepnp_sci_amd import _lib
     dlib = diaglib.load()
     names = header_symbols('scipnp_diag.h')
-    assert len(names) == 14 and sorted(diaglib.SIGNATURES) == names
+    assert len(names) == 17 and sorted(diaglib.SIGNATURES) == names
     assert exported_symbols(diaglib.DIAG_LIB_PATH) == names
     assert not set(names) & set(header_symbols()) and not set(names) & set(_lib.SIGNATURES)
     for n in names:
         assert hasattr(dlib, n) and not hasattr(lib, n), n
     # argument errors of the laboratory entries surface through the product library's error string
     assert dlib.scipnp_bench_mfma(C.c_void_p(256), 1, 1, 7, None) == -1 and lib.scipnp_last_error()
-    for src in ('peaks.o', 'conv_winop.o'):                                  # (objects of the lab never enter the product link)
+    for src in ('peaks.o', 'conv_winop.o', 'conv_wino4x_diag.o'):           # (objects of the lab never enter the product link)
         mk = open(os.path.join(ROOT, 'adaptivepnp_sci_amd', 'csrc', 'Makefile')).read()
-        assert src in mk.split('DIAG_OBJS =')[1].splitlines()[0] and src.replace('.o', '.hip') not in mk.split('\nSRCS =')[1].splitlines()[0]
+        hip = src.replace('_diag.o', '.hip').replace('.o', '.hip')
+        assert src in mk.split('DIAG_OBJS =')[1].splitlines()[0] and hip not in mk.split('\nSRCS =')[1].splitlines()[0]
 
 
 def test_identity(lib):

@@ -70,6 +70,52 @@ def test_config1_ffdnet_512x512x8(solver, ffdnet_state_dict, precision, monkeypa
     assert np.abs(np.array(res[4]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
 
 
+def test_config3_eight_512x512x8_cubes_as_one_unit_batch(solver, ffdnet_state_dict):
+    """configs[3] as written: 8 independent 512x512x8 cubes (seeds 0..7) solved as ONE unit batch on one GPU
+    (what a rank does with its share at 1 GPU; `bench.py --cubes 8`): every unit bit-identical to its single-unit run for 3
+    iterations, and unit 0 within the gates of the CPU oracle (reference loop two_stage_ADMM_Online_FFD_Warm.py:241-275)."""
+    from adaptivepnp_sci_amd import synth
+    from adaptivepnp_sci_amd.nets import FFDNet
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    from oracle import nets as ON
+    from oracle import solver as OS
+    U = 8
+    pr = [synth.make_problem(512, 512, 8, seed=i) for i in range(U)]
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    warm = []
+    for y, Phi, _ in pr:                                     # TV warm start per cube, as the drivers do (:259-263)
+        tv = AdmmRun(y, Phi, 'tv', False)
+        for _ in range(10):
+            tv.step(0)
+        warm.append(tv.result_mosaic())
+    sig = 25 / 255
+    batch = AdmmRun([p[0] for p in pr], [p[1] for p in pr], 'ffdnet_color', True, x0_bayer=warm, X_orig=[p[2] for p in pr],
+                    model=net, conv_precision='f32', units=U)
+    its = []
+    for k in range(3):
+        batch.step(sig, last=(k == 2))
+        its.append([m.clone() for m in batch.result_mosaic()])
+    ps = batch.psnr_all()
+    del batch
+    for u in range(U):
+        r = AdmmRun(pr[u][0], pr[u][1], 'ffdnet_color', True, x0_bayer=warm[u], X_orig=pr[u][2], model=net, conv_precision='f32')
+        for k in range(3):
+            r.step(sig, last=(k == 2))
+            assert torch.equal(its[k][u], r.result_mosaic()), (u, k)
+        assert np.abs(np.array(ps[u]) - np.array(r.psnr_all())).max() < 1e-9, u
+        del r
+    onet = ON.OracleFFDNet()
+    onet.load_state_dict(ffdnet_state_dict)
+    onet.eval()
+    y, Phi, orig = pr[0]
+    with torch.no_grad():
+        o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [3], [sig], x0_bayer=warm[0].cpu().numpy(), X_orig=orig, model_denoise=onet)
+    worst = max(rel_l2(its[k][0].cpu().numpy(), o['theta_iterates'][k]) for k in range(3))
+    assert worst <= REL_TOL, worst
+    assert np.abs(np.array(ps[0]) - np.array(o['psnr_all'])).max() <= PSNR_TOL
+
+
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_config2_fastdvdnet_512x512x8(solver, precision, monkeypatch):
     monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)

@@ -1240,3 +1240,24 @@ def test_tv_banded_kernel_random_shapes(ops):
         ops.tv_chambolle(x, b, coef, o3, p3, 0.1, kernel=3)
         assert torch.equal(p1.stop_iter, p3.stop_iter), (M, N, C_, n_iter)
         assert torch.equal(o1, o3), (M, N, C_, n_iter)
+
+
+def test_conv3x3_winograd_f4_three_waves_per_simd_equals_the_product_kernel(ops):
+    """csrc/conv_wino4x.hip (LABORATORY, libscipnp_diag.so; round 5) -- the F(4x4,3x3) convolution with a tile's 36 positions split
+    over THREE waves (12-wave workgroups of 16 x 64 pixels, 164 VGPRs, three waves per SIMD) on the SAME packed weights:
+    BIT-IDENTICAL to the product's csrc/conv_wino4.hip (whose whole-line store epilogue is thereby checked against the classic
+    per-lane epilogue this kernel still has) for every plain-store epilogue, ragged sizes, narrow outputs, several frames.
+    (Measured 277 us against 249 us on the FFDNet body layer and not adopted: profiles/r05a_*.)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import diaglib
+    g = torch.Generator().manual_seed(5)
+    for (n, cin, cout, h, w) in ((1, 16, 32, 8, 64), (2, 24, 40, 13, 70), (1, 96, 96, 37, 131), (3, 32, 16, 20, 64), (1, 8, 96, 9, 9),
+                                 (2, 64, 64, 64, 64), (8, 96, 96, 128, 128)):
+        x = ops.to_c8(torch.randn(n, cin, h, w, generator=g).cuda())
+        pk = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g), Cin=cin, Cout=cout,
+                              device='cuda')
+        p4 = ops.pack_conv3x3_wino4(pk, cin, cout)
+        res = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        msk = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        for kw in ({}, {'relu': True}, {'relu': True, 'residual': res, 'head': True}, {'mask_src': msk, 'residual': res}):
+            assert torch.equal(ops.conv3x3_c8w4(x, p4, cout, **kw), diaglib.conv3x3_c8w6(x, p4, cout, **kw)), ((n, cin, cout, h, w), sorted(kw))

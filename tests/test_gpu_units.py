@@ -28,7 +28,7 @@ def problems(n, H, W, B, seed0=0):
 
 
 @pytest.mark.parametrize('two_stage', [False, True])
-@pytest.mark.parametrize('shape,U', [((64, 64, 8), 3), ((256, 256, 8), 8), ((64, 128, 5), 2)])
+@pytest.mark.parametrize('shape,U', [((64, 64, 8), 3), ((256, 256, 8), 8), ((64, 128, 5), 2), ((128, 128, 3), 6)])
 def test_admm_tv_unit_batch_equals_single_unit_runs(two_stage, shape, U):
     """ADMM-TV, both solvers: the batch's two-launch iteration (fused dual update + projection over 4 M N U pixels, banded TV over
     4 B U planes) against U single-unit runs, iterate by iterate; deferred and flushed rows both appear (flush at k = 4)"""
@@ -104,6 +104,66 @@ def test_ffdnet_unit_batch_equals_single_unit_runs(ffdnet_state_dict, precision)
         assert torch.equal(rgb[:, u], single[u].out_rgb)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+@pytest.mark.parametrize('close_form', [False, True])
+def test_fastdvdnet_unit_batch_equals_single_unit_runs(precision, close_form):
+    """two-stage ADMM + FastDVDnet, 3 units of 64 x 64 x 8 sharing the (synthetic) weights: the 5-frame temporal windows stay
+    inside a unit (frames t U + u, neighbours +- U and +- 2U through the two DenBlock stages) -- iterates, PSNR rows and
+    denoised frames bit-identical per unit; then split() and two more iterations on per-unit runs"""
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
+    U = 3
+    pr = problems(U, 64, 64, 8, seed0=41)
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
+    kw = dict(model=net, conv_precision=precision, close_form_demosaic=close_form)
+    single = [AdmmRun(y, Phi, 'fastdvd_color', True, X_orig=orig, **kw) for y, Phi, orig in pr]
+    batch = AdmmRun([p[0] for p in pr], [p[1] for p in pr], 'fastdvd_color', True, X_orig=[p[2] for p in pr], units=U, **kw)
+    for k in range(3):
+        for r in single:
+            r.step(8 / 255)
+        batch.step(8 / 255)
+        got = batch.result_mosaic()
+        for u in range(U):
+            assert torch.equal(got[u], single[u].result_mosaic()), (k, u)
+    parts = batch.split()
+    for k in range(3, 5):
+        for r in single:
+            r.step(8 / 255, last=(k == 4))
+        for p in parts:
+            p.step(8 / 255, last=(k == 4))
+    for u in range(U):
+        assert torch.equal(parts[u].result_mosaic(), single[u].result_mosaic()), u
+        assert torch.equal(parts[u].out_rgb, single[u].out_rgb), u
+        assert np.abs(np.array(parts[u].psnr_all()) - np.array(single[u].psnr_all())).max() < 1e-9
+    batch.check_overflow()
+
+
+@pytest.mark.parametrize('denoiser', ['ffdnet_color', 'fastdvd_color'])
+def test_deep_demosaicking_unit_batch_equals_single_unit_runs(ffdnet_state_dict, denoiser):
+    """model_demosaic= (DDnet, the reference drivers' default) in a unit batch: stage 1's temporal triplets are gathered inside
+    a unit (DDnetEngine(units=): only the index tables change), frames [B][U] -- bit-identical per unit for both CNN denoisers"""
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    from oracle.nets import cpu_data_parallel, synth_ddnet_weights, synth_fastdvdnet_weights
+    U = 2
+    pr = problems(U, 64, 64, 8, seed0=51)
+    net = make_ffdnet(ffdnet_state_dict) if denoiser == 'ffdnet_color' else cpu_data_parallel(synth_fastdvdnet_weights(0))
+    dd = synth_ddnet_weights(0)
+    kw = dict(model=net, model_demosaic=dd, conv_precision='f32')
+    single = [AdmmRun(y, Phi, denoiser, True, X_orig=orig, **kw) for y, Phi, orig in pr]
+    batch = AdmmRun([p[0] for p in pr], [p[1] for p in pr], denoiser, True, X_orig=[p[2] for p in pr], units=U, **kw)
+    for k in range(3):
+        for r in single:
+            r.step(12 / 255, last=(k == 2))
+        batch.step(12 / 255, last=(k == 2))
+        got = batch.result_mosaic()
+        for u in range(U):
+            assert torch.equal(got[u], single[u].result_mosaic()), (k, u)
+    ps = batch.psnr_all()
+    for u in range(U):
+        assert np.abs(np.array(ps[u]) - np.array(single[u].psnr_all())).max() < 1e-9
+        assert torch.equal(batch.out_rgb.view(8, U, 3, 64, 64)[:, u], single[u].out_rgb)
+
+
 def test_unit_batch_split_before_the_finetune_event(ffdnet_state_dict):
     """BASELINE configs[4] shape of work: the tiles of a cube share the weights until the online finetune fires, then every
     tile trains ITS OWN copy.  Batch for k < 3, split(), event at k = 3 on per-unit models -> identical to single-unit runs
@@ -149,7 +209,7 @@ def test_unit_batch_argument_errors(ffdnet_state_dict):
     with pytest.raises(ValueError, match='sequences of 3'):
         AdmmRun(ys, Phis, 'tv', False, units=3)
     with pytest.raises(ValueError, match='unit batches'):
-        AdmmRun(ys, Phis, 'fastdvd_color', True, model=cpu_data_parallel(synth_fastdvdnet_weights(0)), units=2)
+        AdmmRun(ys, Phis, 'tv', False, Phi_sum=torch.ones(32, 32), units=2)
     with pytest.raises(ValueError, match='shape of the first'):
         AdmmRun([ys[0], ys[1][:16]], [Phis[0], Phis[1][:16]], 'tv', False, units=2)
     with pytest.raises(ValueError, match='2048'):               # 24 x 24 mosaic: partial blocks would straddle units

@@ -200,3 +200,20 @@ def test_fixed_total_timed_job_gloo(n_units, tiled, batched):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+@pytest.mark.parametrize('n_units,tiled', [(8, False), (16, True)])
+def test_fixed_total_timed_job_gloo_world8(n_units, tiled):
+    """the driver's N = 8 shape of BASELINE configs[3] / [4]: 8 cubes one per rank, 16 tiles two per rank (unit batches), ONE
+    gather to rank 0 -- eight gloo ranks on the CPU (the 8-GPU node is the driver's to launch)"""
+    world = 8
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    port = 35500 + (os.getpid() + n_units) % 2000
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_units, tiled, ret, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True

@@ -23,6 +23,7 @@ SIGNATURES = {
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8w6': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8w6_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w6_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
@@ -81,4 +82,19 @@ def conv3x3_c8p(x, packed_winop, Cout, relu=False, residual=None, mask_src=None,
     flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0)
     _lib.check(load().scipnp_conv3x3_c8p(_p(x), _p(packed_winop), _p(out), _p(residual), _p(mask_src), n, cg * 8, Cout, h, w, flags,
                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8p')
+    return out
+
+
+def conv3x3_c8w6(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
+    """scipnp_conv3x3_c8w4's convolution on the three-waves-per-SIMD laboratory kernel (csrc/conv_wino4x.hip): same packing,
+    bit-identical results, no PixelShuffle store"""
+    import torch
+    from adaptivepnp_sci_amd import _lib
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
+    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0))
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    _lib.check(load().scipnp_conv3x3_c8w6(P(x), P(packed_wino4), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
+                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8w6')
     return out

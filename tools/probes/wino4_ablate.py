@@ -44,7 +44,7 @@ def timed(fn, reps=5, inner=20):
 
 print(f'F(2x2) kernel               {timed(lambda: ops.conv3x3_c8w(x8, p2, c, relu=True, out=out)):7.1f} us')
 print(f'F(4x4) kernel (product)     {timed(lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=out)):7.1f} us')
-print(f'F(4x4) three waves per SIMD {timed(lambda: ops.conv3x3_c8w6(x8, p4, c, relu=True, out=out)):7.1f} us')
+print(f'F(4x4) three waves per SIMD {timed(lambda: diaglib.conv3x3_c8w6(x8, p4, c, relu=True, out=out)):7.1f} us')
 print('ablations of scipnp_conv3x3_c8w' + KER)
 MASKS = [int(v) for v in os.environ['W4_MASKS'].split(',')] if os.environ.get('W4_MASKS') else \
     (1, 2, 4, 8, 16, 32, 3, 5, 9, 10, 12, 14, 6, 7, 15, 39, 47, 48, 49, 55, 63, 128)

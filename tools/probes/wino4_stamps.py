@@ -32,7 +32,7 @@ e0.record()
 _lib.check(stamped(P(x8), P(p4), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
 e1.record()
 torch.cuda.synchronize()
-(ops.conv3x3_c8w6 if KER == '6' else ops.conv3x3_c8w4)(x8, p4, c, relu=True, out=ref)
+(diaglib.conv3x3_c8w6 if KER == '6' else ops.conv3x3_c8w4)(x8, p4, c, relu=True, out=ref)
 print('stamped launch', round(e0.elapsed_time(e1) * 1e3, 1), 'us; equals the product kernel:', bool(torch.equal(out, ref)))
 s = st.cpu().numpy().reshape(nwg, 128).astype(np.float64)
 CG = c // 8

@@ -5,6 +5,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
+import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
 
 g = torch.Generator().manual_seed(1)
 ok = True
@@ -16,7 +18,7 @@ for (n, cin, cout, h, w) in ((1, 16, 32, 8, 64), (2, 24, 40, 13, 70), (1, 96, 96
     msk = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
     for kw in ({}, {'relu': True}, {'relu': True, 'residual': res, 'head': True}, {'mask_src': msk, 'residual': res}):
         a = ops.conv3x3_c8w4(x, p4, cout, **kw)
-        b = ops.conv3x3_c8w6(x, p4, cout, **kw)
+        b = diaglib.conv3x3_c8w6(x, p4, cout, **kw)
         same = bool(torch.equal(a, b))
         ok &= same
         if not same:
@@ -31,7 +33,7 @@ pk = ops.pack_conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.randn(c
 p4 = ops.pack_conv3x3_wino4(pk, c, c)
 o4, o6 = torch.empty_like(x8), torch.empty_like(x8)
 fns = {'c8w4 (2 waves/SIMD)': lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=o4),
-       'c8w6 (3 waves/SIMD)': lambda: ops.conv3x3_c8w6(x8, p4, c, relu=True, out=o6)}
+       'c8w6 (3 waves/SIMD)': lambda: diaglib.conv3x3_c8w6(x8, p4, c, relu=True, out=o6)}
 for f in fns.values():
     for _ in range(200):
         f()
