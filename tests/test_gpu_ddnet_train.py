@@ -19,16 +19,19 @@ FULL = ('weight_tensor_in', 'weight_tensor_in2', 'weight_tensor_out', 'temp1.inc
         'temp11.fusion.convblock.2.weight', 'temp11.outc.convblock.2.weight')
 
 
-def _run(precision, monkeypatch, hook=None):
+GOLDS = ('ddnet_finetune_32x48x8', 'ddnet_finetune_64x64x8')
+
+
+def _run(precision, monkeypatch, hook=None, gold='ddnet_finetune_32x48x8', steps=None):
     monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
     from adaptivepnp_sci_amd import ddnet_train
     from adaptivepnp_sci_amd import test_ddnet as ddnet_plugin
     from oracle.nets import cpu_data_parallel, synth_ddnet_weights
     from oracle.sci_ops import one_to_three_channel
-    g = load_gold('ddnet_finetune_32x48x8')
+    g = load_gold(gold)
     net = cpu_data_parallel(synth_ddnet_weights(0))
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-    args = types.SimpleNamespace(dm_update=True, dm_lr=float(g['lr']), dm_update_per_iter=int(g['steps']))
+    args = types.SimpleNamespace(dm_update=True, dm_lr=float(g['lr']), dm_update_per_iter=int(g['steps']) if steps is None else steps)
     ddnet_train.GRAD_HOOK = hook
     try:
         out, model = ddnet_plugin(one_to_three_channel(torch.from_numpy(g['mosaic'])).cuda(), None, None, net, True, args)
@@ -38,10 +41,11 @@ def _run(precision, monkeypatch, hook=None):
     return g, out, net, sd0
 
 
+@pytest.mark.parametrize('gold', GOLDS)
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
-def test_ddnet_online_finetune_matches_reference(precision, monkeypatch, capsys):
+def test_ddnet_online_finetune_matches_reference(precision, gold, monkeypatch, capsys):
     grads = {}
-    g, out, net, sd0 = _run(precision, monkeypatch, hook=grads.update)
+    g, out, net, sd0 = _run(precision, monkeypatch, hook=grads.update, gold=gold)
     # the demosaicked cube after the update (the final pass runs in the engine's precision)
     assert rel_l2(out.cpu().numpy(), g['out']) <= 1e-5
     # losses, as the reference prints them
@@ -55,9 +59,16 @@ def test_ddnet_online_finetune_matches_reference(precision, monkeypatch, capsys)
         got = float(torch.linalg.vector_norm(gv.double()))
         assert abs(got / want - 1) <= 1e-4, (k, got, want)
         if k in FULL:
+            # element by element.  The ReLU behind a DenBlock's FIRST convolution masks dZ_0, so an input there within round-off
+            # of zero -- decided by the last bit, as for FastDVDnet (tests/test_gpu_solver.py, ..._under_its_own_relu_masks) --
+            # reaches that convolution's weight gradient and the input gates and nothing else: those tensors carry the 1e-3 /
+            # 1e-4 a flip is worth (measured 2.8e-5 .. 1.6e-4 and 3.9e-6 on the 64 x 64 x 8 problem, 2e-7 on 32 x 48 x 8, in BOTH
+            # precisions: the trainer's backward is fp32 either way); every other tensor agrees to arithmetic accuracy, 1e-5
+            # (measured <= 4.1e-7)
             err = rel_l2(gv.cpu().numpy(), g['grad_' + key])
             worst = max(worst, err)
-            assert err <= 1e-4, (k, err)
+            gate = 1e-3 if k.endswith('inc_1.convblock.0.weight') else 1e-4 if k.startswith('weight_tensor_in') else 1e-5
+            assert err <= gate, (k, err, gate)
     assert len(grads) == 53 and worst > 0                      # 16 + 16 + 18 conv weights, three gate tensors
     # the unused `inc` blocks were not touched (no gradient -> Adam skips them); everything else moved by what the reference's
     # fresh-Adam steps moved it (|update| = lr per step wherever |g| >> 1e-8)
@@ -80,6 +91,33 @@ def test_ddnet_online_finetune_matches_reference(precision, monkeypatch, capsys)
             dev_ = np.abs(d.numpy() - ref)[sel]
             total = float(g['lr']) * int(g['steps'])
             assert np.quantile(dev_, 0.99) <= 0.05 * total + 1e-12 and dev_.max() <= 0.25 * total, (k, float(dev_.max()))
+
+
+@pytest.mark.parametrize('gold', GOLDS)
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_ddnet_first_adam_step_is_the_references_element_by_element(precision, gold, monkeypatch):
+    """The FIRST step of the reference's fresh Adam moves every element by -lr g / (|g| + 1e-8) = -lr sign(g) (1 - 1e-8 / |g|):
+    wherever the reference's gradient is not on Adam's eps floor (|g| >= 1e-6) the update is fixed to the rounding of the weight
+    itself whatever the last bits of g are -- an exact, element-by-element check of the HIP Adam against `delta1_*` captured
+    from the reference (tools/make_golden.py ddnettune), EVERY such element, no quantiles."""
+    g, _out, net, sd0 = _run(precision, monkeypatch, gold=gold, steps=1)
+    lr = float(g['lr'])
+    n_cmp = n_floor = 0
+    for k, v in net.state_dict().items():
+        kk = k.replace('module.', '', 1)
+        if kk not in FULL:
+            continue
+        key = kk.replace('.', '_')
+        d = (v.float() - sd0[k].float()).numpy()
+        ref, gref = g['delta1_' + key], g['grad_' + key]
+        live = np.abs(gref) >= 1e-6
+        n_cmp, n_floor = n_cmp + int(live.sum()), n_floor + int((~live).sum())
+        ulp = np.spacing(np.abs(sd0[k].float().numpy()).astype(np.float32))
+        assert np.all(np.sign(d[live]) == -np.sign(gref[live])), k
+        assert np.all(np.abs(np.abs(d[live]) - lr) <= 0.011 * lr + ulp[live]), (k, float(np.abs(np.abs(d[live]) - lr).max()))
+        assert np.all(np.abs(d - ref)[live] <= 1e-3 * lr + 2 * ulp[live]), (k, float(np.abs(d - ref)[live].max()))
+        assert np.abs(d).max() <= 1.001 * lr + ulp.max()                 # nobody moves further than one Adam step can
+    assert n_cmp > 2000 and n_floor < n_cmp, (n_cmp, n_floor)
 
 
 def test_ddnet_finetune_with_zero_steps_is_the_plain_pass(monkeypatch):

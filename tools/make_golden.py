@@ -609,18 +609,24 @@ def g_ddnet():
 
 
 def g_ddnettune():
+    """DDnet's own online finetune, two problems: 32 x 48 x 8 (round 4) and 64 x 64 x 8 (round 5)"""
+    _ddnettune(32, 48, 8, 29, 'ddnet_finetune_32x48x8')
+    _ddnettune(64, 64, 8, 31, 'ddnet_finetune_64x64x8')
+
+
+def _ddnettune(H, W, B, seed, name):
     """DDnet's own online finetune (`args.dm_update`, packages/DDnet/DDnet_test.py:218-296): two steps of { all frames through
     the network, MSE(input cube, CFA samples of the output), a NEW Adam over every parameter, backward, step }, then the pass.
     Captured from the reference: the output cube, the reference's `.grad` after the first backward (every gate tensor and
-    one conv weight per layer type in full, the norm of every tensor), the weights' change, the losses."""
+    one conv weight per layer type in full, the norm of every tensor), the weights' change after the FIRST step (`delta1_*`: a
+    fresh Adam moves every element by lr g / (|g| + 1e-8), i.e. by lr sign(g) wherever |g| >> 1e-8) and after both, the losses."""
     import types
     from models.network_demosaicking import DDnet as RefDDnet
     onet = ON.synth_ddnet_weights(0)
     rnet = RefDDnet()
     rnet.load_state_dict(onet.state_dict(), strict=True)
     sd0 = {k: v.clone() for k, v in onet.state_dict().items()}
-    rng = np.random.default_rng(29)
-    H, W, B = 32, 48, 8
+    rng = np.random.default_rng(seed)
     # a smooth scene seen through the CFA, so that the demosaicker's loss gradient has structure
     yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
     mosaic = np.stack([0.5 + 0.3 * np.sin(0.21 * xx + 0.13 * yy + 0.4 * t) * np.cos(0.17 * yy - 0.1 * t) for t in range(B)], 2)
@@ -630,11 +636,18 @@ def g_ddnettune():
     grads = {}
     orig_step = torch.optim.Adam.step
 
+    after1 = {}
+
     def step(opt, *a, **k):
-        if not grads:
+        first = not grads
+        if first:
             for (n, p_) in rnet.named_parameters():
                 grads[n] = None if p_.grad is None else p_.grad.detach().clone()
-        return orig_step(opt, *a, **k)
+        r_ = orig_step(opt, *a, **k)
+        if first:
+            for (n, p_) in rnet.named_parameters():
+                after1[n] = p_.detach().clone()
+        return r_
     torch.optim.Adam.step = step
     try:
         seed_all()
@@ -676,8 +689,9 @@ def g_ddnettune():
         if k in full:
             out['grad_' + key] = g_.numpy()
             out['delta_' + key] = (rsd[k].float() - sd0[k].float()).numpy()
+            out['delta1_' + key] = (after1[k].float() - sd0[k].float()).numpy()
     print(f'   losses {trace}; |d weight_tensor_out| {out["dnorm_weight_tensor_out"]:.3e}')
-    save('ddnet_finetune_32x48x8', mosaic=mosaic.numpy(), out=ref.detach().numpy(), losses=np.array(trace), lr=np.float64(2e-5),
+    save(name, mosaic=mosaic.numpy(), out=ref.detach().numpy(), losses=np.array(trace), lr=np.float64(2e-5),
          steps=np.int32(2), **out)
 
 
