@@ -274,8 +274,8 @@ def compact_line(full, detail_path=None):
     rf = full.get('roofline')
     if rf:
         out['roofline'] = _pick_keys(rf, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch',
-                                          'flop_per_launch', 'avg_launch_ms', 'launch_shape', 'direct_form_equivalent_TFLOPs',
-                                          'peak_measured'))
+                                          'flop_per_launch', 'avg_launch_ms', 'rocprof_kernel_us', 'launch_shape',
+                                          'direct_form_equivalent_TFLOPs', 'peak_measured'))
         out['roofline']['traffic'] = rf.get('traffic')
         out['roofline']['kernel'] = str(rf.get('kernel', '')).split(' (')[0]
     else:
@@ -283,7 +283,7 @@ def compact_line(full, detail_path=None):
     ph = full.get('phi_step')
     if ph:
         out['phi_step'] = _pick_keys(ph, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch',
-                                          'launch_us', 'host_loop_us'))
+                                          'launch_us', 'host_loop_us', 'rocprof_kernel_us'))
         out['phi_step']['timing'] = 'hipGraph replay'
         out['phi_step']['kernel'] = str(ph.get('kernel', '')).split(' (')[0]
         if ph.get('non_denoiser_chain'):
@@ -392,6 +392,9 @@ def emit(full, tag):
 
 
 # ------------------------------------------------------------------------------------------------ PMC traffic (child runs)
+ROCPROF_KERNEL_US = None      # {kernel: median duration in us} of pmc_traffic()'s plain --kernel-trace child pass
+
+
 def pmc_traffic(timeout_s=150):
     """HBM bytes per launch of the body-layer convolutions and the projection, measured by rocprofv3 PMC passes run as
     CHILD processes of this bench invocation on tools/pmc_probe.py (same kernels, same shapes, same cube): FETCH_SIZE and
@@ -404,6 +407,7 @@ def pmc_traffic(timeout_s=150):
     import glob
     tmp = tempfile.mkdtemp(prefix='scipnp_pmc_', dir='/tmp')
     vals = {}
+    kernel_us = None
     try:
         for name in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(tmp, name)
@@ -417,10 +421,25 @@ def pmc_traffic(timeout_s=150):
                 for row in csv.DictReader(open(f)):
                     if row['Counter_Name'] == name:
                         vals.setdefault(row['Kernel_Name'], {}).setdefault(name, []).append(float(row['Counter_Value']))
+        # third pass, no counters: the kernels' durations as rocprofv3 --kernel-trace reports them (what profiles/ holds), so that
+        # the line's event / hipGraph timings can be read against the profiler's own clock in the SAME run
+        d = os.path.join(tmp, 'trace')
+        r = subprocess.run([exe, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
+                            os.path.join(ROOT, 'tools', 'pmc_probe.py')], cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+        if r.returncode == 0:
+            dur = {}
+            for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    dur.setdefault(row['Kernel_Name'], []).append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-3)
+            # (the first launch of a kernel includes its code-object load: median, not mean)
+            kernel_us = {k.replace('scipnp::', '').replace('void ', ''): float(np.median(v)) for k, v in dur.items()}
     except Exception as e:                                  # noqa: BLE001 -- best effort, the bench line says what happened
         return None, f'{type(e).__name__}: {e}'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    global ROCPROF_KERNEL_US
+    ROCPROF_KERNEL_US = kernel_us
     out = {}
     for k, dct in vals.items():
         if 'FETCH_SIZE' in dct and 'WRITE_SIZE' in dct:
@@ -693,6 +712,7 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
     achieved = flop / body_launch_s
     return {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / peak,
             'traffic': tr, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+            'rocprof_kernel_us': (_pick(ROCPROF_KERNEL_US, kname.split('<')[0] + '<' + {'conv3x3_c8w4_kernel': '0, 0', 'conv3x3_c8w_kernel': '0, 4', 'conv3x3_c8_kernel': '3, 0', 'conv3x3_c8s_kernel': '3, 0'}.get(kname.split('<')[0], '')) if shape is None else None),
             'algorithmic_bytes_per_launch': body_bytes, 'kernel': kname, 'launch_shape': [hs, ws, bs],
             'flop_per_launch': flop, 'avg_launch_ms': body_launch_s * 1e3,
             'direct_form_flop_per_launch': body_flop, 'direct_form_equivalent_TFLOPs': direct_rate / 1e12,
@@ -787,6 +807,11 @@ def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
             'in_step': {'launch_us': phi_s * 1e6, 'achieved': phi_bytes / phi_s / 1e9, 'frac': phi_bytes / phi_s / PEAK_HBM,
                         'note': 'event pair around one ~8 us launch: includes ~2-3 us of event / launch overhead'},
             'traffic': _pick(traffic, 'pm_project_kernel'), 'traffic_source': traffic_src,
+            # the same kernel's duration in a rocprofv3 --kernel-trace child pass of THIS run (one isolated launch, dispatch ramp and
+            # drain included: what profiles/ shows); `launch_us` is the sustained back-to-back rate, where they overlap
+            'rocprof_kernel_us': _pick(ROCPROF_KERNEL_US, 'pm_project_kernel'),
+            'state_note': 'the 36 MB state of a 512x512x8 cube stays in the 256 MB Infinity Cache between launches: `frac` above the '
+                          'HBM stream rate is cache bandwidth; `large_state` (570 MB per launch) is the HBM figure',
             'peak_measured': measured.get('hbm_read_GBs'), 'large_state': phi_large,
             'frac_of_measured_hbm_read_peak': (phi_bytes / b2b / 1e9 / measured['hbm_read_GBs']) if measured.get('hbm_read_GBs') else None}
 
@@ -932,6 +957,59 @@ def config_records(ffd_sd, budget_s=60.0):
     for prec in PRECISIONS:
         rec['parity'][prec] = {'max_rel_l2_per_iterate': max(rel_l2(gpu_it[prec][k], o['theta_iterates'][k]) for k in range(n_or))}
     out['fastdvd_512'] = rec
+
+    # ---- the reference drivers' DEFAULT mode (deep_demosaicking=True, two_stage_ADMM_Online_FFD_Warm.py:28): FFDNet + DDnet per
+    # iteration at 512x512x8 (dvp...:192-194; synthetic DDnet weights: the checkpoint is absent from the reference snapshot)
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=2)
+    tv = AdmmRun(y, Phi, 'tv', False)
+    for _ in range(10):
+        tv.step(0)
+    warm = tv.result_mosaic().cpu().numpy()
+    dnet = synth.synth_ddnet(0)
+    rec = {'workload': "the reference drivers' default: two-stage ADMM + FFDNet-colour with DDnet deep demosaicking in place of Malvar, "
+                       '512x512x8, sigma 25/255; synthetic DDnet weights (checkpoint absent from the reference snapshot)',
+           'dominant_kernel': 'conv3x3 kernels of the 8 DDnet DenBlock evaluations per frame triplet (3 x temp1, 3 x temp11 at half '
+                              'resolution + bilinear x2 + fusion, 2 x temp2) and the 12 FFDNet layers'}
+    gpu_it = {}
+    for prec in PRECISIONS:
+        net = FFDNet()
+        net.load_state_dict(ffd_sd)
+        run = AdmmRun(y, Phi, 'ffdnet_color', True, x0_bayer=warm, X_orig=orig, model=net, model_demosaic=dnet, conv_precision=prec)
+        ms = _ms_per_iter(run, SIGMA, 5, 2)
+        with single_stream_launch_log() as log:
+            for _ in range(2):
+                run.step(SIGMA)
+            torch.cuda.synchronize()
+            table = layer_table(log)
+        ex = sum(r['executed_flop_per_launch'] * r['launches'] for r in table) / 2
+        alg = sum(r['algorithmic_flop_per_launch'] * r['launches'] for r in table) / 2
+        peak = PEAK_FP32_MFMA if prec == 'f32' else PEAK_F16_MFMA
+        rec[prec] = {'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'peak_TFLOPs': peak / 1e12,
+                     'padded_launch_flop_per_iteration': alg, 'executed_matrix_flop_per_iteration': ex,
+                     'frac': min(alg, ex) / (ms * 1e-3) / peak, 'matrix_pipe_duty': ex / (ms * 1e-3) / peak,
+                     'conv_launch_us_per_iteration_single_stream': sum(r['total_us'] for r in table) / 2,
+                     'layers': [{k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in r.items()} for r in table],
+                     'layers_note': 'one stream, HIP event pair per launch, 2 iterations; launches = per 2 iterations; FLOPs of the '
+                                    'PADDED launch shapes (DDnet widths 20 / 40 / 80 run in 24 / 40 / 80-channel c8 tensors)'}
+        del run
+        net2 = FFDNet()
+        net2.load_state_dict(ffd_sd)
+        with conv_precision(prec):
+            gpu_it[prec] = gpu_iterates(lambda: S.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [2], False, [SIGMA],
+                                                                             x0_bayer=warm, X_orig=orig, model_denoise=net2,
+                                                                             model_demosaic=dnet, logf=io.StringIO()))
+    if time.perf_counter() - t_start < 2.0 * budget_s:
+        onet = ON.OracleFFDNet()
+        onet.load_state_dict(ffd_sd)
+        onet.eval()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            o = OS.two_stage_admm(y, Phi, 'ffdnet_color', [2], [SIGMA], x0_bayer=warm, X_orig=orig, model_denoise=onet,
+                                  model_demosaic=ON.synth_ddnet_weights(0))
+        rec['parity'] = {'iterations': 2, 'gate': 1e-5, 'oracle_s_per_iteration': (time.perf_counter() - t0) / 2}
+        for prec in PRECISIONS:
+            rec['parity'][prec] = {'max_rel_l2_per_iterate': max(rel_l2(gpu_it[prec][k], o['theta_iterates'][k]) for k in range(2))}
+    out['ddnet_512'] = rec
 
     # ---- configs[4], one 256x256x16 tile with the online finetune (per-tile model copy), FFDNet
     y, Phi, orig = synth.make_problem(256, 256, 16, seed=3)
