@@ -166,7 +166,7 @@ class TwoStageFfdnetArgs(C.Structure):
                 ('packed_wino', C.c_void_p), ('net_in_c8', C.c_void_p),
                 ('overflow_word', C.c_void_p), ('side_stream', C.c_void_p),
                 ('side_fork_event', C.c_void_p), ('side_join_event', C.c_void_p), ('packed_wino4', C.c_void_p),
-                ('units', C.c_int)]
+                ('units', C.c_int), ('conv_form', C.c_int)]
 
     def __init__(self, **kw):
         super().__init__(C.sizeof(type(self)), **kw)

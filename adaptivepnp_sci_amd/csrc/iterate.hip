@@ -66,7 +66,12 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
                    "scipnp_twostage_ffdnet_args.struct_size is %zu, this library's block has %zu bytes (set it to sizeof the "
                    "struct of the header you compile against, and rebuild against include/scipnp.h of this library)",
                    a->struct_size, sizeof(scipnp_twostage_ffdnet_args));
-    const bool f32 = a->packed_wino != nullptr;
+    SCIPNP_REQUIRE(a->conv_form >= 0 && a->conv_form <= SCIPNP_CONV_F32_WINO_F4, "conv_form %d: 0 (inferred), 1 split-fp16, 2 fp32 F(2x2), 3 fp32 F(4x4)", a->conv_form);
+    SCIPNP_REQUIRE(a->conv_form != SCIPNP_CONV_SPLIT_F16 || (a->packed_split && a->net_in_c8s), "conv_form split-fp16 needs packed_split and net_in_c8s");
+    SCIPNP_REQUIRE(a->conv_form < SCIPNP_CONV_F32_WINO_F2 || (a->packed_wino && a->net_in_c8), "conv_form fp32 needs packed_wino and net_in_c8");
+    SCIPNP_REQUIRE(a->conv_form != SCIPNP_CONV_F32_WINO_F4 || a->packed_wino4, "conv_form fp32 F(4x4) needs packed_wino4");
+    const bool f32 = a->conv_form ? a->conv_form != SCIPNP_CONV_SPLIT_F16 : a->packed_wino != nullptr;
+    const float* const* const p4 = a->conv_form == SCIPNP_CONV_F32_WINO_F2 ? nullptr : a->packed_wino4;
     SCIPNP_REQUIRE(a->theta && a->b && a->x && a->Phi && a->y && a->Phisum && a->w && a->x_rgb && a->net_out_c8 && a->scratch0 &&
                    a->scratch1 && (f32 ? (a->net_in_c8 != nullptr) : (a->net_in_c8s && a->packed_split)),
                    "null pointer in argument block");
@@ -82,7 +87,7 @@ int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nb
                                   f32 ? nullptr : a->net_in_c8s, M, N, BU, inv_rho, inv_tau, a->sigma, s);
     if (rc) return rc;
     if (f32) {
-        rc = scipnp_ffdnet_forward_c8w4(a->net_in_c8, a->net_out_c8, a->packed_wino, a->packed_wino4, a->nb, a->nc,
+        rc = scipnp_ffdnet_forward_c8w4(a->net_in_c8, a->net_out_c8, a->packed_wino, p4, a->nb, a->nc,
                                         (float*)a->scratch0, (float*)a->scratch1, BU, M, N, s);
     } else {
         // the solve's own range-guard word for the launches of this call; the thread's binding is restored afterwards

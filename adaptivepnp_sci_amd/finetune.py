@@ -34,8 +34,8 @@ def _ptr(t):
 def _split_slabs(cin):
     """persistent workgroups of the split weight-gradient kernel = slabs x (Cin/32 input-channel blocks): keep their
     product at ~255 so that every CU of the MI355X gets one workgroup whatever the layer's input width"""
-    import os
-    env = os.environ.get('SCIPNP_WGRAD_SLABS')
+    from . import config
+    env = config.current().wgrad_slabs
     if env:
         return int(env)
     ncib = (cin + 31) // 32
@@ -64,10 +64,8 @@ def wgrad_f4_enabled():
     """the fp32 FFDNet trainer takes the weight gradients of its 32-multiple layers in the Winograd F(4x4) domain
     (csrc/wgrad_wino4.hip: 382 us against 441 us of the F(2x2) form at 96 -> 96 on 8 x 256 x 256, rounding 4.9e-6 against
     1.5e-6 of the gradient's norm, gate 1e-4: DESIGN.md section 5); SCIPNP_F32_WGRAD=f2 keeps the F(2x2) form"""
-    v = os.environ.get('SCIPNP_F32_WGRAD', 'f4').lower()
-    if v not in ('f2', 'f4'):
-        raise ValueError("SCIPNP_F32_WGRAD must be 'f2' or 'f4'")
-    return v == 'f4'
+    from . import config
+    return config.current().f32_wgrad == 'f4'
 
 
 def _wino_wgrad_fits(n, cin, cout, h, w):

@@ -56,13 +56,10 @@ def default_precision():
     Winograd F(4x4,3x3) / F(2x2,3x3) / direct kernels, csrc/conv_wino4.hip, conv_wino.hip, conv.hip) or the opt-in 'f16x3'
     (error-compensated split-fp16 operands on the fp16 MFMA, csrc/conv_split.hip: 22 significant bits per operand, fp32
     accumulation, ~1.2-1.3x faster, inside the 1e-5 / 1e-4 dB gates but NARROWER than the reference's fp32).
-    Set with SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION) or the engines' `precision=` / the solvers'
-    `conv_precision=` argument.  Applies to the FFDNet / FastDVDnet / DDnet passes and their online finetune."""
-    import os
-    p = os.environ.get('SCIPNP_CONV_PRECISION', os.environ.get('SCIPNP_FFDNET_PRECISION', 'f32'))
-    if p not in ('f32', 'f16x3'):
-        raise ValueError("SCIPNP_CONV_PRECISION must be 'f32' or 'f16x3'")
-    return p
+    Set with config.Config(precision=...) (config.use / AdmmRun(config=...)), the engines' `precision=` / the solvers'
+    `conv_precision=` argument, or SCIPNP_CONV_PRECISION (alias: SCIPNP_FFDNET_PRECISION) as the process default.  Applies to the FFDNet / FastDVDnet / DDnet passes and their online finetune."""
+    from . import config
+    return config.current().precision
 
 
 WINO_MAX_PIXELS = 1 << 25          # csrc/conv_wino.hip addresses a plane through 32-bit buffer offsets: h * w < 2^25
@@ -74,10 +71,8 @@ def f32_conv_form(h=None, w=None):
     csrc/conv_wino.hip, for the narrower layers or with SCIPNP_WINO_F4=0) or 'direct' (csrc/conv.hip) for the stride-1
     layers of the fp32 passes; SCIPNP_F32_CONV.
     Planes of h x w >= 2^25 pixels (FFDNet on frames beyond 11585 x 11585) take the direct form, which has no such bound."""
-    import os
-    f = os.environ.get('SCIPNP_F32_CONV', 'winograd')
-    if f not in ('winograd', 'direct'):
-        raise ValueError("SCIPNP_F32_CONV must be 'winograd' or 'direct'")
+    from . import config
+    f = config.current().f32_form
     if f == 'winograd' and h is not None and h * w >= WINO_MAX_PIXELS:
         return 'direct'
     return f

@@ -407,8 +407,8 @@ class WinoPacked:
 def wino_f4_enabled():
     """SCIPNP_WINO_F4=0 keeps every fp32 Winograd layer on the F(2x2,3x3) kernel; default: layers with at least 16 input and 32
     output channels run as F(4x4,3x3) (csrc/conv_wino4.hip)."""
-    import os
-    return os.environ.get('SCIPNP_WINO_F4', '1') != '0'
+    from . import config
+    return config.current().wino_f4
 
 
 def wino_f4_shape(Cin, Cout):
@@ -652,10 +652,8 @@ _SIDE_LOCK = threading.Lock()
 def side_stream_count():
     """SCIPNP_STREAMS (default 2): HIP streams a batched network pass is spread over, 1 = everything on the caller's stream"""
     import os
-    n = int(os.environ.get('SCIPNP_STREAMS', '2'))
-    if n < 1 or n > 8:
-        raise ValueError('SCIPNP_STREAMS must be 1..8')
-    return n
+    from . import config
+    return config.current().streams
 
 
 def _side_pool(n):

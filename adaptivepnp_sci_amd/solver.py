@@ -26,7 +26,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, config, ops
 from .metrics import frame_metrics
 from .nets import FFDNetEngine
 
@@ -73,10 +73,28 @@ class AdmmRun:
     two_stage=False : v = theta + b, denominator Phi_sum + gamma, b -= x - theta, reports x (:385-536)
     """
 
-    def __init__(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
-                 show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
-                 update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None,
-                 conv_precision=None, Phi_sum=None, units=None):
+    def __init__(self, *args, config=None, **kw):
+        """arguments of _construct below, plus config= (adaptivepnp_sci_amd.config.Config, default: the configuration current at
+        construction): the kernel forms of THIS solve -- precision, fp32 form, F(4x4) on / off, weight-gradient form, side
+        streams, ADMM-TV paths -- kept for its whole life: construction, every step(), split() run under it whatever the
+        environment or the caller's configuration says later.  conv_precision= is the short form of config.replace(precision=...)."""
+        from . import config as _config
+        base = config if config is not None else _config.current()
+        prec = kw.get('conv_precision', args[19] if len(args) > 19 else None)
+        self.config = base if prec is None else base.replace(precision=prec)
+        self._pinned = _config.FIELDS if config is not None else (('precision',) if prec is not None else ())
+        with _config.solve_scope(self.config, self._pinned):
+            self._construct(*args, **kw)
+
+    def step(self, *args, **kw):
+        """one ADMM iteration (see _step) under this solve's configuration"""
+        with config.solve_scope(self.config, self._pinned):
+            return self._step(*args, **kw)
+
+    def _construct(self, y_bayer, Phi_bayer, denoiser, two_stage, x0_bayer=None, X_orig=None, model=None,
+                   show_iqa=True, _lambda=1, gamma=0.01, lr_=1e-6, inital_iter=1, interval_iter=5, update_=False,
+                   update_per_iter=1, update_times=-1, logf=None, close_form_demosaic=False, model_demosaic=None,
+                   conv_precision=None, Phi_sum=None, units=None):
         """units=U (round 4): a UNIT BATCH -- y_bayer, Phi_bayer (and x0_bayer, X_orig when given) are sequences of U
         problems of ONE shape that share the denoiser weights; they are stepped by ONE launch sequence (the reference loops
         its measurements one after the other, two_stage_ADMM_Online_FFD_Warm.py:241-275).  State layout [B][U][4][M][N]
@@ -208,7 +226,7 @@ class AdmmRun:
             self._tv_defer = C.c_int(0)
             self._tv_prev_row = None
             self._row_kinds = []             # unit batches: 'flat' / 'fused' per squared-error row (see _unit_rows)
-            if os.environ.get('SCIPNP_TV_DEFER', '1') != '0':
+            if config.current().tv_defer:
                 self._tv_args.defer_state = C.pointer(self._tv_defer)
         else:
             self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
@@ -236,7 +254,7 @@ class AdmmRun:
                     self.dd_mosaic = torch.empty(B, H, W, dtype=F32, device=self.device)
 
     # ------------------------------------------------------------------ one ADMM iteration
-    def step(self, nsig, last=False):
+    def _step(self, nsig, last=False):
         B, M, N = self.BU, self.M, self.N          # (B: frames of the whole unit batch)
         k = self.k
         if self.denoiser == 'tv' and self.phi_events is None:
@@ -382,7 +400,7 @@ class AdmmRun:
 
     _SPLIT_KEEP = ('device', 'denoiser', 'two_stage', 'logf', 'H', 'W', 'B', 'M', 'N', 'iqa', 'alpha', 'rou', 'tau', '_lambda', 'gamma',
                    'lr_', 'inital_iter', 'interval_iter', 'update_', 'update_per_iter', 'update_times', 'close_form',
-                   'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic')
+                   'noise_source', '_sse_fixed', 'conv_precision', 'model_demosaic', 'config', '_pinned')
 
     def prepare_split(self, models=None):
         """Build the U single-unit runs split() hands out -- their state buffers, RGB buffers, TV plans / network engines
@@ -391,6 +409,10 @@ class AdmmRun:
         prepares on its own when this was not called."""
         if self.U == 1:
             return
+        with config.solve_scope(self.config, self._pinned):
+            self._prepare_split(models)
+
+    def _prepare_split(self, models):
         U, B, M, N = self.U, self.B, self.M, self.N
         self._split_runs = []
         for u in range(U):
@@ -750,7 +772,7 @@ def _run_schedule(run, sigma, iter_max, log=None):
     """the iterations of one solver call; `log`: _LogStream (lines stream out during the loop) or None"""
     total = sum(iter_max)
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
-            and os.environ.get('SCIPNP_HIPGRAPH', '0') == '1'):
+            and config.current().hipgraph):
         _run_tv_graphed(run, total)
         if log is not None:                              # graph replay: the values exist only after the replays
             k = 0

@@ -143,17 +143,11 @@ def _usable_cpus():
     return usable_cpus()
 
 
-@contextlib.contextmanager
 def conv_precision(p):
-    old = os.environ.get('SCIPNP_CONV_PRECISION')
-    os.environ['SCIPNP_CONV_PRECISION'] = p
-    try:
-        yield
-    finally:
-        if old is None:
-            os.environ.pop('SCIPNP_CONV_PRECISION', None)
-        else:
-            os.environ['SCIPNP_CONV_PRECISION'] = old
+    """the convolution precision for everything constructed / stepped inside the block (adaptivepnp_sci_amd.config: no
+    environment variable is touched)"""
+    from adaptivepnp_sci_amd import config
+    return config.use(precision=p)
 
 
 def rel_l2(a, b):
@@ -554,19 +548,14 @@ def layer_table(log, real_macs=None):
 
 @contextlib.contextmanager
 def single_stream_launch_log():
-    """ops.LAUNCH_LOG installed and SCIPNP_STREAMS=1: event pairs around overlapping launches would time each other"""
-    from adaptivepnp_sci_amd import ops
-    old = os.environ.get('SCIPNP_STREAMS')
-    os.environ['SCIPNP_STREAMS'] = '1'
+    """ops.LAUNCH_LOG installed and one stream (config.use(streams=1)): event pairs around overlapping launches would time each other"""
+    from adaptivepnp_sci_amd import config, ops
     ops.LAUNCH_LOG = log = []
     try:
-        yield log
+        with config.use(streams=1):
+            yield log
     finally:
         ops.LAUNCH_LOG = None
-        if old is None:
-            os.environ.pop('SCIPNP_STREAMS', None)
-        else:
-            os.environ['SCIPNP_STREAMS'] = old
 
 
 # ------------------------------------------------------------------------------------------------ the timed runs
@@ -578,21 +567,12 @@ def time_precision(prec, args, ctx):
     dist, rank, world, dev, cdev = ctx['dist'], ctx['rank'], ctx['world'], ctx['dev'], ctx['coll_dev']
     direct, f2 = prec == 'f32_direct', prec == 'f32_f2'
     # the fp32 pass in direct form (csrc/conv.hip), or with its body layers as Winograd F(2x2,3x3) instead of F(4x4,3x3)
-    override = {'SCIPNP_F32_CONV': 'direct'} if direct else {'SCIPNP_WINO_F4': '0'} if f2 else {}
-    saved = {k: os.environ.get(k) for k in override}
-    os.environ.update(override)
-    try:
-        run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'],
-                      model=ctx['net'], conv_precision='f32' if (direct or f2) else prec)
-        if f2:                                   # (the kernel choice is read at launch time: keep it for this run's launches)
-            for pw in run.eng.packed_wino:
-                pw.f4 = None
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    from adaptivepnp_sci_amd import config
+    cfg = config.current().replace(precision='f32' if (direct or f2) else prec, f32_form='direct' if direct else 'winograd',
+                                   wino_f4=not f2)
+    # (the run keeps `cfg` for its whole life -- construction and every step -- whatever the process default says)
+    run = AdmmRun(ctx['y_d'], ctx['Phi_d'], 'ffdnet_color', True, x0_bayer=ctx['warm'], X_orig=ctx['orig_d'], model=ctx['net'],
+                  config=cfg)
 
     def barrier():
         if dist is not None:
@@ -603,8 +583,9 @@ def time_precision(prec, args, ctx):
     # matrix load to reach its steady clocks (tools/probes/step_times_probe.py); a production reconstruction lives in the
     # steady state, a --steps 5 run would measure the ramp.  The denoiser pass on a zeroed input, solver state untouched.
     (run.eng.in_c8s if run.eng.precision == 'f16x3' else run.eng.in_c8).zero_()
-    for _ in range(args.preheat):
-        run.eng.forward()
+    with config.solve_scope(run.config, config.FIELDS):
+        for _ in range(args.preheat):
+            run.eng.forward()
     for _ in range(args.warmup):
         run.step(SIGMA)
     if dist is not None:

@@ -119,8 +119,9 @@ static void pnp_solve(pnp_solve_t* job) {
     a.theta = theta; a.b = b; a.x = x; a.Phi = Phi; a.y = y; a.Phisum = Phisum;
     a.w = dmalloc(RGB * 4); a.x_rgb = dmalloc(RGB * 4); a.out_rgb = NULL;
     a.net_out_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4);
-    if (f32) { a.net_in_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4); a.packed_wino = packed_w; a.packed_wino4 = packed_w4; }
-    else { a.net_in_c8s = dmalloc((size_t)B * 2 * 2 * M * N * 8 * 2); a.packed_split = packed; }
+    /* conv_form names the arithmetic the pointers must provide (a mismatch is refused, never run in another form) */
+    if (f32) { a.net_in_c8 = dmalloc((size_t)B * 2 * M * N * 8 * 4); a.packed_wino = packed_w; a.packed_wino4 = packed_w4; a.conv_form = SCIPNP_CONV_F32_WINO_F4; }
+    else { a.net_in_c8s = dmalloc((size_t)B * 2 * 2 * M * N * 8 * 2); a.packed_split = packed; a.conv_form = SCIPNP_CONV_SPLIT_F16; }
     a.nb = nb; a.nc = nc;
     a.scratch0 = dmalloc((size_t)B * nc * M * N * 4); a.scratch1 = dmalloc((size_t)B * nc * M * N * 4);
     a.rho = 1.0; a.alpha = 1.0; a.tau = 100.0; a.sigma = sigma;

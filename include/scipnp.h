@@ -497,7 +497,17 @@ typedef struct {
      * [units][4][M][N], RGB buffers and network buffers for B*units frames (frame f = t*units + u), sse_part with
      * B*units frames of partials.  Every unit's numbers are bit-identical to its own single-unit call. */
     int units;
+    /* The arithmetic of the network pass, named (round 5; mirrors adaptivepnp_sci_amd.config.Config: precision / wino_f4).
+     * 0: inferred from the pointers as before (packed_wino != NULL: fp32, with the F(4x4) kernel where packed_wino4[l] != NULL);
+     * SCIPNP_CONV_SPLIT_F16 (1): split-fp16 -- packed_split and net_in_c8s required;
+     * SCIPNP_CONV_F32_WINO_F2 (2): fp32 Winograd F(2x2,3x3) on every layer -- packed_wino and net_in_c8 required, packed_wino4 ignored;
+     * SCIPNP_CONV_F32_WINO_F4 (3): fp32 with F(4x4,3x3) where packed -- packed_wino, packed_wino4 and net_in_c8 required.
+     * A block whose pointers do not provide the named form is refused (SCIPNP_EINVAL), never silently run in another one. */
+    int conv_form;
 } scipnp_twostage_ffdnet_args;
+#define SCIPNP_CONV_SPLIT_F16 1
+#define SCIPNP_CONV_F32_WINO_F2 2
+#define SCIPNP_CONV_F32_WINO_F4 3
 int scipnp_twostage_ffdnet_iterate(const scipnp_twostage_ffdnet_args* a, int* nblocks, scipnp_stream_t s);
 
 /* ADMM-TV iteration of either solver (dvp...:121-160, :265-271 two-stage; :385-407, :500-509 one-stage):

@@ -91,6 +91,12 @@ def test_iterate_entries_refuse_a_block_of_another_size():
     a.struct_size = 0
     assert lib.scipnp_twostage_ffdnet_iterate(C.byref(a), None, None) == -1
     assert 'struct_size' in lib.scipnp_last_error().decode()
+    # a block that NAMES an arithmetic its pointers do not provide is refused (conv_form mirrors config.Config)
+    a = _lib.TwoStageFfdnetArgs(conv_form=3)
+    assert lib.scipnp_twostage_ffdnet_iterate(C.byref(a), None, None) == -1
+    assert 'conv_form' in lib.scipnp_last_error().decode()
+    a.conv_form = 7
+    assert lib.scipnp_twostage_ffdnet_iterate(C.byref(a), None, None) == -1 and 'conv_form' in lib.scipnp_last_error().decode()
     # a side stream without the caller's two events is refused before anything is launched
     p = C.c_void_p(256)
     ptrs = (C.c_void_p * 12)(*[256] * 12)
