@@ -515,9 +515,15 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                             for (int e = 0; e < 4; ++e) v[it][e] = (fw[e] > 0.f) ? v[it][e] : 0.f;
                         }
                     }
+                    // Cache hints on the stores (DIAG bits 10 / 11, laboratory only): with the nt hint the ISOLATED layer -- the same input
+                    // tensor every launch -- takes 227 - 230 us instead of 246 - 249 (sc1: 241 - 247; profiles/r05d_wino4_store_hints.txt),
+                    // but inside the network pass, where every launch reads what the previous one wrote, the body launch stays at
+                    // 240 us and the 256x256x16 tile iteration gets SLOWER (1.37 -> 1.43 ms: its 100 MB tensors are served from the
+                    // Infinity Cache when the stores allocate there) -- plain stores are the product
+                    constexpr int AUX = (DIAG & 1024) ? 2 : (DIAG & 2048) ? 16 : 0;
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, AUX);
                 }
 #endif
             }
@@ -919,7 +925,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
         hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, D>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);                     \
         break;                                                                                                             \
     }
-    if (diag == 1024) {                                     // the classic per-lane store epilogue (LINES = false), results unchanged
+    if (diag == 4096) {                                     // the classic per-lane store epilogue (LINES = false), results unchanged
         static LdsAttrOnce attr;
         if (int rc = attr.ensure((const void*)conv3x3_c8w4_kernel<0, 0, false, false, false>, W4_LDS_BYTES, "conv3x3_c8w4 classic stores")) return rc;
         hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 0, false, false, false>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
@@ -929,7 +935,7 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
         W4_DIAG_CASE(1) W4_DIAG_CASE(2) W4_DIAG_CASE(4) W4_DIAG_CASE(8) W4_DIAG_CASE(16) W4_DIAG_CASE(32) W4_DIAG_CASE(6)
         W4_DIAG_CASE(7) W4_DIAG_CASE(15) W4_DIAG_CASE(39) W4_DIAG_CASE(47) W4_DIAG_CASE(48) W4_DIAG_CASE(49) W4_DIAG_CASE(55)
         W4_DIAG_CASE(63) W4_DIAG_CASE(3) W4_DIAG_CASE(5) W4_DIAG_CASE(9) W4_DIAG_CASE(10) W4_DIAG_CASE(12) W4_DIAG_CASE(14)
-        W4_DIAG_CASE(128) W4_DIAG_CASE(256) W4_DIAG_CASE(512)
+        W4_DIAG_CASE(128) W4_DIAG_CASE(256) W4_DIAG_CASE(512) W4_DIAG_CASE(1024) W4_DIAG_CASE(2048)
         default: SCIPNP_REQUIRE(false, "diag mask %d has no instantiation", diag);
     }
 #undef W4_DIAG_CASE

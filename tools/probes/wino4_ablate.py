@@ -16,7 +16,7 @@ p4, p2 = ops.pack_conv3x3_wino4(pk, c, c), ops.pack_conv3x3_wino(pk, c, c)
 out = torch.empty_like(x8)
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 NAMES = {1: 'no transform', 2: 'no raw staging', 4: 'no U LDS-DMA', 8: 'no barriers', 16: 'no MFMAs', 32: 'no epilogue',
-         128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory', 512: 'output stores of 1 KB contiguous memory', 1024: 'classic per-lane store epilogue (correct results)'}
+         128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory', 512: 'output stores of 1 KB contiguous memory', 1024: 'stores with the nt hint (isolated layer only: see conv_wino4.hip)', 2048: 'stores with the sc1 hint', 4096: 'classic per-lane store epilogue (correct results)'}
 
 
 KER = os.environ.get('W4_KERNEL', '4')     # '6': scipnp_conv3x3_c8w6_diag (masks 1, 2, 4, 8, 16, 6, 7, 15, 48, 49)
