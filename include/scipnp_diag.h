@@ -42,6 +42,21 @@ int scipnp_conv3x3_c8w6_stamped(const float* in, const float* packed_wino4, floa
 int scipnp_conv3x3_c8w6_diag(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s);
 
+/* ---- 16-channel workgroups, three per CU (csrc/conv_wino4n.hip, round 5; measured, see profiles/r05e_*): scipnp_conv3x3_c8w4's
+ * workgroup shape computing ONE 16-channel half -- 72 accumulator registers, U slabs of 9 KB, a single raw-tile buffer: 39 KB of LDS
+ * and <= 168 VGPRs, i.e. three INDEPENDENT 4-wave workgroups per CU; twice the input transform, patch reads and raw-tile requests
+ * per MFMA.  Weights: scipnp_repack_wino4n(packed_wino4 -> packed_wino4n of scipnp_conv3x3_wino4n_packed_floats floats).  Results
+ * BIT-IDENTICAL to scipnp_conv3x3_c8w4; flags: bit0 ReLU, bit1 residual, bit4 mask.  _stamped: stamp slots as scipnp_conv3x3_c8w4_stamped
+ * (SCIPNP_WN_WGS_PER_CU = 1 / 2 pads the LDS request); _diag: masks 1, 2, 4, 8, 16, 6, 7, 15. */
+size_t scipnp_conv3x3_wino4n_packed_floats(int Cin, int Cout);
+int scipnp_repack_wino4n(const float* packed_wino4, float* packed_wino4n, int Cin, int Cout, scipnp_stream_t s);
+int scipnp_conv3x3_c8wn(const float* in, const float* packed_wino4n, float* out, const float* residual, const float* mask_src,
+                        int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+int scipnp_conv3x3_c8wn_stamped(const float* in, const float* packed_wino4n, float* out, int n, int Cin, int Cout, int h, int w,
+                                int flags, unsigned long long* stamps, scipnp_stream_t s);
+int scipnp_conv3x3_c8wn_diag(const float* in, const float* packed_wino4n, float* out, int n, int Cin, int Cout, int h, int w,
+                             int flags, int diag, scipnp_stream_t s);
+
 /* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
  * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
  * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of

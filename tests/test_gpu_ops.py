@@ -1243,7 +1243,8 @@ def test_tv_banded_kernel_random_shapes(ops):
 
 
 def test_conv3x3_winograd_f4_three_waves_per_simd_equals_the_product_kernel(ops):
-    """csrc/conv_wino4x.hip (LABORATORY, libscipnp_diag.so; round 5) -- the F(4x4,3x3) convolution with a tile's 36 positions split
+    """Both three-waves-per-SIMD prototypes of round 5 (profiles/r05a_*, r05e_*: measured slower, not adopted).
+    csrc/conv_wino4x.hip (LABORATORY, libscipnp_diag.so; round 5) -- the F(4x4,3x3) convolution with a tile's 36 positions split
     over THREE waves (12-wave workgroups of 16 x 64 pixels, 164 VGPRs, three waves per SIMD) on the SAME packed weights:
     BIT-IDENTICAL to the product's csrc/conv_wino4.hip (whose whole-line store epilogue is thereby checked against the classic
     per-lane epilogue this kernel still has) for every plain-store epilogue, ragged sizes, narrow outputs, several frames.
@@ -1260,4 +1261,8 @@ def test_conv3x3_winograd_f4_three_waves_per_simd_equals_the_product_kernel(ops)
         res = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
         msk = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
         for kw in ({}, {'relu': True}, {'relu': True, 'residual': res, 'head': True}, {'mask_src': msk, 'residual': res}):
-            assert torch.equal(ops.conv3x3_c8w4(x, p4, cout, **kw), diaglib.conv3x3_c8w6(x, p4, cout, **kw)), ((n, cin, cout, h, w), sorted(kw))
+            want = ops.conv3x3_c8w4(x, p4, cout, **kw)
+            assert torch.equal(want, diaglib.conv3x3_c8w6(x, p4, cout, **kw)), ((n, cin, cout, h, w), sorted(kw))
+            # and the 16-channel-workgroup form (csrc/conv_wino4n.hip: three independent workgroups per CU, re-laid weights)
+            kwn = {k: v for k, v in kw.items() if k != 'head'}
+            assert torch.equal(want, diaglib.conv3x3_c8wn(x, diaglib.repack_wino4n(p4, cin, cout), cout, **kwn)), ((n, cin, cout, h, w), sorted(kw))

@@ -24,6 +24,11 @@ SIGNATURES = {
     'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8w6': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_wino4n_packed_floats': (_sz, [_int, _int]),
+    'scipnp_repack_wino4n': (_int, [_vp, _vp, _int, _int, _vp]),
+    'scipnp_conv3x3_c8wn': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8wn_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    'scipnp_conv3x3_c8wn_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8w6_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w6_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
@@ -97,4 +102,29 @@ def conv3x3_c8w6(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     _lib.check(load().scipnp_conv3x3_c8w6(P(x), P(packed_wino4), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
                                           _lib.stream_ptr()), 'scipnp_conv3x3_c8w6')
+    return out
+
+
+def repack_wino4n(packed_wino4, Cin, Cout):
+    """the F(4x4) packing of ops.pack_conv3x3_wino4 re-laid into the 16-channel slabs of scipnp_conv3x3_c8wn"""
+    import torch
+    from adaptivepnp_sci_amd import _lib
+    out = torch.empty(load().scipnp_conv3x3_wino4n_packed_floats(Cin, Cout), dtype=torch.float32, device=packed_wino4.device)
+    _lib.check(load().scipnp_repack_wino4n(C.c_void_p(packed_wino4.data_ptr()), C.c_void_p(out.data_ptr()), Cin, Cout, _lib.stream_ptr()),
+               'scipnp_repack_wino4n')
+    return out
+
+
+def conv3x3_c8wn(x, packed_wino4n, Cout, relu=False, residual=None, mask_src=None, out=None):
+    """scipnp_conv3x3_c8w4's convolution on the 16-channel-workgroup laboratory kernel (csrc/conv_wino4n.hip: three workgroups
+    per CU), weights from repack_wino4n: bit-identical results, no PixelShuffle store"""
+    import torch
+    from adaptivepnp_sci_amd import _lib
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
+    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    _lib.check(load().scipnp_conv3x3_c8wn(P(x), P(packed_wino4n), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
+                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8wn')
     return out

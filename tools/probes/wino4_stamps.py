@@ -20,19 +20,25 @@ nwg = (w // 64) * (h // (16 if os.environ.get('W4_KERNEL', '4') == '6' else 8)) 
 st = torch.zeros(nwg * 128, dtype=torch.int64, device='cuda')
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 KER = os.environ.get('W4_KERNEL', '4')            # '6': the three-waves-per-SIMD kernel (scipnp_conv3x3_c8w6_stamped; masks 0, 1, 6, 7)
-stamped = lib.scipnp_conv3x3_c8w6_stamped if KER == '6' else lib.scipnp_conv3x3_c8w4_stamped
+stamped = lib.scipnp_conv3x3_c8w6_stamped if KER == '6' else lib.scipnp_conv3x3_c8wn_stamped if KER == 'n' else lib.scipnp_conv3x3_c8w4_stamped
+if KER == 'n':                                          # 16-channel workgroups: re-laid weights, twice the workgroups
+    p4w = diaglib.repack_wino4n(p4, c, c)
+    st = torch.zeros(2 * nwg * 128, dtype=torch.int64, device='cuda')
+    nwg *= 2
+else:
+    p4w = p4
 print('kernel: scipnp_conv3x3_c8w' + KER)
 OFF = int(os.environ.get('W4_STAMP_OFF', '0'))       # diag bits 0..2 (no transform | no raw staging | no U DMA): timing only
 FL = 1 | (OFF << 12)
 print('parts switched off (diag mask):', OFF)
 for _ in range(3):
-    _lib.check(stamped(P(x8), P(p4), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
+    _lib.check(stamped(P(x8), P(p4w), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-_lib.check(stamped(P(x8), P(p4), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
+_lib.check(stamped(P(x8), P(p4w), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
 e1.record()
 torch.cuda.synchronize()
-(diaglib.conv3x3_c8w6 if KER == '6' else ops.conv3x3_c8w4)(x8, p4, c, relu=True, out=ref)
+ops.conv3x3_c8w4(x8, p4, c, relu=True, out=ref)
 print('stamped launch', round(e0.elapsed_time(e1) * 1e3, 1), 'us; equals the product kernel:', bool(torch.equal(out, ref)))
 s = st.cpu().numpy().reshape(nwg, 128).astype(np.float64)
 CG = c // 8

@@ -19,7 +19,9 @@ for (n, cin, cout, h, w) in ((1, 16, 32, 8, 64), (2, 24, 40, 13, 70), (1, 96, 96
     for kw in ({}, {'relu': True}, {'relu': True, 'residual': res, 'head': True}, {'mask_src': msk, 'residual': res}):
         a = ops.conv3x3_c8w4(x, p4, cout, **kw)
         b = diaglib.conv3x3_c8w6(x, p4, cout, **kw)
-        same = bool(torch.equal(a, b))
+        kwn = {k: v for k, v in kw.items() if k != 'head'}
+        cn = diaglib.conv3x3_c8wn(x, diaglib.repack_wino4n(p4, cin, cout), cout, **kwn)
+        same = bool(torch.equal(a, b)) and bool(torch.equal(a, cn))
         ok &= same
         if not same:
             d = (a - b).abs()
@@ -31,9 +33,11 @@ n, c, h, w = 8, 96, 256, 256
 x8 = ops.to_c8(torch.randn(n, c, h, w, generator=g).cuda())
 pk = ops.pack_conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.randn(c, generator=g), Cin=c, Cout=c, device='cuda')
 p4 = ops.pack_conv3x3_wino4(pk, c, c)
-o4, o6 = torch.empty_like(x8), torch.empty_like(x8)
-fns = {'c8w4 (2 waves/SIMD)': lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=o4),
-       'c8w6 (3 waves/SIMD)': lambda: diaglib.conv3x3_c8w6(x8, p4, c, relu=True, out=o6)}
+o4, o6, on = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
+pn = diaglib.repack_wino4n(p4, c, c)
+fns = {'c8w4 (product: 2 x 4 waves / CU, 32 co)  ': lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=o4),
+       'c8w6 (1 x 12 waves / CU, lockstep, 32 co)': lambda: diaglib.conv3x3_c8w6(x8, p4, c, relu=True, out=o6),
+       'c8wn (3 x 4 waves / CU, 16 co)           ': lambda: diaglib.conv3x3_c8wn(x8, pn, c, relu=True, out=on)}
 for f in fns.values():
     for _ in range(200):
         f()
@@ -48,4 +52,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 50
         print(f'round {rnd}  {name}: {us:7.1f} us   {21.743 / us * 1e3 / 1e3:6.1f} TFLOP/s executed = {21.743e9 / (us * 1e-6) / 157.3e12:.3f} of the fp32 MFMA peak')
-print('body layer equal:', bool(torch.equal(o4, o6)))
+print('body layer equal:', bool(torch.equal(o4, o6)), bool(torch.equal(o4, on)))
