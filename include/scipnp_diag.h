@@ -57,6 +57,23 @@ int scipnp_conv3x3_c8wn_stamped(const float* in, const float* packed_wino4n, flo
 int scipnp_conv3x3_c8wn_diag(const float* in, const float* packed_wino4n, float* out, int n, int Cin, int Cout, int h, int w,
                              int flags, int diag, scipnp_stream_t s);
 
+/* ---- producer / consumer waves (csrc/conv_wino4p.hip, round 5; measured at parity, not adopted): scipnp_conv3x3_c8w4's convolution
+ * for Cout % 64 == 0 on 12-wave workgroups, one per CU -- 8 consumer waves that only multiply (U and V operands from LDS, 144
+ * accumulators, 168 VGPRs) and 4 producer waves that own the raw-tile requests and the input transform, done ONCE for 64 output
+ * channels and written to LDS per k-step (the U requests are spread over the consumers: a wave's LDS-DMA requests execute one after
+ * the other).  The same packed_wino4 buffer, BIT-IDENTICAL results.  flags: bit0 ReLU, bit1 residual, bit4 mask.  Isolated layer -5 .. -9 %,
+ * inside a 4-layer chain -0 .. -5 % (profiles/r05f_*): in lockstep through one barrier per k-step the two consumers of a SIMD take
+ * 27.4 hundred cycles per k-step with the producers idle (23.0 = their MFMAs) and 31.4 with them -- a producer's 18 V stores complete
+ * 2300 cycles after issue behind the consumers' operand reads.  _stamped: wave 0 (a consumer) [0] entry, [1] prologue barriers passed,
+ * [8 + 2s] MFMAs of k-step s issued, [9 + 2s] its barrier passed, [3] loop left, [4] first tile image written, [5] stores issued,
+ * [6] acknowledged, [7] XCC_ID << 32 | HW_ID; wave 8 (a producer) [56] opening tiles landed, [57] first transform in LDS,
+ * [64 + 2s] work of k-step s issued and its LDS operations complete, [65 + 2s] its barrier passed; flags bits 12..14 switch parts off
+ * (1 no V stores, 2 no raw staging, 4 no transform: timing only) */
+int scipnp_conv3x3_c8wp(const float* in, const float* packed_wino4, float* out, const float* residual,
+                        const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
+int scipnp_conv3x3_c8wp_stamped(const float* in, const float* packed_wino4, float* out, int n, int Cin, int Cout, int h, int w,
+                                int flags, unsigned long long* stamps, scipnp_stream_t s);
+
 /* ---- persistent form of the fp32 Winograd convolution for 96-output-channel layers (csrc/conv_winop.hip, round 3): same
  * arithmetic and summation order as scipnp_conv3x3_c8w (bit-identical results), the input transform computed once per tile and
  * shared through LDS by all 96 output channels, 12-wave workgroups that stay resident (one per CU) and walk a static list of

@@ -53,7 +53,7 @@ def test_the_laboratory_is_a_separate_library(lib):
     from adaptivepnp_sci_amd import _lib
     dlib = diaglib.load()
     names = header_symbols('scipnp_diag.h')
-    assert len(names) == 22 and sorted(diaglib.SIGNATURES) == names
+    assert len(names) == 24 and sorted(diaglib.SIGNATURES) == names
     assert exported_symbols(diaglib.DIAG_LIB_PATH) == names
     assert not set(names) & set(header_symbols()) and not set(names) & set(_lib.SIGNATURES)
     for n in names:

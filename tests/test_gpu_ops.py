@@ -1266,3 +1266,23 @@ def test_conv3x3_winograd_f4_three_waves_per_simd_equals_the_product_kernel(ops)
             # and the 16-channel-workgroup form (csrc/conv_wino4n.hip: three independent workgroups per CU, re-laid weights)
             kwn = {k: v for k, v in kw.items() if k != 'head'}
             assert torch.equal(want, diaglib.conv3x3_c8wn(x, diaglib.repack_wino4n(p4, cin, cout), cout, **kwn)), ((n, cin, cout, h, w), sorted(kw))
+
+
+def test_conv3x3_winograd_f4_producer_consumer_kernel_equals_the_product_kernel(ops):
+    """csrc/conv_wino4p.hip (LABORATORY; round 5): 12-wave workgroups of 8 consumer waves (MFMAs only, operands from LDS) and 4
+    producer waves (raw-tile requests, the input transform ONCE for 64 output channels) -- BIT-IDENTICAL to the product's
+    scipnp_conv3x3_c8w4 for Cout % 64 == 0 on ragged shapes, one to sixteen channel groups, every plain-store epilogue.
+    (Measured at parity inside a network pass, profiles/r05f_*: kept as the first step of DESIGN.md section 9.12.)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import diaglib
+    g = torch.Generator().manual_seed(7)
+    for (n, cin, cout, h, w) in ((1, 8, 64, 8, 64), (2, 16, 64, 13, 70), (1, 64, 64, 37, 131), (3, 32, 128, 20, 64), (1, 128, 128, 9, 9),
+                                 (1, 24, 192, 16, 128), (8, 64, 64, 128, 128)):
+        x = ops.to_c8(torch.randn(n, cin, h, w, generator=g).cuda())
+        pk = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g), Cin=cin, Cout=cout,
+                              device='cuda')
+        p4 = ops.pack_conv3x3_wino4(pk, cin, cout)
+        res = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        msk = ops.to_c8(torch.randn(n, cout, h, w, generator=g).cuda())
+        for kw in ({}, {'relu': True}, {'relu': True, 'residual': res}, {'mask_src': msk, 'residual': res}):
+            assert torch.equal(ops.conv3x3_c8w4(x, p4, cout, **kw), diaglib.conv3x3_c8wp(x, p4, cout, **kw)), ((n, cin, cout, h, w), sorted(kw))

@@ -29,6 +29,8 @@ SIGNATURES = {
     'scipnp_conv3x3_c8wn': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8wn_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8wn_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8wp': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_c8wp_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w6_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w6_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
@@ -127,4 +129,19 @@ def conv3x3_c8wn(x, packed_wino4n, Cout, relu=False, residual=None, mask_src=Non
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     _lib.check(load().scipnp_conv3x3_c8wn(P(x), P(packed_wino4n), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
                                           _lib.stream_ptr()), 'scipnp_conv3x3_c8wn')
+    return out
+
+
+def conv3x3_c8wp(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None):
+    """scipnp_conv3x3_c8w4's convolution for Cout % 64 == 0 on the producer / consumer laboratory kernel (csrc/conv_wino4p.hip):
+    same packing, bit-identical results; stride 1, plain store"""
+    import torch
+    from adaptivepnp_sci_amd import _lib
+    n, cg, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
+    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    _lib.check(load().scipnp_conv3x3_c8wp(P(x), P(packed_wino4), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
+                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8wp')
     return out
