@@ -19,7 +19,7 @@
 // scipnp_conv3x3_c8w4: BIT-IDENTICAL results.
 //
 // LDS (150 KB): raw halo tiles [2] (as conv_wino4.hip), U slabs [2 k-step buffers][2 channel blocks] (72 KB), V [2 k-step buffers]
-// [tg, xh][18 positions][64 lanes] (36 KB).  Schedule, k-step s = 2g + j (every wave passes ONE barrier per k-step, so the roles
+// [tg, xh][9 position pairs][64 lanes][2] (36 KB).  Schedule, k-step s = 2g + j (every wave passes ONE barrier per k-step, so the roles
 // cannot fall out of step):
 //   consumers   MFMAs of k-step s on U[s & 1], V[j]
 //   producers   requests: U of k-step s + 1; at j = 0 the raw tile of group g + 2
@@ -130,14 +130,19 @@ conv3x3_c8wp_kernel(const Wino4Args a) {
     const int b_row = (((q >> 1) * W4_THP + 4 * tg + xh) * W4_RSL) * 4 + (q & 1) * 2;    // producers: patch rows xh .. xh + 4
     const int b_off0 = b_row + (4 * tn + (tn >> 2)) * 4, b_off1 = b_row + (4 * tn + ((tn + 1) >> 2)) * 4;
     const int a_off = cb * W4_SLAB + xh * (9 * 256) + lane * 4;                           // consumers: U vectors
-    const int v_off = role * (18 * 64) + lane;                                            // both: V[role][p][lane]
-    f32x2 ta = {0.f, 0.f}, tb = {0.f, 0.f};
+    const int v_off = role * (9 * 128) + lane * 2;                                        // both: V[role][pair r * 3 + np][lane][2]
     const f32x2 m5 = {-5.f, -5.f};
 
-    // producers: own rows of the column pass of the tile in rawp -> T; row pass T -> V (registers)
+    // producers: own rows of the column pass of the tile in rawp -> T; row pass T -> V (registers).  The row pass is written op-major:
+    // operation k of all three rows and both halves back to back -- six independent packed operations per step.  A producer shares
+    // its SIMD with two consumers whose fp32 MFMAs hold the vector port 32 cycles at a time: a DEPENDENT chain gets one operation in
+    // per MFMA boundary (the 36 operations of a row pass took 2800 cycles; op-major 2200).
     auto column_pass = [&](const float* rawp, auto LO) {
         constexpr bool lo = decltype(LO)::value;
         if (DIAG & 4) return;                                // (timing experiment: no transform)
+        // (column by column: with all 30 patch values requested up front and the operations op-major the even k-steps got SLOWER,
+        // 33.6 -> 36.3 hundred cycles -- the burst delays the consumers' own operand reads)
+        f32x2 ta = {0.f, 0.f}, tb = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int bo = (c < 4 ? b_off0 : b_off1) + c * 4;
@@ -149,19 +154,22 @@ conv3x3_c8wp_kernel(const Wino4Args a) {
     };
     auto row_pass = [&]() {
         if (DIAG & 4) return;
+        f32x2 tr[3][2][2];
+        static_for<6>([&](auto K) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            static_for<6>([&](auto K) { half_op<true, decltype(K)::value>(T[r][0], T[r][1], T[r][2], T[r][3], T[r][4], V[r][0], V[r][1], V[r][2], ta, tb, m5); });
-            static_for<6>([&](auto K) { half_op<false, decltype(K)::value>(T[r][1], T[r][2], T[r][3], T[r][4], T[r][5], V[r][3], V[r][4], V[r][5], ta, tb, m5); });
-        }
+            for (int r = 0; r < 3; ++r) {
+                half_op<true, decltype(K)::value>(T[r][0], T[r][1], T[r][2], T[r][3], T[r][4], V[r][0], V[r][1], V[r][2], tr[r][0][0], tr[r][0][1], m5);
+                half_op<false, decltype(K)::value>(T[r][1], T[r][2], T[r][3], T[r][4], T[r][5], V[r][3], V[r][4], V[r][5], tr[r][1][0], tr[r][1][1], m5);
+            }
+        });
     };
-    auto store_v = [&](int j) {                              // V(., j) of the held group -> V[j]
+    auto store_v = [&](int j) {                              // V(., j) of the held group -> V[j], one 8-byte store per position pair
         if (DIAG & 1) return;                                // (timing experiment: no V stores)
         float* dst = v_lds + j * WP_V + v_off;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) dst[(r * 6 + nu) * 64] = V[r][nu][j];
+            for (int np = 0; np < 3; ++np) *(f32x2*)(dst + (r * 3 + np) * 128) = f32x2{V[r][2 * np][j], V[r][2 * np + 1][j]};
     };
 
     if (producer) {
@@ -257,6 +265,20 @@ conv3x3_c8wp_kernel(const Wino4Args a) {
     asm volatile("s_barrier" ::: "memory");                                      // P2
     WP_STAMP(0, 1);
     const float* wc_g = a.wpk + (size_t)split * W4_SLAB + w_step;                // this block's slab of the NEXT k-step
+    // The k-step walks its accumulators row by row (j = 0) or column pair by column pair (j = 1), the order the packer laid the U
+    // vectors out in.  Vector i of k-step j sits in operand slot (i + j) & 1; the LAST vector of a k-step is loaded but multiplied
+    // only behind the barrier, after the next k-step's first operands have been requested: its four MFMAs run while those arrive
+    // (both consumers of a SIMD pass the barrier together -- without this the pipe idles for an LDS round trip every k-step).
+    f32x4 af[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // (slot 1 = the "held vector" of a k-step -1: zeros)
+    f32x2 bv[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    auto mfma4 = [&](auto X, auto NP, const f32x4 u, const f32x2 b) {
+        constexpr int x = decltype(X)::value, np = decltype(NP)::value;
+        if (DIAG & 16) return;
+        acc[x][2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b[0], acc[x][2 * np][0], 0, 0, 0);
+        acc[x][2 * np + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], b[1], acc[x][2 * np + 1][0], 0, 0, 0);
+        acc[x][2 * np][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], b[0], acc[x][2 * np][1], 0, 0, 0);
+        acc[x][2 * np + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], b[1], acc[x][2 * np + 1][1], 0, 0, 0);
+    };
     for (int g = 0; g < CG; ++g) {
         static_for<2>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -265,47 +287,32 @@ conv3x3_c8wp_kernel(const Wino4Args a) {
             const float* const vcur = v_lds + j * WP_V + v_off;
             float* const unext = u_lds + ((s + 1) & 1) * WP_U + cb * W4_SLAB;
             const bool more_u = s + 1 < 2 * CG;
-            // the k-step walks its accumulators row by row (j = 0) or column pair by column pair (j = 1): the order the packer
-            // laid the U vectors out in
-            f32x4 af[2];
-            float bv[2][2];
-            af[0] = *(const f32x4*)(ucur);
-            {
-                bv[0][0] = vcur[0];
-                bv[0][1] = vcur[64];
-            }
-            static_for<9>([&](auto P) {
+            // (row, np) of vector i: j = 0: (i / 3, i % 3); j = 1: (i % 3, i / 3); its V pair: row * 3 + np
+            af[j & 1] = *(const f32x4*)(ucur);
+            bv[j & 1] = *(const f32x2*)(vcur);
+            // the previous k-step's last vector (k-step j ^ 1: vector 8 = (2, 2) either way), held in slot (8 + (j ^ 1)) & 1
+            mfma4(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, af[(j ^ 1) & 1], bv[(j ^ 1) & 1]);
+            static_for<8>([&](auto P) {
                 constexpr int pos = decltype(P)::value;
-                if constexpr (pos + 1 < 9) {
-                    constexpr int nx = pos + 1;
-                    af[nx & 1] = *(const f32x4*)(ucur + nx * 256);
-                    // (row, np) of vector nx: j = 0: (nx / 3, nx % 3); j = 1: (nx % 3, nx / 3) -- j is a loop constant after unrolling
-                    constexpr int r1 = j == 0 ? nx / 3 : nx % 3, np1 = j == 0 ? nx % 3 : nx / 3;
-                    bv[nx & 1][0] = vcur[(r1 * 6 + 2 * np1) * 64];
-                    bv[nx & 1][1] = vcur[(r1 * 6 + 2 * np1 + 1) * 64];
-                }
+                constexpr int nx = pos + 1;
+                constexpr int r1 = j == 0 ? nx / 3 : nx % 3, np1 = j == 0 ? nx % 3 : nx / 3;
+                af[(nx + j) & 1] = *(const f32x4*)(ucur + nx * 256);
+                bv[(nx + j) & 1] = *(const f32x2*)(vcur + (r1 * 3 + np1) * 128);
                 constexpr int x = j == 0 ? pos / 3 : pos % 3, np = j == 0 ? pos % 3 : pos / 3;
-                const f32x4 u = af[pos & 1];
-                const float b0 = bv[pos & 1][0], b1 = bv[pos & 1][1];
-                if (!(DIAG & 16)) {
-                    acc[x][2 * np][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], b0, acc[x][2 * np][0], 0, 0, 0);
-                    if constexpr (pos < WP_U_ITERS) {          // one request of the next k-step's slab behind each of the first vectors
-                        if (more_u) {
-                            int pc = role + 4 * pos;
-                            if (pc >= W4_PIECES) pc -= 4;
+                mfma4(std::integral_constant<int, x>{}, std::integral_constant<int, np>{}, af[(pos + j) & 1], bv[(pos + j) & 1]);
+                if constexpr (pos < WP_U_ITERS) {              // one request of the next k-step's slab behind each of the first vectors
+                    if (more_u && !(DIAG & 8)) {                 // (DIAG bit 3, timing experiment: no U requests)
+                        int pc = role + 4 * pos;
+                        if (pc >= W4_PIECES) pc -= 4;
 #if defined(__HIP_DEVICE_COMPILE__)
-                            // (the lane's offset 16 * lane rides in the register that already addresses its U vectors: a_off * 4 =
-                            // KB + 16 * lane with the wave-uniform KB taken off the descriptor's base; the piece's 1 KiB offset is scalar)
-                            const unsigned KB = (unsigned)((cb * W4_SLAB + xh * (9 * 256)) * 4);
-                            auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)wc_g - KB), 0, KB + W4_SLAB * 4, 0x00020000);
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)((char*)unext + 1024 * pc), 16,
-                                                                     (unsigned)(a_off * 4), (unsigned)(1024 * pc), 0, 0);
+                        // (the lane's offset 16 * lane rides in the register that already addresses its U vectors: a_off * 4 =
+                        // KB + 16 * lane with the wave-uniform KB taken off the descriptor's base; the piece's 1 KiB offset is scalar)
+                        const unsigned KB = (unsigned)((cb * W4_SLAB + xh * (9 * 256)) * 4);
+                        auto r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)wc_g - KB), 0, KB + W4_SLAB * 4, 0x00020000);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)((char*)unext + 1024 * pc), 16,
+                                                                 (unsigned)(a_off * 4), (unsigned)(1024 * pc), 0, 0);
 #endif
-                        }
                     }
-                    acc[x][2 * np + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], b1, acc[x][2 * np + 1][0], 0, 0, 0);
-                    acc[x][2 * np][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], b0, acc[x][2 * np][1], 0, 0, 0);
-                    acc[x][2 * np + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], b1, acc[x][2 * np + 1][1], 0, 0, 0);
                 }
             });
             if (more_u) wc_g += w_step;
@@ -314,6 +321,8 @@ conv3x3_c8wp_kernel(const Wino4Args a) {
             if (s < 24) WP_STAMP(0, 9 + 2 * s);
         });
     }
+    // the very last vector (k-step 2 CG - 1, j = 1: slot (8 + 1) & 1)
+    mfma4(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, af[1], bv[1]);
     WP_STAMP(0, 3);
 
     // ---- epilogue: the consumers' partial tiles through LDS as tile images (two per channel block), whole-line stores -- the LINES
@@ -443,8 +452,8 @@ int scipnp_conv3x3_c8wp_stamped(const float* in, const float* packed_wino4, floa
         hipLaunchKernelGGL((conv3x3_c8wp_kernel<64 | D>), dim3(a.total_units), dim3(WP_THREADS), WP_LDS_BYTES, (hipStream_t)s, a); \
         break;                                                                                                            \
     }
-    switch ((flags >> 12) & 7) {
-        WP_STAMP_CASE(0) WP_STAMP_CASE(1) WP_STAMP_CASE(2) WP_STAMP_CASE(4) WP_STAMP_CASE(6) WP_STAMP_CASE(7)
+    switch ((flags >> 12) & 15) {
+        WP_STAMP_CASE(0) WP_STAMP_CASE(1) WP_STAMP_CASE(2) WP_STAMP_CASE(4) WP_STAMP_CASE(6) WP_STAMP_CASE(7) WP_STAMP_CASE(8) WP_STAMP_CASE(10)
         default: SCIPNP_REQUIRE(false, "no stamped build for that mask");
     }
 #undef WP_STAMP_CASE
