@@ -215,3 +215,47 @@ def test_unit_batch_argument_errors(ffdnet_state_dict):
     with pytest.raises(ValueError, match='2048'):               # 24 x 24 mosaic: partial blocks would straddle units
         p3 = problems(2, 24, 24, 4)
         AdmmRun([p[0] for p in p3], [p[1] for p in p3], 'tv', False, X_orig=[p[2] for p in p3], units=2)
+
+
+def test_a_solve_keeps_its_configuration_whatever_the_environment_says(ffdnet_state_dict, monkeypatch):
+    """AdmmRun(config=...) (adaptivepnp_sci_amd.config, round 5): the kernel forms of a solve are fixed at construction and used by
+    every step -- a later environment change or an enclosing full configuration does not reach it, an explicit field override
+    does unless the constructor pinned that field; the three fp32 forms and f16x3 agree with each other within the gates"""
+    from adaptivepnp_sci_amd import config, ops
+    from adaptivepnp_sci_amd.solver import AdmmRun
+    (y, Phi, orig), = problems(1, 64, 64, 8, seed0=61)
+    net = make_ffdnet(ffdnet_state_dict)
+    forms = {'f4': config.Config(), 'f2': config.Config(wino_f4=False), 'direct': config.Config(f32_form='direct'),
+             'f16x3': config.Config(precision='f16x3')}
+    runs = {k: AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net, config=c) for k, c in forms.items()}
+    assert runs['f16x3'].eng.precision == 'f16x3' and runs['f4'].eng.precision == 'f32' and runs['direct'].eng.f32_form == 'direct'
+    assert runs['f4'].eng.packed_wino[1].f4 is not None and runs['f2'].eng.packed_wino[1].f4 is None
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', 'f16x3')          # the process default changes under the runs' feet ...
+    monkeypatch.setenv('SCIPNP_WINO_F4', '0')
+    seen = {}
+    try:
+        with config.use(config.Config(f32_form='direct')):        # ... and so does the enclosing full configuration
+            for k, r in runs.items():
+                ops.LAUNCH_LOG = log = []
+                r.step(25 / 255)
+                seen[k] = {e[0] for e in log if e[0].startswith('conv3x3')}
+    finally:
+        ops.LAUNCH_LOG = None
+    assert seen['f4'] == {'conv3x3_c8w4_kernel', 'conv3x3_c8w_kernel'}                  # head + body on F(4x4), tail on F(2x2)
+    assert seen['f2'] == {'conv3x3_c8w_kernel'}
+    assert seen['direct'] == {'conv3x3_c8_kernel'}
+    assert seen['f16x3'] == {'conv3x3_c8s_kernel'}
+    ref = runs['direct'].result_mosaic()
+    for k in ('f4', 'f2', 'f16x3'):
+        d = float((runs[k].result_mosaic() - ref).norm() / ref.norm())
+        assert d < 1e-5, (k, d)
+    # a run built WITHOUT config= follows explicit field overrides of the caller
+    free = AdmmRun(y, Phi, 'ffdnet_color', True, X_orig=orig, model=net, conv_precision='f32')
+    log2 = []
+    ops.LAUNCH_LOG = log2
+    try:
+        with config.use(wino_f4=True, precision='f16x3'):         # wino_f4 reaches in; precision was pinned by conv_precision=
+            free.step(25 / 255)
+    finally:
+        ops.LAUNCH_LOG = None
+    assert 'conv3x3_c8s_kernel' not in {e[0] for e in log2} and free.eng.precision == 'f32'
