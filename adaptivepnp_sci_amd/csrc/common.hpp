@@ -223,19 +223,23 @@ __device__ __forceinline__ int tv_band_stop_test(const double* __restrict__ pc, 
 // The same test for EIGHT channels at once when a channel has at most 8 bands: lane = 8 * (channel of the wave) + band; `pc` is
 // the lane's channel (nullptr: none).  The shuffle tree inside the 8-lane segments adds exactly the terms the 64-lane tree of
 // tv_band_stop_test adds that are not zeros, in the same order -- bit-identical sums; lanes with band 0 return their channel's result.
-__device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc, int nbands, int n_iter, size_t MN, double weight,
-                                                  double eps) {
-    constexpr int MAXIT = 4;
+// In two halves, so that a caller can put its own loads between the operand loads and the arithmetic (round 5:
+// pm_dual_project_spec_kernel).  inv_mn != 0: M*N is a power of two and E / (double)MN is the exact scaling E * inv_mn.
+constexpr int TV_STOP_MAXIT = 4;
+__device__ __forceinline__ void tv_band_stop_load8(const double* __restrict__ pc, int nbands, int n_iter,
+                                                   double (&s1)[TV_STOP_MAXIT], double (&s2)[TV_STOP_MAXIT]) {
     const int k = threadIdx.x & 7;
-    double s1[MAXIT], s2[MAXIT];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
         const bool on = pc != nullptr && it < n_iter - 1 && k < nbands;
         s1[it] = on ? pc[(size_t)k * 2 * n_iter + 2 * it] : 0.0;
         s2[it] = on ? pc[(size_t)k * 2 * n_iter + 2 * it + 1] : 0.0;
     }
+}
+__device__ __forceinline__ int tv_band_stop_finish8(double (&s1)[TV_STOP_MAXIT], double (&s2)[TV_STOP_MAXIT], int n_iter, size_t MN,
+                                                    double weight, double eps, double inv_mn = 0.0) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < TV_STOP_MAXIT; ++it)
         for (int off = 4; off > 0; off >>= 1) {
             s1[it] += __shfl_down(s1[it], off, 8);
             s2[it] += __shfl_down(s2[it], off, 8);
@@ -243,16 +247,23 @@ __device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc,
     double E0 = 0.0, Eprev = 0.0;
     int stop_at = n_iter - 1;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
         if (it >= n_iter - 1 || stop_at != n_iter - 1) continue;
         double E = (double)(float)s1[it];
         E += weight * (double)(float)s2[it];
-        E /= (double)MN;
+        if (inv_mn != 0.0) E *= inv_mn;
+        else E /= (double)MN;
         if (it == 0) { E0 = E; Eprev = E; }
         else if (fabs(Eprev - E) < eps * E0) stop_at = it;
         else Eprev = E;
     }
     return stop_at;
+}
+__device__ __forceinline__ int tv_band_stop_test8(const double* __restrict__ pc, int nbands, int n_iter, size_t MN, double weight,
+                                                  double eps) {
+    double s1[TV_STOP_MAXIT], s2[TV_STOP_MAXIT];
+    tv_band_stop_load8(pc, nbands, n_iter, s1, s2);
+    return tv_band_stop_finish8(s1, s2, n_iter, MN, weight, eps);
 }
 // sci_ops.hip: scipnp_pm_dual_update with theta_raw selected per channel (sel != nullptr: theta_raw is the candidate base,
 // element i of channel c = i / MN comes from theta_raw[(sel[c] - 1) * img + i]) and scipnp_pm_dual_project doing the stop test

@@ -621,6 +621,84 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
     }
 }
 
+// ---- round 5: the same launch for SMALL states with the candidate form of the TV step (the ADMM-TV iteration at 256x256x8: one
+// pixel per thread, a workgroup's 256 pixels inside one plane, at most 8 frames, at most 8 bands per channel), arranged so that
+// the kernel is ONE memory round trip deep instead of three.  The general kernel above loads the stop-test operands, evaluates
+// the test in wave 0, passes the result through LDS and a barrier, and only then knows which candidate to load (a second round
+// trip; y and Phisum a third) -- 12.2 us for 28 MB on a 2 MB state (profiles/r03d_*).  Here every wave loads the stop-test
+// operands FIRST, then every other operand including ALL (n_iter - 1) candidates of its pixel (6 MB of extra reads that never
+// leave the memory-side cache), evaluates the test itself while those are in flight (no LDS, no barrier; E / MN as an exact
+// scaling when M*N is a power of two) and picks the candidate in registers.  Same expressions in the same order as the general
+// kernel: theta, b, x and the squared-error partials are bit-identical to it.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_eps, double inv_mn, float* xio, float* theta, float* bb,
+                            const float* __restrict__ Phi, const float* __restrict__ y, const float* __restrict__ Phisum,
+                            const float* __restrict__ orig, double* sse_part, int nfill, long long Q, long long MN, int B, float c0,
+                            float c1) {
+    constexpr int MAXB = 8;
+    __shared__ double red[16];
+    const int P = (int)(Q / MN);                                        // planes per frame
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // (host: Q % 256 == 0, MN % 256 == 0)
+    const int ib = (int)(((long long)blockIdx.x * 256) / MN);           // the plane of this workgroup's pixels
+    const int lane = threadIdx.x & 63, t8 = lane >> 3;
+    double s1[TV_STOP_MAXIT], s2[TV_STOP_MAXIT];
+    tv_band_stop_load8(t8 < B ? cd.part + ((size_t)t8 * P + ib) * cd.nbands * 2 * cd.n_iter : nullptr, cd.nbands, cd.n_iter, s1, s2);
+    float xr[MAXB], br[MAXB], ph[MAXB], og[MAXB], cr[TV_STOP_MAXIT][MAXB];
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        if (t < B) {
+            const size_t o = (size_t)t * Q + q;
+            xr[t] = xio[o];
+            br[t] = bb[o];
+            ph[t] = Phi[o];
+        }
+    }
+    const float yv = y[q], sv = Phisum[q];
+#pragma unroll
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
+#pragma unroll
+        for (int t = 0; t < MAXB; ++t)
+            cr[it][t] = (t < B && it < cd.n_iter - 1) ? cd.cand[(size_t)it * ((size_t)B * Q) + (size_t)t * Q + q] : 0.f;
+    }
+    if (sse_part) {
+#pragma unroll
+        for (int t = 0; t < MAXB; ++t) og[t] = t < B ? orig[(size_t)t * Q + q] : 0.f;
+    }
+    const int st = tv_band_stop_finish8(s1, s2, cd.n_iter, cd.MN, tv_weight, tv_eps, inv_mn);   // lane 8 t: channel (t, ib)
+    double acc = 0.0;
+    float p[MAXB];
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        if (t < B) {
+            const size_t o = (size_t)t * Q + q;
+            const int sel = __builtin_amdgcn_readlane(st, 8 * t);       // channel kept the `out` of iteration sel: candidate sel - 1
+            const float raw = sel == 1 ? cr[0][t] : sel == 2 ? cr[1][t] : sel == 3 ? cr[2][t] : cr[3][t];
+            const float th = fminf(fmaxf(raw, 0.f), 1.f);
+            const float d = xr[t] - th;
+            const float bn = (MODE == 0) ? (br[t] + d) : (br[t] - d);
+            p[t] = (MODE == 0) ? (th - c0 * bn) : (th + bn);
+            theta[o] = th;
+            bb[o] = bn;
+            if (sse_part) {
+                const float e = og[t] - (MODE == 0 ? th : xr[t]);
+                acc += (double)(e * e);
+            }
+        }
+    }
+    const float yb = torch_contig_sum<MAXB>(B, [&](int i) { return p[i] * ph[i]; });
+    const float r = (MODE == 0) ? (yv - yb) / (c1 + sv) : (yv - yb) / (sv + c1);
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t)
+        if (t < B) xio[(size_t)t * Q + q] = (MODE == 0) ? (p[t] + ph[t] * r) : (p[t] + c0 * (r * ph[t]));
+    if (sse_part) {
+        const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
+        if (threadIdx.x == 0) sse_part[blockIdx.x] = s;
+        if (blockIdx.x == 0)
+            for (int i = gridDim.x + threadIdx.x; i < nfill; i += blockDim.x) sse_part[i] = 0.0;
+    }
+}
+
 // launch shape of pm_dual_project_kernel: pixels per thread, chunks per workgroup (more than one only where one workgroup per
 // chunk would be more squared-error partials than the caller's nfill entries), workgroups
 void dual_project_shape(long long Q, int B, int nfill, bool vec_ok, int* VEC, int* CH, unsigned* grid, int units) {
@@ -885,6 +963,18 @@ int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double 
     // the candidate form keeps the stop iteration of at most 4 planes per workgroup (always true for one unit)
     SCIPNP_REQUIRE(!use_cd || units == 1 || ((long long)CH * threads * VECs - 1) / MN + 2 <= 4,
                    "unit-batched candidate form: planes of %lld pixels are too small for this launch shape", MN);
+    // small states in the candidate form: the one-round-trip kernel (SCIPNP_DUAL_PROJECT_GENERAL=1 keeps the general one, for A/B)
+    static const bool general_only = [] { const char* e = getenv("SCIPNP_DUAL_PROJECT_GENERAL"); return e && e[0] == '1'; }();
+    if (use_cd && !general_only && VECs == 1 && CH == 1 && B <= 8 && cd.nbands <= 8 && MN % 256 == 0 && Q % 256 == 0) {
+        const double inv_mn = (MN & (MN - 1)) == 0 ? 1.0 / (double)MN : 0.0;
+        if (mode == 0)
+            hipLaunchKernelGGL((pm_dual_project_spec_kernel<0>), dim3(grid), dim3(threads), 0, st, cd, tv_weight, tv_eps, inv_mn, x,
+                               theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1);
+        else
+            hipLaunchKernelGGL((pm_dual_project_spec_kernel<1>), dim3(grid), dim3(threads), 0, st, cd, tv_weight, tv_eps, inv_mn, x,
+                               theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1);
+        return launch_status("pm_dual_project_spec_kernel");
+    }
 #define SCIPNP_DP(VEC, MAXB)                                                                                     \
     do {                                                                                                         \
         if (mode == 0)                                                                                           \

@@ -456,10 +456,331 @@ __device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, fl
     }
 }
 
-// kernel A (STAGE 0): all iterations + partials; kernel B (STAGE 1): stop test per channel, recomputation if it stopped early.
-// NOTE on the energy of the LAST iteration: skimage evaluates the stop test after the p-update of every iteration including
-// the last, but nothing depends on that value (the loop ends either way), so its norm sum is not needed.
-template <int COLS, int R, int STRIPS, int STAGE>
+// ---- round 5: the same band computation rearranged (the kernel above measured 3.0 us per Chambolle iteration on the ADMM-TV
+// shape -- 32 planes of 128 x 128, 6 pixels per thread, two waves per SIMD -- against 1.7 us of instruction issue for its 75
+// vector instructions per pixel: profiles/r05x_tv_band_sweep.txt).  Identical results -- `out`, candidates and partial sums bit
+// for bit -- from fewer and better ordered instructions:
+//   * the energy sums of an iteration stay in per-thread fp64 registers and are reduced ONCE after the loop (the per-iteration
+//     wave reduction was a chain of 12 dependent cross-lane permutes + thread 0 adding the wave partials between two barriers);
+//   * lane neighbours come from DPP wave shifts (one VALU move) instead of ds_bpermute round trips, the wave-seam values from
+//     one unconditional broadcast LDS read per phase instead of R branches; row conditions are wave-uniform (scalar);
+//   * sqrt and the two divisions by the same denominator are written out: the compiler's correctly rounded expansions are 17 +
+//     2 x 11 instructions, most of them range handling (operands below 2^-96, infinities) -- here v_sqrt + the +-1 ulp fix-up (9)
+//     and ONE reciprocal refinement shared by both quotients, whose Newton / residual steps run as packed fp32 pairs (8): the
+//     same instruction sequence the compiler emits minus the scaling, hence the same bits whenever no scaling would have
+//     happened.  A wave checks exactly that for every operand (gradient energy and both numerators: zero or >= 2^-60) and
+//     redoes the phase with the compiler's sqrtf and '/' otherwise (tests/test_gpu_ops.py drives both paths; the one case
+//     the fast path does not reproduce is the SIGN of a zero quotient for a -0 numerator, which only an earlier underflow
+//     can produce and which reaches `out` only through an input pixel that is itself -0);
+//   * the pixels of a thread go through each stage together (gradients, sqrt, reciprocal, quotients), so the quarter-rate
+//     v_sqrt / v_rcp results and the compare -> select hazards of one pixel are covered by the next pixel's instructions.
+typedef float tv_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float tv_lane_prev(float v) {      // lane l <- lane l - 1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float tv_lane_next(float v) {      // lane l <- lane l + 1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// guard word of a non-negative-or-signed operand: (|bits| << 1) - 1 -- zero maps to the largest unsigned, anything in
+// (0, 2^-60) below TVB_GUARD
+constexpr unsigned TVB_GUARD = (0x21800000u << 1) - 1u;      // bits(2^-60) = 0x21800000
+__device__ __forceinline__ unsigned tv_guard_word(float f) { return (__builtin_bit_cast(unsigned, f) << 1) - 1u; }
+
+// the p-update of R pixels of one thread: g[k] = (g0, g1), pz[k] = (p0, p1) in, pz out; nrm[k] out; returns the guard word
+template <int R>
+__device__ __forceinline__ unsigned tv_p_update_fast(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
+    float x[R], s[R];
+    tv_f2 num[R];
+    unsigned guard = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const tv_f2 sq = g[k] * g[k];
+        x[k] = sq.x + sq.y;
+        const tv_f2 t = g[k] * 0.25f;
+        num[k] = pz[k] - t;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) s[k] = __builtin_amdgcn_sqrtf(x[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned a = tv_guard_word(x[k]), b = tv_guard_word(num[k].x), c = tv_guard_word(num[k].y);
+        guard = min(guard, min(a, min(b, c)));
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {            // v_sqrt_f32 is within 1 ulp: pick among s - 1 ulp, s, s + 1 ulp by the sign of the residuals
+        const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) - 1);
+        const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) + 1);
+        const float r1 = __builtin_fmaf(-sm, s[k], x[k]);
+        const float r2 = __builtin_fmaf(-sp, s[k], x[k]);
+        float q = (0.f >= r1) ? sm : s[k];
+        q = (0.f < r2) ? sp : q;
+        nrm[k] = q;
+    }
+    float den[R], rc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        float d = nrm[k] * tau_over_w;
+        den[k] = d + 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) rc[k] = __builtin_amdgcn_rcpf(den[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const float e = __builtin_fmaf(-den[k], rc[k], 1.f);
+        rc[k] = __builtin_fmaf(e, rc[k], rc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const tv_f2 r = {rc[k], rc[k]}, nd = {-den[k], -den[k]};
+        tv_f2 q = num[k] * r;
+        tv_f2 rem = __builtin_elementwise_fma(nd, q, num[k]);
+        q = __builtin_elementwise_fma(rem, r, q);
+        rem = __builtin_elementwise_fma(nd, q, num[k]);
+        pz[k] = __builtin_elementwise_fma(rem, r, q);
+    }
+    return guard;
+}
+
+// ... and with the compiler's correctly rounded sqrtf and division (every operand range)
+template <int R>
+__device__ __forceinline__ void tv_p_update_ieee(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        float n = sqrtf(g[k].x * g[k].x + g[k].y * g[k].y);
+        nrm[k] = n;
+        n = n * tau_over_w;
+        n = n + 1.f;
+        pz[k].x = (pz[k].x - 0.25f * g[k].x) / n;
+        pz[k].y = (pz[k].y - 0.25f * g[k].y) / n;
+    }
+}
+
+// clock stamps of one workgroup's first and last wave (build/variants/libscipnp_tvstamps.so, -DSCIPNP_TV_STAMPS: the candidate form
+// writes them behind the first 256 bytes of its otherwise unused stop_iter argument; tools/probes/tv_band_stamps.py)
+#if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define TVB_STAMP(slot)                                                                                                 \
+    do {                                                                                                                \
+        if (stamps) {                                                                                                   \
+            unsigned long long t_;                                                                                      \
+            const unsigned long long* p_ = stamps + (slot);                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t_) : "s"(p_) : "memory"); \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+    } while (0)
+#define TVB_REALTIME(slot)                                                                                              \
+    do {                                                                                                                \
+        if (stamps) {                                                                                                   \
+            unsigned long long t_;                                                                                      \
+            const unsigned long long* p_ = stamps + (slot);                                                             \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t_) : "s"(p_) : "memory"); \
+        }                                                                                                               \
+    } while (0)
+#else
+#define TVB_STAMP(slot) (void)0
+#define TVB_REALTIME(slot) (void)0
+#endif
+
+template <int COLS, int R, int STRIPS, bool FULLW>       // FULLW: N == COLS (no column mask anywhere)
+__device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, float coef, float* th, int M, int N,
+                                             int n_iter, int a_lo, int a_hi, int ext_lo, float tau_over_w, double* part_out,
+                                             float* cand = nullptr, size_t cand_stride = 0, unsigned long long* stamp_buf = nullptr) {
+    constexpr int WPS = COLS / 64;                       // waves per strip
+    constexpr int NW = COLS * STRIPS / 64;
+    constexpr int RP = (R + 3) & ~3;                     // seam vectors padded to 16 bytes
+    constexpr int NACC = 2 * TVB_HALO;
+    static_assert(NW >= NACC, "one wave per energy sum in the final reduction");
+    __shared__ float s_p0e[STRIPS + 1][COLS];            // [s+1]: p0 on the last row of strip s
+    __shared__ float s_oe[STRIPS + 1][COLS];             // [s]:   out on the first row of strip s
+    __shared__ __attribute__((aligned(16))) float s_p1e[STRIPS][WPS + 1][RP];   // [w+1]: p1 of wave w's last column
+    __shared__ __attribute__((aligned(16))) float s_oce[STRIPS][WPS + 1][RP];   // [w]:   out of wave w's first column
+    __shared__ double s_acc[NACC][COLS * STRIPS];        // every thread's energy sums (after the loop)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: strip and row conditions are wave-uniform
+    const int strip = wave / WPS, wcol = wave - strip * WPS;
+    const int col = wcol * 64 + lane;
+    const int r0 = ext_lo + strip * R;
+    const bool colok = FULLW || col < N, last_col = !FULLW && col >= N - 1;
+    const int kM = M - 1 - r0;                           // the image's last row inside this strip (if 0 <= kM < R)
+#if defined(SCIPNP_TV_STAMPS)
+    unsigned long long* const stamps = (stamp_buf && (wave == 0 || wave == NW - 1)) ? stamp_buf + (wave == 0 ? 0 : 64) : nullptr;
+#endif
+    TVB_REALTIME(60);
+    TVB_STAMP(0);
+
+    float v[R], out[R];
+    tv_f2 pz[R];
+    bool rowown[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = r0 + k;
+        rowown[k] = r < M && r >= a_lo && r < a_hi;
+        v[k] = (colok && r < M) ? tv_input(xc, bc, coef, (size_t)r * N + col) : 0.f;
+        pz[k] = tv_f2{0.f, 0.f};
+        out[k] = v[k];
+    }
+    // The edges of the image enter as operands that leave the arithmetic unchanged instead of as per-pixel selects: the dual
+    // field "above row 0" and "left of column 0" is -0 (d + -0 == d for every d, signed zeros included); the `out` "below the
+    // last row" / "right of the last column" is the edge pixel's own value (x - x == +0, what the reference's zero gradient is).
+    // Band edges that are not image edges get the same values: they only feed halo rows, which go stale by construction.
+    if (strip == 0) { s_p0e[0][col] = -0.f; s_oe[STRIPS][col] = 0.f; }
+    if (wcol == 0 && lane < RP) s_p1e[strip][0][lane] = -0.f;
+    if (wcol == WPS - 1 && lane < RP) s_oce[strip][WPS][lane] = 0.f;      // (FULLW: the same wave's lane 63 overwrites it below)
+    double a1s[TVB_HALO], a2s[TVB_HALO];
+#pragma unroll
+    for (int i = 0; i < TVB_HALO; ++i) { a1s[i] = 0.0; a2s[i] = 0.0; }
+#if defined(SCIPNP_TV_STAMPS)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TVB_STAMP(1);
+
+#pragma unroll 1
+    for (int it = 0; it < n_iter; ++it) {
+        double a1 = 0.0, a2 = 0.0;
+        TVB_STAMP(8 + 8 * it);
+        if (it > 0) {           // the seams of p were published before the barrier that closed iteration it-1
+            float sl[RP];
+#pragma unroll
+            for (int k = 0; k < RP; k += 4) *(float4*)&sl[k] = *(const float4*)&s_p1e[strip][wcol][k];
+            const float up0 = s_p0e[strip][col];
+            float left[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                left[k] = tv_lane_prev(pz[k].y);
+                if (lane == 0) left[k] = sl[k];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float up = k > 0 ? pz[k > 0 ? k - 1 : 0].x : up0;
+                float d = -(pz[k].x + pz[k].y);
+                d = d + up;
+                d = d + left[k];
+                out[k] = v[k] + d;
+                a1 += (double)((rowown[k] && colok) ? d * d : 0.f);      // (+0.0 for halo rows and columns >= N: the sum is unchanged)
+            }
+            if (cand) {         // candidate form: the band's own rows of EVERY iteration's `out` (the stop test picks one later)
+                float* cp = cand + (size_t)(it - 1) * cand_stride + (size_t)r0 * N + col;
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (rowown[k] && colok) cp[(size_t)k * N] = out[k];
+            }
+        }
+        TVB_STAMP(9 + 8 * it);
+        if (it == n_iter - 1) break;          // only `out` of the last iteration is used (its energy decides nothing)
+        if (kM >= 0 && kM < R - 1) {          // (one wave row of the launch) the row below the image's last row repeats it
+#pragma unroll
+            for (int k = 1; k < R; ++k)
+                if (k == kM + 1) out[k] = out[k - 1];
+        }
+        s_oe[strip][col] = out[0];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < RP; k += 4) {
+                float4 q;
+                q.x = out[k < R ? k : R - 1]; q.y = out[k + 1 < R ? k + 1 : R - 1];
+                q.z = out[k + 2 < R ? k + 2 : R - 1]; q.w = out[k + 3 < R ? k + 3 : R - 1];
+                *(float4*)&s_oce[strip][wcol][k] = q;
+            }
+        }
+        if (FULLW && wcol == WPS - 1 && lane == 63) {      // the last column's right neighbour is the column itself
+#pragma unroll
+            for (int k = 0; k < RP; k += 4) {
+                float4 q;
+                q.x = out[k < R ? k : R - 1]; q.y = out[k + 1 < R ? k + 1 : R - 1];
+                q.z = out[k + 2 < R ? k + 2 : R - 1]; q.w = out[k + 3 < R ? k + 3 : R - 1];
+                *(float4*)&s_oce[strip][WPS][k] = q;
+            }
+        }
+        __syncthreads();
+        TVB_STAMP(10 + 8 * it);
+        {
+            float sr[RP];
+#pragma unroll
+            for (int k = 0; k < RP; k += 4) *(float4*)&sr[k] = *(const float4*)&s_oce[strip][wcol + 1][k];
+            float downR = s_oe[strip + 1][col];
+            if (kM == R - 1) downR = out[R - 1];          // (wave-uniform)
+            tv_f2 g[R];
+            float nrm[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                float right = tv_lane_next(out[k]);
+                if (lane == 63) right = sr[k];
+                const float down = k + 1 < R ? out[k + 1 < R ? k + 1 : k] : downR;
+                g[k].x = down - out[k];
+                g[k].y = last_col ? 0.f : (right - out[k]);
+            }
+            tv_f2 pn[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) pn[k] = pz[k];
+            const unsigned guard = tv_p_update_fast<R>(g, pn, nrm, tau_over_w);
+            if (__any(guard < TVB_GUARD)) {           // an operand in (0, 2^-60): the general sqrtf and division (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < R; ++k) pn[k] = pz[k];
+                tv_p_update_ieee<R>(g, pn, nrm, tau_over_w);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                pz[k] = pn[k];
+                a2 += (double)((rowown[k] && colok) ? nrm[k] : 0.f);
+            }
+        }
+        TVB_STAMP(11 + 8 * it);
+        s_p0e[strip + 1][col] = pz[R - 1].x;
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < RP; k += 4) {
+                float4 q;
+                q.x = pz[k < R ? k : R - 1].y; q.y = pz[k + 1 < R ? k + 1 : R - 1].y;
+                q.z = pz[k + 2 < R ? k + 2 : R - 1].y; q.w = pz[k + 3 < R ? k + 3 : R - 1].y;
+                *(float4*)&s_p1e[strip][wcol + 1][k] = q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TVB_HALO; ++i)    // (it is scalar: two selects per double; keeps the loop rolled and the sums in registers)
+            if (it == i) { a1s[i] = a1; a2s[i] = a2; }
+        __syncthreads();                      // publishes the seams of p
+        TVB_STAMP(12 + 8 * it);
+    }
+    TVB_STAMP(50);
+    if (part_out) {
+        // the band's own-row partial energy sums of every iteration.  Through LDS, one wave per sum: eight 64-lane permute trees
+        // per wave (the round-2 form, 768 ds_bpermute per workgroup) measured 4100 clocks here -- the LDS pipe, not latency.
+        // (fp64 sums of exact fp32 terms in a fixed order: deterministic; the association differs from the round-2 kernel's in
+        // the last bits of a double, far below what the stop test -- which rounds the channel sums to float32 -- can see)
+#pragma unroll
+        for (int i = 0; i < TVB_HALO; ++i) { s_acc[2 * i][tid] = a1s[i]; s_acc[2 * i + 1][tid] = a2s[i]; }
+        TVB_STAMP(51);
+        __syncthreads();
+        if (wave < 2 * (n_iter - 1)) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) t += s_acc[wave][j * 64 + lane];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) part_out[wave] = t;
+        }
+        TVB_STAMP(52);
+    }
+    if (th) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (rowown[k] && colok) th[(size_t)(r0 + k) * N + col] = out[k];
+    }
+    TVB_STAMP(53);
+    TVB_REALTIME(61);
+#if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (stamps) asm volatile("s_dcache_wb" ::: "memory");      // (the scalar data cache is not written back at the end of a kernel)
+#endif
+}
+
+template <int COLS, int R, int STRIPS, int V2, typename... A>      // V2: 0 round-2 schedule, 1 round 5, 2 round 5 with N == COLS
+__device__ __forceinline__ void tv_band_go(A... a) {
+    if (V2 == 2) tv_band_run2<COLS, R, STRIPS, true>(a...);
+    else if (V2 == 1) tv_band_run2<COLS, R, STRIPS, false>(a...);
+    else tv_band_run<COLS, R, STRIPS>(a...);
+}
+
+template <int COLS, int R, int STRIPS, int STAGE, int V2>
 __global__ void __launch_bounds__(COLS* STRIPS)
 tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float coef, float* __restrict__ theta, int M, int N,
                int n_iter, int RB, int nbands, double weight, float tau_over_w, double eps, double* __restrict__ part,
@@ -471,7 +792,7 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     const float* xc = x + chan;
     const float* bc = b ? b + chan : nullptr;
     if (STAGE == 0) {
-        tv_band_run<COLS, R, STRIPS>(xc, bc, coef, theta + chan, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
+        tv_band_go<COLS, R, STRIPS, V2>(xc, bc, coef, theta + chan, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
                                      part + ((size_t)c * nbands + band) * 2 * n_iter);
         return;
     }
@@ -484,7 +805,15 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
         // second pass almost every time; and a "last band of the channel decides" scheme needs a device-scope fence per
         // workgroup -- an L2 write-back across the XCDs -- that costs more than the launch it saves (measured: 82 us against
         // 17 us for 32 planes of 128 x 128).
-        tv_band_run<COLS, R, STRIPS>(xc, bc, coef, nullptr, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
+#if defined(SCIPNP_TV_STAMPS)
+        if (V2) {
+            tv_band_run2<COLS, R, STRIPS, V2 == 2>(xc, bc, coef, nullptr, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
+                                          part + ((size_t)c * nbands + band) * 2 * n_iter, theta + chan, cand_stride,
+                                          (stop_iter && blockIdx.x == gridDim.x / 2 + 3) ? (unsigned long long*)(stop_iter + 64) : nullptr);
+            return;
+        }
+#endif
+        tv_band_go<COLS, R, STRIPS, V2>(xc, bc, coef, nullptr, M, N, n_iter, a_lo, a_hi, ext_lo, tau_over_w,
                                      part + ((size_t)c * nbands + band) * 2 * n_iter, theta + chan, cand_stride);
         return;
     }
@@ -500,7 +829,7 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     __syncthreads();
     const int stop_at = s_stop_at;
     if (stop_at == n_iter - 1) return;                   // theta already holds the `out` of the last iteration
-    tv_band_run<COLS, R, STRIPS>(xc, bc, coef, theta + chan, M, N, stop_at + 1, a_lo, a_hi, ext_lo, tau_over_w, nullptr);
+    tv_band_go<COLS, R, STRIPS, V2>(xc, bc, coef, theta + chan, M, N, stop_at + 1, a_lo, a_hi, ext_lo, tau_over_w, nullptr);
 }
 
 // band height for N <= 256: 16-row bands when 32-row bands would leave the chip short of workgroups
@@ -510,6 +839,13 @@ bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && 
 // bands (twice the workgroups, 16 computed rows per 8 useful ones)
 static bool tv_tiny_bands() {
     static const bool on = [] { const char* e = getenv("SCIPNP_TV_TINY_BANDS"); return e && e[0] == '1'; }();
+    return on;
+}
+
+// experiment switch (SCIPNP_TV_BAND_V1=1): the round-2 schedule of the band computation (tv_band_run) instead of round 5's
+// (tv_band_run2) -- same results, for A/B timing
+static bool tv_band_v1() {
+    static const bool on = [] { const char* e = getenv("SCIPNP_TV_BAND_V1"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -529,20 +865,27 @@ static int tv_band_launch(const float* x, const float* b, float coef, float* the
     int RB, nbands;
     tv_band_geometry(M, C, &RB, &nbands);
     const bool small = RB == 16, tiny = RB == 8;
+    const bool v1 = tv_band_v1();
     const dim3 grid((unsigned)(C * nbands));
     const size_t img = (size_t)C * M * N;
-#define SCIPNP_TVB(COLS, R, STRIPS, RBV)                                                                                \
+#define SCIPNP_TVB_(COLS, R, STRIPS, RBV, V2)                                                                               \
     do {                                                                                                                \
         static_assert(STRIPS * R >= RBV + 2 * TVB_HALO, "a workgroup's rows must cover its band + both halos");        \
         if (candidates) {                                                                                               \
-            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 3>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, candidates, M, \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 3, V2>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, candidates, M, \
                                N, n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);               \
         } else {                                                                                                        \
-            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 0, V2>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
                                n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);                  \
-            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
+            hipLaunchKernelGGL((tv_band_kernel<COLS, R, STRIPS, 1, V2>), grid, dim3(COLS * STRIPS), 0, st, x, b, coef, theta, M, N, \
                                n_iter, RB, nbands, weight_d, tau_over_w, eps_d, part, stop_iter, img);                  \
         }                                                                                                               \
+    } while (0)
+#define SCIPNP_TVB(COLS, R, STRIPS, RBV)                                                                                \
+    do {                                                                                                                \
+        if (v1) SCIPNP_TVB_(COLS, R, STRIPS, RBV, 0);                                                                   \
+        else if (N == COLS) SCIPNP_TVB_(COLS, R, STRIPS, RBV, 2);                                                       \
+        else SCIPNP_TVB_(COLS, R, STRIPS, RBV, 1);                                                                      \
     } while (0)
     if (N <= 64) {
         if (tiny) SCIPNP_TVB(64, 2, 8, 8); else if (small) SCIPNP_TVB(64, 3, 8, 16); else SCIPNP_TVB(64, 5, 8, 32);
@@ -552,6 +895,7 @@ static int tv_band_launch(const float* x, const float* b, float coef, float* the
         if (tiny) SCIPNP_TVB(256, 4, 4, 8); else if (small) SCIPNP_TVB(256, 6, 4, 16); else SCIPNP_TVB(256, 10, 4, 32);
     }
 #undef SCIPNP_TVB
+#undef SCIPNP_TVB_
     return launch_status("tv_band_kernel");
 }
 

@@ -1242,6 +1242,34 @@ def test_tv_banded_kernel_random_shapes(ops):
         assert torch.equal(o1, o3), (M, N, C_, n_iter)
 
 
+def test_tv_banded_kernel_tiny_operands_take_the_general_path(ops):
+    """round 5: the banded kernel writes out sqrt and the two divisions of the dual update itself (csrc/tv.hip tv_p_update_fast:
+    v_sqrt + 1-ulp fix-up, one shared reciprocal refinement, no operand scaling) and a wave falls back to the compiler's
+    correctly rounded sqrtf and '/' when a gradient energy or a numerator lies in (0, 2^-60) -- amplitudes from 1 down to the
+    denormals, alone and mixed inside one wave, flat (all-zero-gradient) regions included: bit-identical to the tiled kernel,
+    which only uses sqrtf and '/'"""
+    rng = np.random.default_rng(2025)
+    M, N = 70, 128
+    scales = [1.0, 1e-9, 1e-15, 1e-20, 1e-25, 1e-32, 1e-38, 3e-42, 0.0]
+    base = rng.uniform(0, 1, (len(scales) + 3, M, N)).astype(np.float32)
+    for c, sc in enumerate(scales):
+        base[c] *= np.float32(sc)
+    base[-3, :, 40:] *= np.float32(1e-24)             # one wave, both regimes
+    base[-2, 20:50, :] = 0.25                         # a flat region inside a normal image
+    base[-1, ::2, :] *= np.float32(1e-30)             # alternating rows
+    x = dev(base)
+    for b, coef in ((None, 0.0), (dev((rng.normal(0, 1, base.shape) * 1e-28).astype(np.float32)), 1.0)):
+        for n_iter in (2, 5):
+            p1, p3 = ops.TvPlan(M, N, x.shape[0], n_iter, x.device), ops.TvPlan(M, N, x.shape[0], n_iter, x.device)
+            o1, o3, o4 = torch.empty_like(x), torch.full_like(x, -5.0), torch.full_like(x, -6.0)
+            ops.tv_chambolle(x, b, coef, o1, p1, 0.1, kernel=1)
+            ops.tv_chambolle(x, b, coef, o3, p3, 0.1, kernel=3)
+            assert torch.equal(p1.stop_iter, p3.stop_iter), (n_iter, p1.stop_iter, p3.stop_iter)
+            assert torch.equal(o1, o3), n_iter
+            ops.tv_chambolle(x, b, coef, o4, p3, 0.1, kernel=4)
+            assert torch.equal(o1, o4) and torch.equal(p1.stop_iter, p3.stop_iter), n_iter
+
+
 def test_conv3x3_winograd_f4_three_waves_per_simd_equals_the_product_kernel(ops):
     """Both three-waves-per-SIMD prototypes of round 5 (profiles/r05a_*, r05e_*: measured slower, not adopted).
     csrc/conv_wino4x.hip (LABORATORY, libscipnp_diag.so; round 5) -- the F(4x4,3x3) convolution with a tile's 36 positions split
