@@ -180,6 +180,31 @@ int tv_band_candidates(const float* x, const float* b, float coef, int M, int N,
 int tv_stop_test_launch(const TvCandidates& cd, int C, float weight, float eps, hipStream_t st);
 double tv_scalar_as_double(float f);     // weight / eps: the shortest decimal that round-trips the float (tv.hip as_double)
 
+// State handed from one launch of the ADMM-TV iteration to the next (the band kernel's candidates and partial sums; theta / b / x
+// of the fused dual update + projection) is stored NON-TEMPORALLY: the consumer runs on all eight XCDs, whose L2s are not coherent
+// with each other, so these lines have to reach the memory side before the next launch can read them -- written through as they
+// are produced instead of in the end-of-kernel write-back, the iteration at 256x256x8 takes 22.4 us instead of 24.4
+// (profiles/r05zd_*; -DSCIPNP_TV_NT=0 builds the plain stores, =2 also loads the hand-off state non-temporally).
+#ifndef SCIPNP_TV_NT
+#define SCIPNP_TV_NT 1
+#endif
+template <typename T>
+__device__ __forceinline__ void tv_handoff_store(T* p, T v) {
+#if SCIPNP_TV_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T tv_handoff_load(const T* p) {
+#if SCIPNP_TV_NT >= 2
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // skimage's stop test of one channel from the partial sums of its bands (pc[band][it][2] = sum d^2, sum |grad|): executed by
 // ONE FULL WAVE (all 64 lanes call it); lane l sums bands l, l+64, ... in order, then a fixed shuffle tree -- the same sums in
 // the same order wherever it is evaluated -- and every lane returns the iteration whose `out` skimage keeps.

@@ -628,7 +628,9 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
 // trip; y and Phisum a third) -- 12.2 us for 28 MB on a 2 MB state (profiles/r03d_*).  Here every wave loads the stop-test
 // operands FIRST, then every other operand including ALL (n_iter - 1) candidates of its pixel (6 MB of extra reads that never
 // leave the memory-side cache), evaluates the test itself while those are in flight (no LDS, no barrier; E / MN as an exact
-// scaling when M*N is a power of two) and picks the candidate in registers.  Same expressions in the same order as the general
+// scaling when M*N is a power of two) and picks the candidate in registers.  (Loading only the candidate the channel kept in the
+// previous ADMM iteration, the right one after the test where that prediction fails, measured the same 8.7 us: the kernel is
+// as deep as its one round trip, not as wide as its reads -- profiles/r05zf_*.)  Same expressions in the same order as the general
 // kernel: theta, b, x and the squared-error partials are bit-identical to it.
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -649,8 +651,8 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
     for (int t = 0; t < MAXB; ++t) {
         if (t < B) {
             const size_t o = (size_t)t * Q + q;
-            xr[t] = xio[o];
-            br[t] = bb[o];
+            xr[t] = tv_handoff_load(xio + o);
+            br[t] = tv_handoff_load(bb + o);
             ph[t] = Phi[o];
         }
     }
@@ -659,7 +661,7 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
     for (int it = 0; it < TV_STOP_MAXIT; ++it) {
 #pragma unroll
         for (int t = 0; t < MAXB; ++t)
-            cr[it][t] = (t < B && it < cd.n_iter - 1) ? cd.cand[(size_t)it * ((size_t)B * Q) + (size_t)t * Q + q] : 0.f;
+            cr[it][t] = (t < B && it < cd.n_iter - 1) ? tv_handoff_load(cd.cand + (size_t)it * ((size_t)B * Q) + (size_t)t * Q + q) : 0.f;
     }
     if (sse_part) {
 #pragma unroll
@@ -678,8 +680,8 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
             const float d = xr[t] - th;
             const float bn = (MODE == 0) ? (br[t] + d) : (br[t] - d);
             p[t] = (MODE == 0) ? (th - c0 * bn) : (th + bn);
-            theta[o] = th;
-            bb[o] = bn;
+            tv_handoff_store(theta + o, th);
+            tv_handoff_store(bb + o, bn);
             if (sse_part) {
                 const float e = og[t] - (MODE == 0 ? th : xr[t]);
                 acc += (double)(e * e);
@@ -690,10 +692,10 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
     const float r = (MODE == 0) ? (yv - yb) / (c1 + sv) : (yv - yb) / (sv + c1);
 #pragma unroll
     for (int t = 0; t < MAXB; ++t)
-        if (t < B) xio[(size_t)t * Q + q] = (MODE == 0) ? (p[t] + ph[t] * r) : (p[t] + c0 * (r * ph[t]));
+        if (t < B) tv_handoff_store(xio + (size_t)t * Q + q, (MODE == 0) ? (p[t] + ph[t] * r) : (p[t] + c0 * (r * ph[t])));
     if (sse_part) {
         const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
-        if (threadIdx.x == 0) sse_part[blockIdx.x] = s;
+        if (threadIdx.x == 0) tv_handoff_store(sse_part + blockIdx.x, s);
         if (blockIdx.x == 0)
             for (int i = gridDim.x + threadIdx.x; i < nfill; i += blockDim.x) sse_part[i] = 0.0;
     }

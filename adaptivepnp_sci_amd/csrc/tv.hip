@@ -58,6 +58,10 @@ __device__ __forceinline__ float tv_input(const float* __restrict__ x, const flo
                                           size_t o) {
     return b ? (x[o] + coef * b[o]) : x[o];
 }
+// (the band kernels of round 5: x and b are the previous launch's hand-off state)
+__device__ __forceinline__ float tv_input_handoff(const float* __restrict__ x, const float* __restrict__ b, float coef, size_t o) {
+    return b ? (tv_handoff_load(x + o) + coef * tv_handoff_load(b + o)) : tv_handoff_load(x + o);
+}
 
 // `out` of the current iteration at (r,c) from the previous dual field (global memory, cache-served)
 // (x, b, p0, p1 already point at this channel's image)
@@ -616,7 +620,7 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
     for (int k = 0; k < R; ++k) {
         const int r = r0 + k;
         rowown[k] = r < M && r >= a_lo && r < a_hi;
-        v[k] = (colok && r < M) ? tv_input(xc, bc, coef, (size_t)r * N + col) : 0.f;
+        v[k] = (colok && r < M) ? tv_input_handoff(xc, bc, coef, (size_t)r * N + col) : 0.f;
         pz[k] = tv_f2{0.f, 0.f};
         out[k] = v[k];
     }
@@ -663,7 +667,7 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
                 float* cp = cand + (size_t)(it - 1) * cand_stride + (size_t)r0 * N + col;
 #pragma unroll
                 for (int k = 0; k < R; ++k)
-                    if (rowown[k] && colok) cp[(size_t)k * N] = out[k];
+                    if (rowown[k] && colok) tv_handoff_store(cp + (size_t)k * N, out[k]);
             }
         }
         TVB_STAMP(9 + 8 * it);
@@ -757,7 +761,7 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
 #pragma unroll
             for (int j = 0; j < NW; ++j) t += s_acc[wave][j * 64 + lane];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-            if (lane == 0) part_out[wave] = t;
+            if (lane == 0) tv_handoff_store(part_out + wave, t);
         }
         TVB_STAMP(52);
     }
