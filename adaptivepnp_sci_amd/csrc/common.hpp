@@ -205,6 +205,32 @@ __device__ __forceinline__ T tv_handoff_load(const T* p) {
 #endif
 }
 
+// a double moved between lanes by DPP (two 32-bit VALU moves; lanes without a source read 0): CTRL 0x100 + n = row_shl:n (lane l
+// reads lane l + n of its row of 16), 0x110 + n = row_shr:n -- the ds_bpermute pairs that __shfl_down(double) compiles to go
+// through the LDS pipe (8 waves reducing 8 doubles each measured 4100 clocks in the round-5 band kernel)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum of one double per lane over the wave, the same value in every lane (fixed order: rows of 16 by a shift tree, then the rows)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0x111>(v);
+    v += dpp_f64<0x112>(v);
+    v += dpp_f64<0x114>(v);
+    v += dpp_f64<0x118>(v);
+    const double r0 = readlane_f64(v, 15), r1 = readlane_f64(v, 31), r2 = readlane_f64(v, 47), r3 = readlane_f64(v, 63);
+    return (r0 + r1) + (r2 + r3);
+}
+
 // skimage's stop test of one channel from the partial sums of its bands (pc[band][it][2] = sum d^2, sum |grad|): executed by
 // ONE FULL WAVE (all 64 lanes call it); lane l sums bands l, l+64, ... in order, then a fixed shuffle tree -- the same sums in
 // the same order wherever it is evaluated -- and every lane returns the iteration whose `out` skimage keeps.
@@ -263,12 +289,23 @@ __device__ __forceinline__ void tv_band_stop_load8(const double* __restrict__ pc
 }
 __device__ __forceinline__ int tv_band_stop_finish8(double (&s1)[TV_STOP_MAXIT], double (&s2)[TV_STOP_MAXIT], int n_iter, size_t MN,
                                                     double weight, double eps, double inv_mn = 0.0) {
+    // v[l] += v[l + 4], v[l + 2], v[l + 1] by DPP row shifts: the lanes with band 0 (l = 0, 8 of a row of 16) add exactly the terms
+    // of their own 8-lane segment in the order of __shfl_down(., off, 8) -- the other lanes hold nothing that is used
 #pragma unroll
-    for (int it = 0; it < TV_STOP_MAXIT; ++it)
-        for (int off = 4; off > 0; off >>= 1) {
-            s1[it] += __shfl_down(s1[it], off, 8);
-            s2[it] += __shfl_down(s2[it], off, 8);
-        }
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
+        s1[it] += dpp_f64<0x104>(s1[it]);
+        s2[it] += dpp_f64<0x104>(s2[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
+        s1[it] += dpp_f64<0x102>(s1[it]);
+        s2[it] += dpp_f64<0x102>(s2[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
+        s1[it] += dpp_f64<0x101>(s1[it]);
+        s2[it] += dpp_f64<0x101>(s2[it]);
+    }
     double E0 = 0.0, Eprev = 0.0;
     int stop_at = n_iter - 1;
 #pragma unroll

@@ -631,9 +631,6 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
     if (strip == 0) { s_p0e[0][col] = -0.f; s_oe[STRIPS][col] = 0.f; }
     if (wcol == 0 && lane < RP) s_p1e[strip][0][lane] = -0.f;
     if (wcol == WPS - 1 && lane < RP) s_oce[strip][WPS][lane] = 0.f;      // (FULLW: the same wave's lane 63 overwrites it below)
-    double a1s[TVB_HALO], a2s[TVB_HALO];
-#pragma unroll
-    for (int i = 0; i < TVB_HALO; ++i) { a1s[i] = 0.0; a2s[i] = 0.0; }
 #if defined(SCIPNP_TV_STAMPS)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -740,9 +737,8 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
                 *(float4*)&s_p1e[strip][wcol + 1][k] = q;
             }
         }
-#pragma unroll
-        for (int i = 0; i < TVB_HALO; ++i)    // (it is scalar: two selects per double; keeps the loop rolled and the sums in registers)
-            if (it == i) { a1s[i] = a1; a2s[i] = a2; }
+        s_acc[2 * it][tid] = a1;              // (the thread's own words: read back after the loop; keeps the loop rolled without
+        s_acc[2 * it + 1][tid] = a2;          // a register per iteration -- selecting one by `it` cost 16 v_cndmask on VCC)
         __syncthreads();                      // publishes the seams of p
         TVB_STAMP(12 + 8 * it);
     }
@@ -752,15 +748,12 @@ __device__ __forceinline__ void tv_band_run2(const float* xc, const float* bc, f
         // per wave (the round-2 form, 768 ds_bpermute per workgroup) measured 4100 clocks here -- the LDS pipe, not latency.
         // (fp64 sums of exact fp32 terms in a fixed order: deterministic; the association differs from the round-2 kernel's in
         // the last bits of a double, far below what the stop test -- which rounds the channel sums to float32 -- can see)
-#pragma unroll
-        for (int i = 0; i < TVB_HALO; ++i) { s_acc[2 * i][tid] = a1s[i]; s_acc[2 * i + 1][tid] = a2s[i]; }
         TVB_STAMP(51);
-        __syncthreads();
-        if (wave < 2 * (n_iter - 1)) {
+        if (wave < 2 * (n_iter - 1)) {        // (the loop's last barrier has published every thread's sums)
             double t = 0.0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) t += s_acc[wave][j * 64 + lane];
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            t = wave_sum_f64(t);
             if (lane == 0) tv_handoff_store(part_out + wave, t);
         }
         TVB_STAMP(52);

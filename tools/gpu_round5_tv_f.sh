@@ -5,7 +5,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r05zd}
 cd /tmp && export TMPDIR=/tmp
-for v in product nt0 nt2; do
+for v in ${VARIANTS:-product}; do
   unset SCIPNP_LIB
   [ $v != product ] && export SCIPNP_LIB=$GRAFT_REPO_ROOT/build/variants/libscipnp_tv$v.so
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/${TAG}_iter_$v
