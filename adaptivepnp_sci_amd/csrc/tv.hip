@@ -191,6 +191,90 @@ tv_iter_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
     }
 }
 
+// ---- round 5: the dual update of R pixels of one thread written out (used by the banded kernel tv_band_run2 and the whole-plane
+// kernel): see the comment on tv_band_run2 below for what is shared and guarded
+typedef float tv_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float tv_lane_prev(float v) {      // lane l <- lane l - 1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float tv_lane_next(float v) {      // lane l <- lane l + 1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// guard word of a non-negative-or-signed operand: (|bits| << 1) - 1 -- zero maps to the largest unsigned, anything in
+// (0, 2^-60) below TVB_GUARD
+constexpr unsigned TVB_GUARD = (0x21800000u << 1) - 1u;      // bits(2^-60) = 0x21800000
+__device__ __forceinline__ unsigned tv_guard_word(float f) { return (__builtin_bit_cast(unsigned, f) << 1) - 1u; }
+
+// the p-update of R pixels of one thread: g[k] = (g0, g1), pz[k] = (p0, p1) in, pz out; nrm[k] out; returns the guard word
+template <int R>
+__device__ __forceinline__ unsigned tv_p_update_fast(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
+    float x[R], s[R];
+    tv_f2 num[R];
+    unsigned guard = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const tv_f2 sq = g[k] * g[k];
+        x[k] = sq.x + sq.y;
+        const tv_f2 t = g[k] * 0.25f;
+        num[k] = pz[k] - t;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) s[k] = __builtin_amdgcn_sqrtf(x[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned a = tv_guard_word(x[k]), b = tv_guard_word(num[k].x), c = tv_guard_word(num[k].y);
+        guard = min(guard, min(a, min(b, c)));
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {            // v_sqrt_f32 is within 1 ulp: pick among s - 1 ulp, s, s + 1 ulp by the sign of the residuals
+        const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) - 1);
+        const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) + 1);
+        const float r1 = __builtin_fmaf(-sm, s[k], x[k]);
+        const float r2 = __builtin_fmaf(-sp, s[k], x[k]);
+        float q = (0.f >= r1) ? sm : s[k];
+        q = (0.f < r2) ? sp : q;
+        nrm[k] = q;
+    }
+    float den[R], rc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        float d = nrm[k] * tau_over_w;
+        den[k] = d + 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) rc[k] = __builtin_amdgcn_rcpf(den[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const float e = __builtin_fmaf(-den[k], rc[k], 1.f);
+        rc[k] = __builtin_fmaf(e, rc[k], rc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const tv_f2 r = {rc[k], rc[k]}, nd = {-den[k], -den[k]};
+        tv_f2 q = num[k] * r;
+        tv_f2 rem = __builtin_elementwise_fma(nd, q, num[k]);
+        q = __builtin_elementwise_fma(rem, r, q);
+        rem = __builtin_elementwise_fma(nd, q, num[k]);
+        pz[k] = __builtin_elementwise_fma(rem, r, q);
+    }
+    return guard;
+}
+
+// ... and with the compiler's correctly rounded sqrtf and division (every operand range)
+template <int R>
+__device__ __forceinline__ void tv_p_update_ieee(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        float n = sqrtf(g[k].x * g[k].x + g[k].y * g[k].y);
+        nrm[k] = n;
+        n = n * tau_over_w;
+        n = n + 1.f;
+        pz[k].x = (pz[k].x - 0.25f * g[k].x) / n;
+        pz[k].y = (pz[k].y - 0.25f * g[k].y) / n;
+    }
+}
+
 // ---- whole-plane variant for M, N <= 128: ONE launch for all n_iter_max iterations, one 1024-thread workgroup per
 // channel.  Thread (column, strip) keeps its R = ceil(M/8) rows of image, dual field and `out` in registers; row
 // neighbours inside a strip are register neighbours, column neighbours are wave neighbours (DPP shuffles); only the
@@ -211,18 +295,25 @@ struct TvDual {
     float sign;
 };
 
-template <int TVP_COLS, int TVP_R, bool DUAL>
+// V2 (round 5): the same iteration with the band kernel's instruction diet -- lane neighbours by DPP wave shifts, the wave seams
+// as one broadcast LDS read per phase, the dual update through tv_p_update_fast in chunks of four rows (general-path fallback per
+// chunk), the wave's energy sums by DPP row shifts + readlane instead of 24 ds_bpermute -- bit-identical `out`; the energy
+// sums associate differently inside a wave (fp64, far below the float32 the stop test rounds them to).  SCIPNP_TV_PLANE_V1=1
+// launches the round-2 form (A/B).
+template <int TVP_COLS, int TVP_R, bool DUAL, bool V2>
 __global__ void __launch_bounds__(TVP_THREADS)
 tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
                 int N, int n_iter, double weight, float tau_over_w, double eps, int32_t* __restrict__ stop_iter, TvDual dual) {
     constexpr int TVP_STRIPS = TVP_THREADS / TVP_COLS;
     __shared__ float s_p0e[TVP_STRIPS + 1][TVP_COLS];   // [s+1]: p0 on the last row of strip s
     __shared__ float s_oe[TVP_STRIPS + 1][TVP_COLS];    // [s]:   out on the first row of strip s
-    __shared__ float s_p1e[TVP_STRIPS][TVP_R];          // p1 of column 63 (read by column 64)
-    __shared__ float s_oce[TVP_STRIPS][TVP_R];          // out of column 64 (read by column 63)
+    __shared__ __attribute__((aligned(16))) float s_p1e[TVP_STRIPS][TVP_R];          // p1 of column 63 (read by column 64)
+    __shared__ __attribute__((aligned(16))) float s_oce[TVP_STRIPS][TVP_R];          // out of column 64 (read by column 63)
     __shared__ double s_red[2][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = tid & (TVP_COLS - 1), strip = tid / TVP_COLS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = V2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const int col = V2 ? (wave % (TVP_COLS / 64)) * 64 + lane : (tid & (TVP_COLS - 1));
+    const int strip = V2 ? wave / (TVP_COLS / 64) : tid / TVP_COLS;
     const int R = (M + TVP_STRIPS - 1) / TVP_STRIPS;
     const int r0 = strip * R;
     const size_t chan = (size_t)blockIdx.x * M * N;
@@ -245,6 +336,74 @@ tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
     int stop_at = n_iter - 1;
     for (int it = 0; it < n_iter; ++it) {
         double a1 = 0.0, a2 = 0.0;
+        if (V2) {
+            if (it > 0) {           // the seams of p were published before the barrier that closed iteration it-1
+                const float up0 = s_p0e[strip][col];
+#pragma unroll
+                for (int k = 0; k < TVP_R; ++k) {
+                    float sl[4];                                   // (one 16-byte broadcast read per four rows)
+                    if (k % 4 == 0) *(float4*)&sl[0] = *(const float4*)&s_p1e[strip][k];
+                    float left = tv_lane_prev(p1[k]);
+                    if (lane == 0) left = sl[k % 4];
+                    const float up = k > 0 ? p0[k > 0 ? k - 1 : 0] : up0;
+                    float d = -(p0[k] + p1[k]);
+                    if (k > 0 || r0 > 0) d = d + up;
+                    if (col > 0) d = d + left;
+                    out[k] = v[k] + d;
+                    a1 += (double)(ok[k] ? d * d : 0.f);
+                }
+                if (it == n_iter - 1) break;      // only `out` of the last iteration is used
+            }
+            s_oe[strip][col] = out[0];
+            if (col == 64) {
+#pragma unroll
+                for (int k = 0; k < TVP_R; k += 4) *(float4*)&s_oce[strip][k] = float4{out[k], out[k + 1], out[k + 2], out[k + 3]};
+            }
+            __syncthreads();
+            const float downR = s_oe[strip + 1][col];
+            const bool gcol = col < N - 1;
+            constexpr int CH = TVP_R >= 16 ? 2 : 4;          // rows per pass of the dual update (16 rows per thread: 128 VGPRs)
+            float sr[4];
+#pragma unroll
+            for (int c0 = 0; c0 < TVP_R; c0 += CH) {
+                tv_f2 g[CH], pn[CH];
+                float nrm[CH];
+                if (c0 % 4 == 0) *(float4*)&sr[0] = *(const float4*)&s_oce[strip][c0];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int k = c0 + j;
+                    float right = tv_lane_next(out[k]);
+                    if (lane == 63) right = sr[k % 4];
+                    float down = downR;
+                    if (k + 1 < TVP_R && k + 1 < R) down = out[k + 1 < TVP_R ? k + 1 : k];
+                    g[j].x = (r0 + k < M - 1) ? (down - out[k]) : 0.f;
+                    g[j].y = gcol ? (right - out[k]) : 0.f;
+                    pn[j] = tv_f2{p0[k], p1[k]};
+                }
+                const unsigned guard = tv_p_update_fast<CH>(g, pn, nrm, tau_over_w);
+                if (__any(guard < TVB_GUARD)) {       // an operand in (0, 2^-60): the general sqrtf and division (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) pn[j] = tv_f2{p0[c0 + j], p1[c0 + j]};
+                    tv_p_update_ieee<CH>(g, pn, nrm, tau_over_w);
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int k = c0 + j;
+                    p0[k] = pn[j].x;
+                    p1[k] = pn[j].y;
+                    a2 += (double)(ok[k] ? nrm[j] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TVP_R; ++k)
+                if (k == R - 1) s_p0e[strip + 1][col] = p0[k];
+            if (col == 63) {
+#pragma unroll
+                for (int k = 0; k < TVP_R; k += 4) *(float4*)&s_p1e[strip][k] = float4{p1[k], p1[k + 1], p1[k + 2], p1[k + 3]};
+            }
+            a1 = wave_sum_f64(a1);
+            a2 = wave_sum_f64(a2);
+        } else {
         if (it > 0) {           // the seams of p were published before the barrier that closed iteration it-1
 #pragma unroll
             for (int k = 0; k < TVP_R; ++k) {
@@ -286,6 +445,7 @@ tv_plane_kernel(const float* x, const float* b, float coef, float* theta, int M,
         for (int off = 32; off > 0; off >>= 1) {
             a1 += __shfl_down(a1, off, 64);
             a2 += __shfl_down(a2, off, 64);
+        }
         }
         if (lane == 0) { s_red[0][wave] = a1; s_red[1][wave] = a2; }
         __syncthreads();
@@ -478,88 +638,6 @@ __device__ __forceinline__ void tv_band_run(const float* xc, const float* bc, fl
 //     can produce and which reaches `out` only through an input pixel that is itself -0);
 //   * the pixels of a thread go through each stage together (gradients, sqrt, reciprocal, quotients), so the quarter-rate
 //     v_sqrt / v_rcp results and the compare -> select hazards of one pixel are covered by the next pixel's instructions.
-typedef float tv_f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float tv_lane_prev(float v) {      // lane l <- lane l - 1 (lane 0: 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float tv_lane_next(float v) {      // lane l <- lane l + 1 (lane 63: 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-// guard word of a non-negative-or-signed operand: (|bits| << 1) - 1 -- zero maps to the largest unsigned, anything in
-// (0, 2^-60) below TVB_GUARD
-constexpr unsigned TVB_GUARD = (0x21800000u << 1) - 1u;      // bits(2^-60) = 0x21800000
-__device__ __forceinline__ unsigned tv_guard_word(float f) { return (__builtin_bit_cast(unsigned, f) << 1) - 1u; }
-
-// the p-update of R pixels of one thread: g[k] = (g0, g1), pz[k] = (p0, p1) in, pz out; nrm[k] out; returns the guard word
-template <int R>
-__device__ __forceinline__ unsigned tv_p_update_fast(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
-    float x[R], s[R];
-    tv_f2 num[R];
-    unsigned guard = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const tv_f2 sq = g[k] * g[k];
-        x[k] = sq.x + sq.y;
-        const tv_f2 t = g[k] * 0.25f;
-        num[k] = pz[k] - t;
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) s[k] = __builtin_amdgcn_sqrtf(x[k]);
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const unsigned a = tv_guard_word(x[k]), b = tv_guard_word(num[k].x), c = tv_guard_word(num[k].y);
-        guard = min(guard, min(a, min(b, c)));
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) {            // v_sqrt_f32 is within 1 ulp: pick among s - 1 ulp, s, s + 1 ulp by the sign of the residuals
-        const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) - 1);
-        const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) + 1);
-        const float r1 = __builtin_fmaf(-sm, s[k], x[k]);
-        const float r2 = __builtin_fmaf(-sp, s[k], x[k]);
-        float q = (0.f >= r1) ? sm : s[k];
-        q = (0.f < r2) ? sp : q;
-        nrm[k] = q;
-    }
-    float den[R], rc[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        float d = nrm[k] * tau_over_w;
-        den[k] = d + 1.f;
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) rc[k] = __builtin_amdgcn_rcpf(den[k]);
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const float e = __builtin_fmaf(-den[k], rc[k], 1.f);
-        rc[k] = __builtin_fmaf(e, rc[k], rc[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const tv_f2 r = {rc[k], rc[k]}, nd = {-den[k], -den[k]};
-        tv_f2 q = num[k] * r;
-        tv_f2 rem = __builtin_elementwise_fma(nd, q, num[k]);
-        q = __builtin_elementwise_fma(rem, r, q);
-        rem = __builtin_elementwise_fma(nd, q, num[k]);
-        pz[k] = __builtin_elementwise_fma(rem, r, q);
-    }
-    return guard;
-}
-
-// ... and with the compiler's correctly rounded sqrtf and division (every operand range)
-template <int R>
-__device__ __forceinline__ void tv_p_update_ieee(const tv_f2 (&g)[R], tv_f2 (&pz)[R], float (&nrm)[R], float tau_over_w) {
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        float n = sqrtf(g[k].x * g[k].x + g[k].y * g[k].y);
-        nrm[k] = n;
-        n = n * tau_over_w;
-        n = n + 1.f;
-        pz[k].x = (pz[k].x - 0.25f * g[k].x) / n;
-        pz[k].y = (pz[k].y - 0.25f * g[k].y) / n;
-    }
-}
-
 // clock stamps of one workgroup's first and last wave (build/variants/libscipnp_tvstamps.so, -DSCIPNP_TV_STAMPS: the candidate form
 // writes them behind the first 256 bytes of its otherwise unused stop_iter argument; tools/probes/tv_band_stamps.py)
 #if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -932,21 +1010,25 @@ static int tv_plane_launch(const float* x, const float* b, float coef, float* th
                            hipStream_t st) {
     // rows per thread: ceil(M / strips), strips = 1024 / columns
     const TvDual d = dual ? *dual : TvDual{};
-#define SCIPNP_TVP(COLS, R)                                                                                             \
+    static const bool plane_v1 = [] { const char* e = getenv("SCIPNP_TV_PLANE_V1"); return e && e[0] == '1'; }();
+#define SCIPNP_TVP_(COLS, R, V2)                                                                                        \
     do {                                                                                                                \
         if (dual)                                                                                                       \
-            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, true>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
+            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, true, V2>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
                                N, n_iter_max, weight_d, tau_over_w, eps_d, stop_iter, d);                                \
         else                                                                                                            \
-            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, false>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
+            hipLaunchKernelGGL((tv_plane_kernel<COLS, R, false, V2>), dim3(C), dim3(TVP_THREADS), 0, st, x, b, coef, theta, M, \
                                N, n_iter_max, weight_d, tau_over_w, eps_d, stop_iter, d);                                \
     } while (0)
+#define SCIPNP_TVP(COLS, R)                                                                                             \
+    do { if (plane_v1) SCIPNP_TVP_(COLS, R, false); else SCIPNP_TVP_(COLS, R, true); } while (0)
     if (N <= 64) {
         if (M <= 64) SCIPNP_TVP(64, 4); else SCIPNP_TVP(64, 8);
     } else {
         if (M <= 64) SCIPNP_TVP(128, 8); else SCIPNP_TVP(128, 16);
     }
 #undef SCIPNP_TVP
+#undef SCIPNP_TVP_
     return launch_status("tv_plane_kernel");
 }
 

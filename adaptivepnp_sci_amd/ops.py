@@ -412,10 +412,12 @@ def wino_f4_enabled():
 
 
 def wino_f4_shape(Cin, Cout):
-    """layer shapes the F(4x4,3x3) kernel is used for: its workgroup computes 32 output channels -- a narrower output is padding
-    there (96 -> 16: 89 against 81 us) -- and needs at least two 8-channel groups to get its pipeline going (16 -> 96: 86 against
-    107 us, profiles/r03f_wino4_check.txt)"""
-    return Cin >= 16 and Cout >= 32
+    """layer shapes the F(4x4,3x3) kernel is used for: at least 24 output channels.  Its workgroup computes 32 output channels,
+    so a narrower layer pays for the padding: 96 -> 16 (FFDNet's tail) 92 against 76 us, 24 -> 8 322 against 313 us on F(2x2),
+    but 96 -> 24 (DDnet, 24 evaluations of 512 x 512) 1049 against 1374 us, 24 -> 24 386 against 516 us; the input width does
+    not matter at these sizes (8 -> 96: 743 against 946 us; until round 5 the rule also asked for 16 input channels).
+    profiles/r05zj_narrow_layers.txt"""
+    return Cout >= 24
 
 
 def pack_conv3x3_wino_both(packed_f32, Cin, Cout):

@@ -1160,9 +1160,9 @@ def test_conv3x3_winograd_f4_pixel_shuffle_store(ops):
 
 def test_conv3x3_winograd_f4_is_what_the_engines_run(ops, monkeypatch):
     """conv3x3_c8w takes the F(4x4,3x3) kernel for a layer packed by pack_conv3x3_wino_both when the shape has one (at least
-    16 input and 32 output channels); SCIPNP_WINO_F4=0 at pack or launch time keeps the F(2x2,3x3) kernel; the FFDNet
+    24 output channels); SCIPNP_WINO_F4=0 at pack or launch time keeps the F(2x2,3x3) kernel; the FFDNet
     engine's C entry (scipnp_ffdnet_forward_c8w4) runs the same launches as its Python layer loop"""
-    assert ops.wino_f4_shape(16, 96) and ops.wino_f4_shape(96, 96) and not ops.wino_f4_shape(96, 16)
+    assert ops.wino_f4_shape(16, 96) and ops.wino_f4_shape(96, 96) and ops.wino_f4_shape(96, 24) and not ops.wino_f4_shape(96, 16)
     g = torch.Generator().manual_seed(45)
     x = ops.to_c8(torch.randn(2, 96, 24, 40, generator=g).cuda())
     packed = ops.pack_conv3x3(torch.randn(96, 96, 3, 3, generator=g) * 0.05, torch.randn(96, generator=g), Cin=96, Cout=96, device='cuda')
@@ -1181,9 +1181,10 @@ def test_conv3x3_winograd_f4_is_what_the_engines_run(ops, monkeypatch):
     assert 0 < rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 4e-6
     assert ops.pack_conv3x3_wino_both(packed, 96, 96).f4 is None                 # (not packed while switched off)
     monkeypatch.setenv('SCIPNP_WINO_F4', '1')
-    for cin, cout in ((8, 96), (96, 16), (24, 24)):                              # narrow layers keep F(2x2,3x3)
+    for cin, cout, f4 in ((8, 96, True), (96, 16, False), (24, 24, True), (24, 8, False), (96, 24, True)):
+        # fewer than 24 output channels keep F(2x2,3x3); the input width does not matter (profiles/r05zj_narrow_layers.txt)
         pk = ops.pack_conv3x3(torch.zeros(cout, cin, 3, 3), None, Cin=cin, Cout=cout, device='cuda')
-        assert ops.pack_conv3x3_wino_both(pk, cin, cout).f4 is None
+        assert (ops.pack_conv3x3_wino_both(pk, cin, cout).f4 is not None) == f4
     assert ops.conv3x3_c8w(x, both, 96, shuffle=True).shape == (2, 3, 48, 80, 8)   # (the PixelShuffle store is an epilogue of both kernels)
 
 

@@ -5,7 +5,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-T=r05w
+T=${1:-r05w}
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/${T}_gpu_tests.txt; cat gpurun_out/${T}_gpu_tests.txt
 grep -q passed gpurun_out/${T}_gpu_tests.txt && ! grep -q failed gpurun_out/${T}_gpu_tests.txt || exit 1
 timeout -k 10 900 python bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err || exit 1
@@ -13,10 +13,11 @@ cp gpurun_out/bench_detail_headline_n1.json gpurun_out/${T}_bench_detail.json
 tail -c 1200 gpurun_out/${T}_bench_line.json; echo
 timeout -k 10 600 python bench.py --cubes 8 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_cubes8_line.json 2>> gpurun_out/${T}_bench.err || exit 1
 timeout -k 10 600 python bench.py --config tile1024 --no-cpu-baseline > gpurun_out/${T}_bench_tile1024_line.json 2>> gpurun_out/${T}_bench.err || exit 1
-python - <<'PY'
-import json
+T=$T python - <<'PY'
+import json, os
+T = os.environ['T']
 for f in ('cubes8', 'tile1024'):
-    d = json.loads(open(f'gpurun_out/r05w_bench_{f}_line.json').read().strip().splitlines()[-1])
+    d = json.loads(open(f'gpurun_out/{T}_bench_{f}_line.json').read().strip().splitlines()[-1])
     print(f, d['metric'], d['value'], d['unit'], d['ms_per_step'], d.get('seconds_total'))
 PY
 bash tools/profile_bench.sh $T > gpurun_out/${T}_profile_bench.log 2>&1; grep -v "at::native\|rocclr" gpurun_out/prof_$T/summary.txt | head -16 | cut -c1-200
@@ -28,6 +29,6 @@ cp gpurun_out/prof_$T/traffic.json gpurun_out/${T}_pmc_traffic.json 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${T}_dd/trace -- python3 $GRAFT_REPO_ROOT/tools/ddnet_bench.py > $GRAFT_REPO_ROOT/gpurun_out/${T}_ddnet_f32.log 2>&1 )
 python tools/summarize_prof.py gpurun_out/prof_${T}_fd > gpurun_out/${T}_fastdvd_f32_rocprofv3_summary.txt 2>&1
 python tools/summarize_prof.py gpurun_out/prof_${T}_dd > gpurun_out/${T}_ddnet_f32_rocprofv3_summary.txt 2>&1
-tail -2 gpurun_out/${T}_fastdvd_f32.log gpurun_out/${T}_ddnet_f32.log
+tail -n 2 gpurun_out/${T}_fastdvd_f32.log; tail -n 2 gpurun_out/${T}_ddnet_f32.log
 head -8 gpurun_out/${T}_fastdvd_f32_rocprofv3_summary.txt
 echo done
