@@ -666,6 +666,52 @@ class GrayAdmmRun:
         return frame_metrics(ops.mosaic_to_state(self._cube(self.orig)), ops.mosaic_to_state(self._cube(self.x)))
 
 
+class PartLanes:
+    """Steps the single-unit runs of a split() batch on `lanes` host threads, each with its own HIP stream (round 5).  After the
+    first online-finetune event every unit has its own weights, so its launches can no longer ride in the batch's: one after
+    the other they leave the chip partly idle (a 256x256x16 tile is 768 workgroups of the F(4x4) kernel for 512 slots: the
+    second generation is half empty) and every event stalls the host twice (the loss read-back, the weights' write-back into
+    the module).  Units are independent, so lane j steps parts[j::lanes] behind the caller's stream, and the caller's stream
+    continues behind all lanes; each part keeps its own configuration (AdmmRun(config=)), a network pass inside a lane runs on
+    one stream (the lanes are the concurrency).  Results are those of stepping the parts in order (the `loss:` lines of
+    different units interleave)."""
+
+    def __init__(self, parts, lanes=4):
+        import concurrent.futures as cf
+        self.parts = list(parts)
+        self.n = max(1, min(int(lanes), len(self.parts)))
+        dev = self.parts[0].device if self.parts else None
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.n)] if self.n > 1 else []
+        self.pool = cf.ThreadPoolExecutor(self.n) if self.n > 1 else None
+
+    def _lane(self, j, sigma):
+        dev = self.parts[0].device
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(self.streams[j]), config.use(streams=1):
+            for p in self.parts[j::self.n]:
+                p.step(sigma)
+
+    def step(self, sigma):
+        if self.n <= 1:
+            for p in self.parts:
+                p.step(sigma)
+            return
+        cur = torch.cuda.current_stream(self.parts[0].device)
+        for st in self.streams:
+            st.wait_stream(cur)
+        try:
+            for f in [self.pool.submit(self._lane, j, sigma) for j in range(self.n)]:
+                f.result()
+        finally:                               # also after a failed step: the caller's stream never runs ahead of queued lane work
+            for st in self.streams:
+                cur.wait_stream(st)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+            self.pool = None
+
+
 def _count_finetune_events(update_, two_stage, denoiser, total, inital_iter, interval_iter, update_times, k0=0, done=0):
     """number of FastDVDnet finetune events a schedule of `total` iterations will fire (the gate of _cnn_step, evaluated
     ahead of time)"""

@@ -1150,8 +1150,10 @@ def fixed_total_mode(args, ctx, net, wdesc):
         if st['parts'] is None:
             st['batch'].step(sig)
         else:
-            for part in st['parts']:
-                part.step(sig)
+            if st.get('lanes') is None:                                     # per-unit weights: the parts on host threads / streams
+                from adaptivepnp_sci_amd.solver import PartLanes
+                st['lanes'] = PartLanes(st['parts'], args.lanes)
+            st['lanes'].step(sig)
 
     def finish_all(st):
         ms = [part.result_mosaic() for part in st['parts']] if st['parts'] is not None else st['batch'].result_mosaic()
@@ -1223,6 +1225,7 @@ def fixed_total_mode(args, ctx, net, wdesc):
                                    'one ADMM iteration of the whole cube (all 16 tiles)',
                        'cube': [Hc, Wc, Bc], 'tile': tile, 'parallelism': f'16 tiles over {world} rank(s), one gather, stitched on rank 0'},
             'finetune_events_per_tile': sum(1 for k in range(args.steps) if k > 1 and k % 15 == 0),
+            'lanes_after_split': (args.lanes if batch else 1),    # per-tile weights: the tiles' runs on this many host threads / streams
             'stitched_psnr_db': psnr})
     else:
         line.update({
@@ -1251,6 +1254,8 @@ def main():
                                                          'the ranks (strong scaling); 0 = one cube per rank (weak, the default)')
     ap.add_argument('--no-unit-batch', action='store_true', help='fixed-total modes: step the units of a rank one after the other '
                                                                   '(round 3 behaviour) instead of as one unit batch')
+    ap.add_argument('--lanes', type=int, default=2, help='fixed-total modes after the first finetune event (per-unit weights): host '
+                                                        'threads / HIP streams the per-unit runs are stepped on (solver.PartLanes)')
     ap.add_argument('--config', choices=['headline', 'tile1024'], default='headline',
                     help='tile1024 = BASELINE configs[4]: 1024x1024x16 cube as 16 tiles of 256x256 with the online finetune')
     args = ap.parse_args()

@@ -201,6 +201,44 @@ def test_unit_batch_split_before_the_finetune_event(ffdnet_state_dict):
         assert not torch.equal(a['model.2.weight'], ffdnet_state_dict['model.2.weight'])      # the event did train
 
 
+def test_part_lanes_step_the_split_runs_concurrently_with_identical_results(ffdnet_state_dict):
+    """solver.PartLanes (round 5): after split() the per-unit runs are stepped on host threads with a HIP stream each (the
+    units are independent; the finetune event's loss read-back and weight write-back stall only their own lane) -- every unit
+    bit-identical to stepping the parts one after the other, trained weights included; the caller's stream continues behind
+    all lanes (results read on it right after)"""
+    from adaptivepnp_sci_amd.solver import AdmmRun, PartLanes
+    U = 5
+    pr = problems(U, 64, 64, 8, seed0=77)
+    kw = dict(update_=True, lr_=2e-6, update_per_iter=2, inital_iter=1, interval_iter=2)
+
+    def build():
+        shared = make_ffdnet(ffdnet_state_dict)
+        batch = AdmmRun([p[0] for p in pr], [p[1] for p in pr], 'ffdnet_color', True, X_orig=[p[2] for p in pr], model=shared,
+                        conv_precision='f32', units=U, **kw)
+        for _ in range(2):
+            batch.step(25 / 255)
+        nets = [copy.deepcopy(shared) for _ in range(U)]
+        return batch.split(models=nets), nets
+    seq, nets_seq = build()
+    par, nets_par = build()
+    lanes = PartLanes(par, lanes=3)
+    assert lanes.n == 3
+    for k in range(2, 5):                                      # k = 2 and k = 4 fire the event (two Adam steps each)
+        for p in seq:
+            p.step(25 / 255)
+        lanes.step(25 / 255)
+    lanes.close()
+    for u in range(U):
+        assert torch.equal(par[u].result_mosaic(), seq[u].result_mosaic()), u
+        assert np.array_equal(np.array(par[u].psnr_all()), np.array(seq[u].psnr_all()))
+        a, b = nets_par[u].state_dict(), nets_seq[u].state_dict()
+        assert all(torch.equal(a[k_], b[k_]) for k_ in a)
+        assert not torch.equal(a['model.2.weight'], ffdnet_state_dict['model.2.weight'])
+    one = PartLanes(seq[:1], lanes=4)                          # a single part: no threads, no streams
+    assert one.n == 1 and one.pool is None
+    one.step(25 / 255)
+
+
 def test_unit_batch_argument_errors(ffdnet_state_dict):
     from adaptivepnp_sci_amd.solver import AdmmRun
     from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
