@@ -287,6 +287,21 @@ __device__ __forceinline__ void tv_band_stop_load8(const double* __restrict__ pc
         s2[it] = on ? pc[(size_t)k * 2 * n_iter + 2 * it + 1] : 0.0;
     }
 }
+// ... for exactly 5 TV iterations (4 energy pairs per band), from an address that is valid for EVERY lane (`pc_valid`: the lane's
+// own band where it has one, any band of the workspace otherwise; `lane_on` says which): four unconditional 16-byte loads, no
+// branch -- the predicated form above compiles to a load / wait / select block per iteration (four round trips)
+__device__ __forceinline__ void tv_band_stop_load8_full(const double* __restrict__ pc_valid, bool lane_on,
+                                                        double (&s1)[TV_STOP_MAXIT], double (&s2)[TV_STOP_MAXIT]) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v[TV_STOP_MAXIT];
+#pragma unroll
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) v[it] = *(const d2*)(pc_valid + 2 * it);
+#pragma unroll
+    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
+        s1[it] = lane_on ? v[it].x : 0.0;
+        s2[it] = lane_on ? v[it].y : 0.0;
+    }
+}
 __device__ __forceinline__ int tv_band_stop_finish8(double (&s1)[TV_STOP_MAXIT], double (&s2)[TV_STOP_MAXIT], int n_iter, size_t MN,
                                                     double weight, double eps, double inv_mn = 0.0) {
     // v[l] += v[l + 4], v[l + 2], v[l + 1] by DPP row shifts: the lanes with band 0 (l = 0, 8 of a row of 16) add exactly the terms
@@ -344,7 +359,7 @@ int tv_plane_dual(const float* x, float* b, float coef, float* theta, int M, int
 // block-wide sum of one double per thread (block size a multiple of 64, <= 1024; `tid` is the
 // linear thread id); result valid in thread 0.  Fixed tree + fixed wave order: deterministic.
 __device__ __forceinline__ double block_sum_double(double v, double* lds /* >= 16 doubles */, int tid, int nthreads) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum_f64(v);                  // (DPP row shifts + readlane: 12 ds_bpermute through the LDS pipe before round 5)
     const int wave = tid >> 6, lane = tid & 63;
     if (lane == 0) lds[wave] = v;
     __syncthreads();

@@ -632,47 +632,83 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
 // previous ADMM iteration, the right one after the test where that prediction fails, measured the same 8.7 us: the kernel is
 // as deep as its one round trip, not as wide as its reads -- profiles/r05zf_*.)  Same expressions in the same order as the general
 // kernel: theta, b, x and the squared-error partials are bit-identical to it.
-template <int MODE>
+#if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define DPS_STAMP(slot)                                                                                                 \
+    do {                                                                                                                \
+        if (stamps) {                                                                                                   \
+            unsigned long long t_;                                                                                      \
+            const unsigned long long* p_ = stamps + (slot);                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t_) : "s"(p_) : "memory"); \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+    } while (0)
+#define DPS_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define DPS_STAMP(slot) (void)0
+#define DPS_WAIT_VM() (void)0
+#endif
+// FULL: exactly 8 frames and 5 TV iterations (4 candidates), SSE: squared-error partials wanted -- compile-time, so that the
+// kernel is straight-line code: with run-time `t < B` / `it < n_iter - 1` / `sse_part` tests every frame was its own basic block,
+// its loads stayed inside it, and each block waited for the previous block's stores (stamps: 3700 clocks of arithmetic + stores)
+template <int MODE, bool FULL, bool SSE>
 __global__ void __launch_bounds__(256)
 pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_eps, double inv_mn, float* xio, float* theta, float* bb,
                             const float* __restrict__ Phi, const float* __restrict__ y, const float* __restrict__ Phisum,
                             const float* __restrict__ orig, double* sse_part, int nfill, long long Q, long long MN, int B, float c0,
-                            float c1) {
+                            float c1
+#if defined(SCIPNP_TV_STAMPS)
+                            , unsigned long long* stamp_buf          // (clock stamps of one wave: tools/probes/tv_band_stamps.py)
+#endif
+                            ) {
     constexpr int MAXB = 8;
     __shared__ double red[16];
+#if defined(SCIPNP_TV_STAMPS)
+    unsigned long long* const stamps = (stamp_buf && blockIdx.x == gridDim.x / 2 + 3 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) ? stamp_buf : nullptr;
+#endif
+    DPS_STAMP(0);
     const int P = (int)(Q / MN);                                        // planes per frame
     const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // (host: Q % 256 == 0, MN % 256 == 0)
     const int ib = (int)(((long long)blockIdx.x * 256) / MN);           // the plane of this workgroup's pixels
     const int lane = threadIdx.x & 63, t8 = lane >> 3;
     double s1[TV_STOP_MAXIT], s2[TV_STOP_MAXIT];
-    tv_band_stop_load8(t8 < B ? cd.part + ((size_t)t8 * P + ib) * cd.nbands * 2 * cd.n_iter : nullptr, cd.nbands, cd.n_iter, s1, s2);
+    if (FULL) {                       // (8 frames: every lane has a channel; lanes of a band the channel does not have read band 0)
+        const int k8 = lane & 7;
+        const bool on = k8 < cd.nbands;
+        tv_band_stop_load8_full(cd.part + (((size_t)t8 * P + ib) * cd.nbands + (on ? k8 : 0)) * 2 * 5, on, s1, s2);
+    } else {
+        tv_band_stop_load8(t8 < B ? cd.part + ((size_t)t8 * P + ib) * cd.nbands * 2 * cd.n_iter : nullptr, cd.nbands, cd.n_iter, s1, s2);
+    }
     float xr[MAXB], br[MAXB], ph[MAXB], og[MAXB], cr[TV_STOP_MAXIT][MAXB];
+    // frame by frame, in the order the arithmetic below consumes them: frame t's operands are back (s_waitcnt vmcnt counts down
+    // in issue order) while the later frames' are still in flight
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
-        if (t < B) {
-            const size_t o = (size_t)t * Q + q;
+        const bool on = FULL || t < B;
+        const size_t o = (size_t)t * Q + q;
+        if (on) {
             xr[t] = tv_handoff_load(xio + o);
             br[t] = tv_handoff_load(bb + o);
             ph[t] = Phi[o];
         }
+#pragma unroll
+        for (int it = 0; it < TV_STOP_MAXIT; ++it)
+            cr[it][t] = (FULL || (on && it < cd.n_iter - 1)) ? tv_handoff_load(cd.cand + (size_t)it * ((size_t)B * Q) + o) : 0.f;
+        if (SSE) og[t] = on ? orig[o] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);    // (keeps the issue order frame-major: the scheduler clusters loads by base pointer)
     }
     const float yv = y[q], sv = Phisum[q];
-#pragma unroll
-    for (int it = 0; it < TV_STOP_MAXIT; ++it) {
-#pragma unroll
-        for (int t = 0; t < MAXB; ++t)
-            cr[it][t] = (t < B && it < cd.n_iter - 1) ? tv_handoff_load(cd.cand + (size_t)it * ((size_t)B * Q) + (size_t)t * Q + q) : 0.f;
-    }
-    if (sse_part) {
-#pragma unroll
-        for (int t = 0; t < MAXB; ++t) og[t] = t < B ? orig[(size_t)t * Q + q] : 0.f;
-    }
+    __builtin_amdgcn_sched_barrier(0);        // every load is in flight before the stop test starts
+    DPS_STAMP(1);                 // every load issued
+    DPS_WAIT_VM();
+    DPS_STAMP(2);                 // ... and back
     const int st = tv_band_stop_finish8(s1, s2, cd.n_iter, cd.MN, tv_weight, tv_eps, inv_mn);   // lane 8 t: channel (t, ib)
+    DPS_STAMP(3);                 // stop test
     double acc = 0.0;
     float p[MAXB];
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
-        if (t < B) {
+        if (FULL || t < B) {
             const size_t o = (size_t)t * Q + q;
             const int sel = __builtin_amdgcn_readlane(st, 8 * t);       // channel kept the `out` of iteration sel: candidate sel - 1
             const float raw = sel == 1 ? cr[0][t] : sel == 2 ? cr[1][t] : sel == 3 ? cr[2][t] : cr[3][t];
@@ -682,23 +718,30 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
             p[t] = (MODE == 0) ? (th - c0 * bn) : (th + bn);
             tv_handoff_store(theta + o, th);
             tv_handoff_store(bb + o, bn);
-            if (sse_part) {
+            if (SSE) {
                 const float e = og[t] - (MODE == 0 ? th : xr[t]);
                 acc += (double)(e * e);
             }
         }
     }
-    const float yb = torch_contig_sum<MAXB>(B, [&](int i) { return p[i] * ph[i]; });
+    const float yb = torch_contig_sum<MAXB>(FULL ? MAXB : B, [&](int i) { return p[i] * ph[i]; });
     const float r = (MODE == 0) ? (yv - yb) / (c1 + sv) : (yv - yb) / (sv + c1);
 #pragma unroll
     for (int t = 0; t < MAXB; ++t)
-        if (t < B) tv_handoff_store(xio + (size_t)t * Q + q, (MODE == 0) ? (p[t] + ph[t] * r) : (p[t] + c0 * (r * ph[t])));
-    if (sse_part) {
+        if (FULL || t < B) tv_handoff_store(xio + (size_t)t * Q + q, (MODE == 0) ? (p[t] + ph[t] * r) : (p[t] + c0 * (r * ph[t])));
+    DPS_STAMP(4);                 // arithmetic, stores issued
+    if (SSE) {
         const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
         if (threadIdx.x == 0) tv_handoff_store(sse_part + blockIdx.x, s);
         if (blockIdx.x == 0)
             for (int i = gridDim.x + threadIdx.x; i < nfill; i += blockDim.x) sse_part[i] = 0.0;
     }
+    DPS_STAMP(5);
+    DPS_WAIT_VM();
+    DPS_STAMP(6);                 // stores acknowledged
+#if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (stamps) asm volatile("s_dcache_wb" ::: "memory");
+#endif
 }
 
 // launch shape of pm_dual_project_kernel: pixels per thread, chunks per workgroup (more than one only where one workgroup per
@@ -969,12 +1012,25 @@ int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double 
     static const bool general_only = [] { const char* e = getenv("SCIPNP_DUAL_PROJECT_GENERAL"); return e && e[0] == '1'; }();
     if (use_cd && !general_only && VECs == 1 && CH == 1 && B <= 8 && cd.nbands <= 8 && MN % 256 == 0 && Q % 256 == 0) {
         const double inv_mn = (MN & (MN - 1)) == 0 ? 1.0 / (double)MN : 0.0;
-        if (mode == 0)
-            hipLaunchKernelGGL((pm_dual_project_spec_kernel<0>), dim3(grid), dim3(threads), 0, st, cd, tv_weight, tv_eps, inv_mn, x,
-                               theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1);
-        else
-            hipLaunchKernelGGL((pm_dual_project_spec_kernel<1>), dim3(grid), dim3(threads), 0, st, cd, tv_weight, tv_eps, inv_mn, x,
-                               theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1);
+#if defined(SCIPNP_TV_STAMPS)
+        static unsigned long long* const stamp_buf = [] { const char* e = getenv("SCIPNP_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr; }();
+#define SCIPNP_DPS_EXTRA , stamp_buf
+#else
+#define SCIPNP_DPS_EXTRA
+#endif
+        const bool full = B == 8 && cd.n_iter == 5, sse = sse_part != nullptr;
+#define SCIPNP_DPS(MODE, FULL, SSE)                                                                                        \
+        hipLaunchKernelGGL((pm_dual_project_spec_kernel<MODE, FULL, SSE>), dim3(grid), dim3(threads), 0, st, cd, tv_weight, tv_eps,  \
+                           inv_mn, x, theta, b, Phi, y, Phisum, orig, sse_part, nfill, Q, MN, B, c0, c1 SCIPNP_DPS_EXTRA)
+        if (mode == 0) {
+            if (full) { if (sse) SCIPNP_DPS(0, true, true); else SCIPNP_DPS(0, true, false); }
+            else { if (sse) SCIPNP_DPS(0, false, true); else SCIPNP_DPS(0, false, false); }
+        } else {
+            if (full) { if (sse) SCIPNP_DPS(1, true, true); else SCIPNP_DPS(1, true, false); }
+            else { if (sse) SCIPNP_DPS(1, false, true); else SCIPNP_DPS(1, false, false); }
+        }
+#undef SCIPNP_DPS
+#undef SCIPNP_DPS_EXTRA
         return launch_status("pm_dual_project_spec_kernel");
     }
 #define SCIPNP_DP(VEC, MAXB)                                                                                     \
