@@ -632,6 +632,13 @@ pm_dual_project_kernel(const float* __restrict__ theta_raw, const TvCandidates c
 // previous ADMM iteration, the right one after the test where that prediction fails, measured the same 8.7 us: the kernel is
 // as deep as its one round trip, not as wide as its reads -- profiles/r05zf_*.)  Same expressions in the same order as the general
 // kernel: theta, b, x and the squared-error partials are bit-identical to it.
+// (mask & a) | (~mask & b) with a wave-uniform mask, one v_bfi_b32
+__device__ __forceinline__ unsigned bit_select(unsigned mask, float a, unsigned b) {
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 #if defined(SCIPNP_TV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define DPS_STAMP(slot)                                                                                                 \
     do {                                                                                                                \
@@ -711,7 +718,14 @@ pm_dual_project_spec_kernel(const TvCandidates cd, double tv_weight, double tv_e
         if (FULL || t < B) {
             const size_t o = (size_t)t * Q + q;
             const int sel = __builtin_amdgcn_readlane(st, 8 * t);       // channel kept the `out` of iteration sel: candidate sel - 1
-            const float raw = sel == 1 ? cr[0][t] : sel == 2 ? cr[1][t] : sel == 3 ? cr[2][t] : cr[3][t];
+            // (v_bfi_b32 with the wave-uniform `sel` as a scalar mask: as a ?: chain the compiler builds a maze of scalar branches
+            // around the waits for the candidates it can skip -- 270 clocks per frame; as and / or it picks v_cndmask on VCC, which
+            // issues in 19.5 clocks on this part against 5.5: profiles/r05zh_valu_issue_cost.txt)
+            unsigned rb = __builtin_bit_cast(unsigned, cr[3][t]);
+            rb = bit_select(sel == 3 ? ~0u : 0u, cr[2][t], rb);
+            rb = bit_select(sel == 2 ? ~0u : 0u, cr[1][t], rb);
+            rb = bit_select(sel == 1 ? ~0u : 0u, cr[0][t], rb);
+            const float raw = __builtin_bit_cast(float, rb);
             const float th = fminf(fmaxf(raw, 0.f), 1.f);
             const float d = xr[t] - th;
             const float bn = (MODE == 0) ? (br[t] + d) : (br[t] - d);
