@@ -1270,8 +1270,9 @@ def main():
                                                          'the ranks (strong scaling); 0 = one cube per rank (weak, the default)')
     ap.add_argument('--no-unit-batch', action='store_true', help='fixed-total modes: step the units of a rank one after the other '
                                                                   '(round 3 behaviour) instead of as one unit batch')
-    ap.add_argument('--lanes', type=int, default=2, help='fixed-total modes after the first finetune event (per-unit weights): host '
-                                                        'threads / HIP streams the per-unit runs are stepped on (solver.PartLanes)')
+    ap.add_argument('--lanes', type=int, default=1, help='fixed-total modes after the first finetune event (per-unit weights): host '
+                                                        'threads / HIP streams the per-unit runs are stepped on (solver.PartLanes; 2 lanes '
+                                                        'measured 0.693 against 0.710 s on one box and 0.776 against 0.715 s on another: off by default)')
     ap.add_argument('--config', choices=['headline', 'tile1024'], default='headline',
                     help='tile1024 = BASELINE configs[4]: 1024x1024x16 cube as 16 tiles of 256x256 with the online finetune')
     args = ap.parse_args()
