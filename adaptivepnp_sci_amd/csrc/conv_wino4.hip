@@ -740,10 +740,9 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
 }
 
 // U = G g G^T from the fp32 direct packing [cig][tap][CoutP][8]; one thread per slab element
-__global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restrict__ out, int CGin, int CoutP) {
+__device__ __forceinline__ void pack_wino4_body(const float* __restrict__ pk, float* __restrict__ out, int CGin, int CoutP, size_t i) {
     const size_t NCB = CoutP / 32;
     const size_t total = (size_t)2 * CGin * NCB * W4_SLAB;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
         // slab element index: [xh 2][v 9][lane 64 = q*16 + tn][e 4] -> U_p[co = 32 cb + 16 (e >> 1) + tn][ci = 2 q + j],
         // p = (xi = 3 xh + own row, nu = 2 np + (e & 1)), (own row, np) = (v / 3, v % 3) for j = 0 and (v % 3, v / 3) for j = 1;
@@ -767,6 +766,20 @@ __global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restric
     }
     if (i < (size_t)CoutP) out[total + i] = pk[(size_t)CGin * 9 * CoutP * 8 + i];       // bias
 }
+__global__ void pack_wino4_kernel(const float* __restrict__ pk, float* __restrict__ out, int CGin, int CoutP) {
+    pack_wino4_body(pk, out, CGin, CoutP, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// ... of MANY layers in one launch (blockIdx.y = the job): see pack_device_multi_kernel (finetune.hip)
+constexpr int PACK4_MULTI_MAX = 32;
+struct PackWino4Jobs {
+    const float* pk[PACK4_MULTI_MAX];
+    float* out[PACK4_MULTI_MAX];
+    int cgin[PACK4_MULTI_MAX], coutp[PACK4_MULTI_MAX];
+};
+__global__ void pack_wino4_multi_kernel(const PackWino4Jobs j) {
+    const int q = blockIdx.y;
+    pack_wino4_body(j.pk[q], j.out[q], j.cgin[q], j.coutp[q], (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 static inline int round_up_w4(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -782,6 +795,27 @@ size_t scipnp_conv3x3_wino4_packed_floats(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return 0;
     const int CoutP = round_up_w4(Cout, 32);
     return (size_t)2 * (Cin / 8) * (CoutP / 32) * W4_SLAB + CoutP;
+}
+
+int scipnp_pack_conv3x3_wino4_multi(int n, const float* const* packed_f32, float* const* packed_wino4, const int* Cin,
+                                    const int* Cout, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(n >= 0 && (n == 0 || (packed_f32 && packed_wino4 && Cin && Cout)), "bad arguments");
+    for (int base = 0; base < n; base += PACK4_MULTI_MAX) {
+        const int m = n - base < PACK4_MULTI_MAX ? n - base : PACK4_MULTI_MAX;
+        PackWino4Jobs j = {};
+        size_t most = 0;
+        for (int q = 0; q < m; ++q) {
+            const int g = base + q;
+            SCIPNP_REQUIRE(packed_f32[g] && packed_wino4[g] && Cin[g] > 0 && Cout[g] > 0 && Cin[g] % 8 == 0 && Cout[g] % 8 == 0,
+                           "bad arguments in job %d", g);
+            j.pk[q] = packed_f32[g]; j.out[q] = packed_wino4[g];
+            j.cgin[q] = Cin[g] / 8; j.coutp[q] = round_up_w4(Cout[g], 32);
+            const size_t total = (size_t)2 * j.cgin[q] * (j.coutp[q] / 32) * W4_SLAB;
+            most = total > most ? total : most;
+        }
+        hipLaunchKernelGGL(pack_wino4_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)s, j);
+    }
+    return launch_status("pack_wino4_multi_kernel");
 }
 
 int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int Cin, int Cout, scipnp_stream_t s) {

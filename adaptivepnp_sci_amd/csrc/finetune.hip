@@ -226,12 +226,11 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 // forward : packed[cig][tap][coP][8] = W[co][ci][tap]                       (+ bias[coP] appended)
 // backward: the conv that maps dZ (Cout ch) to dA (Cin ch):  W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
 //           -> packed'[cog][tap][ciP][8], no bias
-__global__ void __launch_bounds__(256)
-pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
-                   float* __restrict__ packed, int Cin_real, int Cout_real, int Kin /*padded in-ch of the packed conv*/,
-                   int KoutP, int transpose) {
+__device__ __forceinline__ void pack_device_body(const float* __restrict__ w, const float* __restrict__ bias,
+                                                 const float* __restrict__ scale, float* __restrict__ packed, int Cin_real,
+                                                 int Cout_real, int Kin /*padded in-ch of the packed conv*/, int KoutP, int transpose,
+                                                 size_t i) {
     const size_t nw = (size_t)(Kin / 8) * 9 * KoutP * 8;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + KoutP) return;
     if (i >= nw) {
         const int o = (int)(i - nw);
@@ -257,6 +256,28 @@ pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, 
         }
     }
     packed[i] = val;
+}
+
+__global__ void __launch_bounds__(256)
+pack_device_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                   float* __restrict__ packed, int Cin_real, int Cout_real, int Kin, int KoutP, int transpose) {
+    pack_device_body(w, bias, scale, packed, Cin_real, Cout_real, Kin, KoutP, transpose, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// the packs of MANY layers in one launch (round 5: a trainer repacks every layer in both directions after each Adam step -- 46
+// launches of 4 us for FFDNet, each a dependent launch of its own; blockIdx.y = the job)
+constexpr int PACK_MULTI_MAX = 32;
+struct PackDeviceJobs {
+    const float* w[PACK_MULTI_MAX];
+    const float* bias[PACK_MULTI_MAX];
+    const float* scale[PACK_MULTI_MAX];
+    float* packed[PACK_MULTI_MAX];
+    int cin_real[PACK_MULTI_MAX], cout_real[PACK_MULTI_MAX], kin[PACK_MULTI_MAX], koutp[PACK_MULTI_MAX], transpose[PACK_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256) pack_device_multi_kernel(const PackDeviceJobs j) {
+    const int q = blockIdx.y;
+    pack_device_body(j.w[q], j.bias[q], j.scale[q], j.packed[q], j.cin_real[q], j.cout_real[q], j.kin[q], j.koutp[q], j.transpose[q],
+                     (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
@@ -296,6 +317,30 @@ static inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 using namespace scipnp;
 
 extern "C" {
+
+int scipnp_pack_conv3x3_device_multi(int n, const float* const* w, const float* const* bias, const float* const* scale,
+                                     float* const* packed, const int* Cin_real, const int* Cout_real, const int* Cin, const int* Cout,
+                                     const int* transpose_flip, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(n >= 0 && (n == 0 || (w && packed && Cin_real && Cout_real && Cin && Cout && transpose_flip)), "bad arguments");
+    for (int base = 0; base < n; base += PACK_MULTI_MAX) {
+        const int m = n - base < PACK_MULTI_MAX ? n - base : PACK_MULTI_MAX;
+        PackDeviceJobs j = {};
+        size_t most = 0;
+        for (int q = 0; q < m; ++q) {
+            const int g = base + q;
+            SCIPNP_REQUIRE(w[g] && packed[g] && Cin[g] % 8 == 0 && Cout[g] % 8 == 0 && Cin_real[g] <= Cin[g] && Cout_real[g] <= Cout[g],
+                           "bad arguments in job %d", g);
+            j.w[q] = w[g]; j.bias[q] = bias ? bias[g] : nullptr; j.scale[q] = scale ? scale[g] : nullptr; j.packed[q] = packed[g];
+            j.cin_real[q] = Cin_real[g]; j.cout_real[q] = Cout_real[g]; j.transpose[q] = transpose_flip[g];
+            j.kin[q] = transpose_flip[g] ? Cout[g] : Cin[g];
+            j.koutp[q] = round_up_i(transpose_flip[g] ? Cin[g] : Cout[g], 32);
+            const size_t total = (size_t)(j.kin[q] / 8) * 9 * j.koutp[q] * 8 + j.koutp[q];
+            most = total > most ? total : most;
+        }
+        hipLaunchKernelGGL(pack_device_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)s, j);
+    }
+    return launch_status("pack_device_multi_kernel");
+}
 
 int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
                                       int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,

@@ -13,6 +13,7 @@ module's parameters are updated in place and the engine continues on the device-
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -145,6 +146,9 @@ GRAD_HOOK = None
 TAP = None
 
 
+_WB_TLS = threading.local()          # per host thread: {(device, floats): (pinned buffer, side stream)} of deferred write-backs
+
+
 class _FFDNetTrainer:
     """Device master copies of the parameters, packed forward/backward weights, Adam state and the
     activation stash of one FFDNetEngine geometry."""
@@ -155,14 +159,19 @@ class _FFDNetTrainer:
         self.eng = eng
         dev = eng.device
         self.split = eng.precision == 'f16x3'
+        self.model = model
         self.layers = ffdnet_layers(model)                # [(weight, bias)] tensors of the module (any device)
         srcs = [w.detach() for w, _ in self.layers] + [b.detach() for _, b in self.layers]
         total = sum(t.numel() for t in srcs)
+        self._synced = None                               # (data_ptr, _version) of every parameter when device == module
+        self._host = None                                 # pinned staging buffer of the deferred write-back
+        self._wb = None                                   # (stream, event) of a write-back in flight
         # master parameters, gradients and Adam moments live in four flat buffers: one Adam launch per step
         self.flat_p, self.flat_g = torch.empty(total, dtype=F32, device=dev), torch.empty(total, dtype=F32, device=dev)
         self.flat_m, self.flat_v = torch.zeros(total, dtype=F32, device=dev), torch.zeros(total, dtype=F32, device=dev)
         views = _carve(self.flat_p, srcs)
         _upload_flat(self.flat_p, srcs)
+        self._synced = self._mark()                       # (self.layers is set: the module and the device master agree)
         nl = len(self.layers)
         self.w, self.b = views[:nl], views[nl:]
         self.nb, self.nc = eng.nb, eng.nc
@@ -241,17 +250,25 @@ class _FFDNetTrainer:
                     _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), _ptr(self.b[l]), _ptr(self.fwd[l]), ci_r,
                                                                    co_r, self.cin[l], self.cout[l], 0, _s()), 'pack fwd')
             return
+        # every layer's packs in two launches (scipnp_pack_conv3x3_device_multi, scipnp_pack_conv3x3_wino4_multi; round 5: the 46
+        # launches of 4 us each per pack() -- three packs per event -- were 1.2 ms of kernels and 1.7 ms of gaps in a 25 ms event)
+        dev_jobs = []                                         # (w, bias, packed, ci_r, co_r, cin, cout, transpose)
+        w4_jobs, rest = [], []                                # (packed_f32, f4, cin, cout) / layers that keep an F(2x2) packing
         for l in range(self.nb):
             ci_r, co_r = self._real(l)
-            _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), _ptr(self.b[l]), _ptr(self.fwd[l]), ci_r, co_r,
-                                                           self.cin[l], self.cout[l], 0, _s()), 'pack fwd')
+            dev_jobs.append((self.w[l], self.b[l], self.fwd[l], ci_r, co_r, self.cin[l], self.cout[l], 0))
             if l > 0:
-                _lib.check(self.lib.scipnp_pack_conv3x3_device(_ptr(self.w[l]), None, _ptr(self.bwd[l]), ci_r, co_r,
-                                                               self.cin[l], self.cout[l], 1, _s()), 'pack bwd')
+                dev_jobs.append((self.w[l], None, self.bwd[l], ci_r, co_r, self.cin[l], self.cout[l], 1))
             if self.wino:
-                _repack_wino(self.fwd[l], self.fwd_w[l])
-                if l > 0 and not final:
-                    _repack_wino(self.bwd[l], self.bwd_w[l])
+                for pk, wp in ((self.fwd[l], self.fwd_w[l]),) + (((self.bwd[l], self.bwd_w[l]),) if (l > 0 and not final) else ()):
+                    if wp.f4 is not None and wp.w is None:
+                        w4_jobs.append((pk, wp.f4, wp.cin, wp.cout))
+                    else:
+                        rest.append((pk, wp))
+        ops.pack_conv3x3_device_multi(dev_jobs)
+        ops.pack_conv3x3_wino4_multi(w4_jobs)
+        for pk, wp in rest:
+            _repack_wino(pk, wp)
 
     def forward_keep(self):
         eng = self.eng
@@ -335,12 +352,77 @@ class _FFDNetTrainer:
                                              self.flat_p.numel(), float(lr), 0.9, 0.999, 1e-8, self.step, _s()),
                    'scipnp_adam_step')
 
-    def write_back(self):
-        """the reference mutates `model` in place and returns it (test_ffdnet_ipol.py:356-357)"""
-        _download_flat(self.flat_p, [w for w, _ in self.layers] + [b for _, b in self.layers])
+    def _params(self):
+        return [w for w, _ in self.layers] + [b for _, b in self.layers]
+
+    def _mark(self):
+        return [(t.data_ptr(), t._version) for t in self._params()]
+
+    def reuse(self, model):
+        """the trainer of an earlier event of the same engine for the next one (round 5: building it -- 40 allocations, the
+        parameter upload, two Adam-state fills -- kept the GPU idle for 0.7 ms per event): same module and parameter tensors ->
+        fresh Adam state (the reference builds a new optimiser per event, test_ffdnet_ipol.py:286-288), and the parameters are
+        uploaded again unless the module still holds exactly what this trainer wrote back (tensor identity and version
+        counters).  False: build a new trainer."""
+        self.finish_write_back()
+        if model is not self.model:
+            return False
+        cur = ffdnet_layers(model)                        # (state_dict views: new tensor objects over the parameters' storage)
+        if len(cur) != len(self.layers) or any(a.data_ptr() != c.data_ptr() or b.data_ptr() != d.data_ptr() or a.shape != c.shape
+                                               for (a, b), (c, d) in zip(cur, self.layers)):
+            return False
+        if self._synced is None or self._synced != self._mark():
+            _upload_flat(self.flat_p, [t.detach() for t in self._params()])
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        self.step = 0
+        return True
+
+    def write_back(self, defer=False):
+        """the reference mutates `model` in place and returns it (test_ffdnet_ipol.py:356-357).  defer: the device -> host copy
+        goes to a pinned buffer on a side stream behind the last Adam step; finish_write_back() -- called by the solver once the
+        evaluation pass is enqueued, and by anything else that touches the trainer -- waits for it and fills the module's
+        tensors, so the host's 0.35 ms are spent while the GPU runs the denoiser"""
+        dsts = self._params()
+        if not defer or any(t.is_cuda for t in dsts):
+            _download_flat(self.flat_p, dsts)
+            self._synced = self._mark()
+            return
+        if self._host is None:                  # pinned staging + side stream: one per host thread, shared by its trainers
+            key = (self.flat_p.device.index, self.flat_p.numel())
+            pool = getattr(_WB_TLS, 'pool', None)
+            if pool is None:
+                pool = _WB_TLS.pool = {}
+            if key not in pool:
+                pool[key] = (torch.empty(self.flat_p.numel(), dtype=F32, pin_memory=True), torch.cuda.Stream(self.flat_p.device))
+            self._host, self._wb_stream = pool[key]
+        cur = torch.cuda.current_stream(self.flat_p.device)
+        self._wb_stream.wait_stream(cur)
+        with torch.cuda.stream(self._wb_stream):
+            self._host.copy_(self.flat_p, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._wb_stream)
+        self._wb = ev
+
+    def finish_write_back(self):
+        if self._wb is None:
+            return
+        self._wb.synchronize()
+        self._wb = None
+        host = self._host.numpy()
+        off = 0
+        with torch.no_grad():
+            for t in self._params():                  # NumPy copies: see ops.host_flat on why not Tensor.copy_
+                n = t.numel()
+                if t.dtype == torch.float32 and t.is_contiguous():
+                    np.copyto(t.detach().numpy().reshape(-1), host[off:off + n])
+                else:
+                    t.copy_(torch.from_numpy(host[off:off + n]).view(t.shape))
+                off += n
+        self._synced = self._mark()
 
 
-def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None):
+def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter, logf=None, trace=None, defer_write_back=False):
     """`update_per_iter` Adam steps on the measurement loss for the input currently held in eng.in_c8
     (written by scipnp_pm_pre_denoise); y_pm [4][M][N], Phi_pm [B][4][M][N] plane-major.  Leaves the
     engine's packed weights refreshed and the module's parameters updated; the caller then runs the
@@ -348,7 +430,9 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
     _lib.require_gpu()
     if update_per_iter <= 0:                 # no Adam step: nothing changes (the trainer's fp32 forward packs are only
         return model                         # filled by the last step's pack(final=True); never adopt them unfilled)
-    tr = _FFDNetTrainer(model, eng)
+    tr = getattr(eng, '_ft_trainer', None)                # (defer_write_back: the caller calls the returned trainer's
+    if tr is None or not tr.reuse(model):                 # finish_write_back() once its evaluation pass is enqueued)
+        tr = eng._ft_trainer = _FFDNetTrainer(model, eng)
     tr.pack()
     for it in range(update_per_iter):
         tr.forward_keep()
@@ -363,9 +447,10 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
         print('loss:', val)                                   # the reference prints the loss tensor (:298-299)
         if trace is not None:
             trace.append(val)
-    tr.write_back()
-    eng.adopt(tr.fwd, tr.fwd_s if tr.split else None)     # the engine continues on the device-packed updated weights
-    return model
+    tr.write_back(defer=defer_write_back)
+    eng.adopt(tr.fwd, tr.fwd_s if tr.split else None,     # the engine continues on the device-packed updated weights
+              packed_wino=tr.fwd_w if tr.wino else None)
+    return tr if defer_write_back else model
 
 
 # ============================================================================================ FastDVDnet

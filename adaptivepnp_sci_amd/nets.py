@@ -129,14 +129,19 @@ class FFDNetEngine:
                 cout = self.cout_last if i == self.nb - 1 else self.nc
                 self.packed_wino.append(ops.pack_conv3x3_wino_both(self.packed[i], cin, cout))
 
-    def adopt(self, packed_f32, packed_split=None):
+    def adopt(self, packed_f32, packed_split=None, packed_wino=None):
         """Take over device-packed weights (the online finetune packs its updated master weights on the GPU,
-        scipnp_pack_conv3x3_device / _split_device) instead of re-packing on the host."""
+        scipnp_pack_conv3x3_device / _split_device) instead of re-packing on the host.  packed_wino: the trainer's Winograd-domain
+        packings of the same weights (ops.WinoPacked per layer; a layer latched onto the F(4x4) kernel carries only that form) --
+        taken over as they are instead of 23 more pack launches per event."""
         self.packed = list(packed_f32)
         self._ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed])
         if self.precision == 'f16x3':
             self.packed_split = list(packed_split)
-        self._pack_wino()
+        if packed_wino is not None and self.f32_form == 'winograd':
+            self.packed_wino = list(packed_wino)
+        else:
+            self._pack_wino()
 
     def forward(self, in_c8=None, out_c8=None, events=None):
         """12 conv launches on the current stream (same sequence as the C entry scipnp_ffdnet_forward).
@@ -211,7 +216,7 @@ class FFDNetEngine:
         lib = _lib.load()
         _lib.require_gpu()
         if self.packed_wino is not None:                  # the engine's own form: Winograd layers, one C call
-            ptrs = (C.c_void_p * self.nb)(*[p.data_ptr() for p in self.packed_wino])
+            ptrs = (C.c_void_p * self.nb)(*[(p.w.data_ptr() if p.w is not None else None) for p in self.packed_wino])   # (None: F(4x4) only)
             p4 = (C.c_void_p * self.nb)(*[(p.f4.data_ptr() if (p.f4 is not None and ops.wino_f4_enabled()) else None)
                                          for p in self.packed_wino])
             rc = lib.scipnp_ffdnet_forward_c8w4(C.c_void_p(in_c8.data_ptr()), C.c_void_p(out_c8.data_ptr()), ptrs, p4, self.nb,

@@ -373,6 +373,30 @@ def pack_conv3x3_wino4(packed_f32, Cin, Cout, out=None):
     return out
 
 
+def pack_conv3x3_device_multi(jobs, scales=None):
+    """device-side packs of many layers in ONE launch: jobs = [(w, bias or None, packed, Cin_real, Cout_real, Cin, Cout,
+    transpose_flip)], scales = per-job folded BatchNorm scale tensors (or None)"""
+    n = len(jobs)
+    if n == 0:
+        return
+    P, I = C.c_void_p * n, C.c_int * n
+    ptr = lambda t: None if t is None else t.data_ptr()
+    _call('scipnp_pack_conv3x3_device_multi', n, P(*[ptr(j[0]) for j in jobs]), P(*[ptr(j[1]) for j in jobs]),
+          (P(*[ptr(t) for t in scales]) if scales is not None else None), P(*[ptr(j[2]) for j in jobs]),
+          I(*[j[3] for j in jobs]), I(*[j[4] for j in jobs]), I(*[j[5] for j in jobs]), I(*[j[6] for j in jobs]),
+          I(*[int(j[7]) for j in jobs]), _stream())
+
+
+def pack_conv3x3_wino4_multi(jobs):
+    """F(4x4,3x3) packs of many layers in ONE launch: jobs = [(packed_f32, packed_wino4, Cin, Cout)]"""
+    n = len(jobs)
+    if n == 0:
+        return
+    P, I = C.c_void_p * n, C.c_int * n
+    _call('scipnp_pack_conv3x3_wino4_multi', n, P(*[j[0].data_ptr() for j in jobs]), P(*[j[1].data_ptr() for j in jobs]),
+          I(*[j[2] for j in jobs]), I(*[j[3] for j in jobs]), _stream())
+
+
 def conv3x3_c8w4(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False, shuffle=False):
     """stride-1 3x3 conv on c8 activations in fp32 Winograd F(4x4,3x3) arithmetic (csrc/conv_wino4.hip): 2.25 multiply-adds per
     output on the matrix cores instead of 4 (conv3x3_c8w) or 9 (conv3x3_c8).

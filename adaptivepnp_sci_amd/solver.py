@@ -240,6 +240,11 @@ class AdmmRun:
             with ops.overflow_scope(self.ovf_word):
                 if denoiser == 'ffdnet_color':
                     self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
+                    if getattr(self, 'update_', False) and getattr(self, 'U', 1) == 1 and getattr(self, 'update_per_iter', 0) > 0:
+                        # the online finetune's trainer (device master weights, activation stash, workspaces) is built with the
+                        # engine, like every other buffer of the solve; an event reuses it (finetune._FFDNetTrainer.reuse)
+                        from .finetune import _FFDNetTrainer
+                        self.eng._ft_trainer = _FFDNetTrainer(model, self.eng)
                 else:
                     from .fastdvd import FastDVDEngine
                     self.eng = FastDVDEngine(model, B, H, W, self.device, precision=conv_precision, units=U)
@@ -330,12 +335,15 @@ class AdmmRun:
                 ops.pm_pre_rgb(w, self.x_rgb, None, c8, inv_tau, nsig, net_in_c8s=c8s)
             else:
                 ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s)
+            pending = None
             if gate:
                 from .finetune import ffdnet_online_finetune
-                ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,
-                                       logf=self.logf)
+                pending = ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,
+                                                 logf=self.logf, defer_write_back=True)
             self.eng.forward(events=self.profile_events)
-            src_rgb, src_c8 = None, self.eng.out_c8
+            if pending is not None and hasattr(pending, 'finish_write_back'):
+                pending.finish_write_back()             # (the module holds the updated weights when step() returns, as before;
+            src_rgb, src_c8 = None, self.eng.out_c8     # the copy ran beside the evaluation pass)
         else:
             net_in = self.rgb_w if self.two_stage else self.x_rgb
             if closed:

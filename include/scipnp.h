@@ -343,6 +343,12 @@ int scipnp_pack_conv3x3_device(const float* w, const float* bias, float* packed,
 int scipnp_pack_conv3x3_device_scaled(const float* w, const float* bias, const float* scale, float* packed,
                                       int Cin_real, int Cout_real, int Cin, int Cout, int transpose_flip,
                                       scipnp_stream_t s);
+/* the same packs for n layers in ONE launch (host arrays of n entries; bias / scale may be NULL or hold NULL entries): a trainer
+ * repacks every layer in both directions after each optimiser step, and a launch of its own per pack is a dependent launch of
+ * ~4 us each (the reference re-reads the module's parameters every forward: test_ffdnet_ipol.py:289-300) */
+int scipnp_pack_conv3x3_device_multi(int n, const float* const* w, const float* const* bias, const float* const* scale,
+                                     float* const* packed, const int* Cin_real, const int* Cout_real, const int* Cin,
+                                     const int* Cout, const int* transpose_flip, scipnp_stream_t s);
 /* ---------------------------------------------------------------- fp32 Winograd F(2x2,3x3) form of the same convolution
  * (stride 1, zero padding 1; csrc/conv_wino.hip): Y = A^T[(G g G^T) (.) (B^T d B)]A with every product an exact fp32
  * product accumulated in fp32 on v_mfma_f32_16x16x4_f32 -- 2.25x fewer multiply-adds than scipnp_conv3x3_c8, results
@@ -378,6 +384,9 @@ int scipnp_conv3x3_c8w(const float* in, const float* packed_wino, float* out, co
  * -- same nn.Conv2d(..., 3, 1, 1) call sites as scipnp_conv3x3_c8w. */
 size_t scipnp_conv3x3_wino4_packed_floats(int Cin, int Cout);
 int scipnp_pack_conv3x3_wino4(const float* packed_f32, float* packed_wino4, int Cin, int Cout, scipnp_stream_t s);
+/* ... for n layers in ONE launch (host arrays of n entries) */
+int scipnp_pack_conv3x3_wino4_multi(int n, const float* const* packed_f32, float* const* packed_wino4, const int* Cin,
+                                    const int* Cout, scipnp_stream_t s);
 int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, const float* residual,
                         const float* mask_src, int n, int Cin, int Cout, int h, int w, int flags, scipnp_stream_t s);
 
