@@ -63,6 +63,8 @@ SIGNATURES = {
     'scipnp_conv_bias_grad': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'scipnp_adam_step': (_int, [_vp, _vp, _vp, _vp, _sz, C.c_double, C.c_double, C.c_double, C.c_double, _int, _vp]),
     'scipnp_pack_conv3x3_device': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'scipnp_conv3x3_wgrad_wino4_finish_multi': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'scipnp_conv_bias_grad_reduce_multi': (_int, [_int, _vp, _vp, _vp, _vp]),
     'scipnp_pack_conv3x3_device_multi': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'scipnp_pack_conv3x3_wino4_multi': (_int, [_int, _vp, _vp, _vp, _vp, _vp]),
     'scipnp_conv3x3_c8_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),

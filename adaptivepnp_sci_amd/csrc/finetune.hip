@@ -198,12 +198,25 @@ bgrad_partial_kernel(const float* __restrict__ dz, float* __restrict__ part, int
     }
 }
 
-__global__ void bgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout_real, int nchunk) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bgrad_reduce_body(const float* __restrict__ part, float* __restrict__ db, int Cout_real, int nchunk, int co) {
     if (co >= Cout_real) return;
     float s = 0.f;
     for (int k = 0; k < nchunk; ++k) s += part[((size_t)(co >> 3) * nchunk + k) * 8 + (co & 7)];
     db[co] = s;
+}
+__global__ void bgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout_real, int nchunk) {
+    bgrad_reduce_body(part, db, Cout_real, nchunk, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// ... of MANY layers in one launch (blockIdx.y = the layer)
+constexpr int BGRAD_MULTI_MAX = 32;
+struct BgradJobs {
+    const float* part[BGRAD_MULTI_MAX];
+    float* db[BGRAD_MULTI_MAX];
+    int cout_real[BGRAD_MULTI_MAX];
+};
+__global__ void bgrad_reduce_multi_kernel(const BgradJobs j, int nchunk) {
+    const int q = blockIdx.y;
+    bgrad_reduce_body(j.part[q], j.db[q], j.cout_real[q], nchunk, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------- Adam
@@ -400,14 +413,30 @@ int scipnp_conv3x3_wgrad(const float* act_c8, const float* dz_c8, float* dW, flo
 
 int scipnp_conv_bias_grad(const float* dz_c8, float* db, float* workspace, int n, int Cout_real, int Cout, int h, int w,
                           scipnp_stream_t s) {
-    SCIPNP_REQUIRE(dz_c8 && db && workspace && n > 0 && Cout % 8 == 0 && Cout_real <= Cout, "bad arguments");
-    SCIPNP_ALIGNED(dz_c8);
+    SCIPNP_REQUIRE(dz_c8 && workspace && n > 0 && Cout % 8 == 0 && Cout_real <= Cout, "bad arguments");   // (db == NULL: the partial
+    SCIPNP_ALIGNED(dz_c8);                                                                              // sums only, see ..._reduce_multi)
     const int nchunk = 64;   // workspace: (Cout/8) * 64 * 8 floats
     hipStream_t st = (hipStream_t)s;
     hipLaunchKernelGGL(bgrad_partial_kernel, dim3(nchunk, Cout / 8), dim3(256), 0, st, dz_c8, workspace, n, Cout / 8,
                        (size_t)h * w, nchunk);
-    hipLaunchKernelGGL(bgrad_reduce_kernel, dim3((Cout_real + 63) / 64), dim3(64), 0, st, workspace, db, Cout_real, nchunk);
+    if (db) hipLaunchKernelGGL(bgrad_reduce_kernel, dim3((Cout_real + 63) / 64), dim3(64), 0, st, workspace, db, Cout_real, nchunk);
     return launch_status("bgrad kernels");
+}
+
+int scipnp_conv_bias_grad_reduce_multi(int n, const float* const* workspace, float* const* db, const int* Cout_real, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(n >= 0 && (n == 0 || (workspace && db && Cout_real)), "bad arguments");
+    for (int base = 0; base < n; base += BGRAD_MULTI_MAX) {
+        const int m = n - base < BGRAD_MULTI_MAX ? n - base : BGRAD_MULTI_MAX;
+        BgradJobs j = {};
+        int most = 0;
+        for (int q = 0; q < m; ++q) {
+            SCIPNP_REQUIRE(workspace[base + q] && db[base + q] && Cout_real[base + q] > 0, "bad arguments in job %d", base + q);
+            j.part[q] = workspace[base + q]; j.db[q] = db[base + q]; j.cout_real[q] = Cout_real[base + q];
+            most = Cout_real[base + q] > most ? Cout_real[base + q] : most;
+        }
+        hipLaunchKernelGGL(bgrad_reduce_multi_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)m), dim3(64), 0, (hipStream_t)s, j, 64);
+    }
+    return launch_status("bgrad_reduce_multi_kernel");
 }
 
 int scipnp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,

@@ -385,9 +385,7 @@ conv3x3_wgrad_wino4_kernel(const float* __restrict__ act, const float* __restric
 
 // sum over slabs in fixed order, one thread per (position, co, ci): the sums replace slab 0 in place (every thread reads
 // and writes only its own element)
-__global__ void __launch_bounds__(256)
-wgrad_wino4_sum_kernel(float* __restrict__ slabs, int nslab, size_t stride) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void w4g_sum_body(float* __restrict__ slabs, int nslab, size_t stride, size_t idx) {
     if (idx >= stride) return;
     float* pp = slabs + idx;
     // four interleaved partial sums (slab k -> accumulator k % 4), then ((s0+s1)+s2)+s3, as wgrad_reduce_kernel
@@ -404,9 +402,8 @@ wgrad_wino4_sum_kernel(float* __restrict__ slabs, int nslab, size_t stride) {
 }
 
 // dW[co][ci][ky][kx] (OIHW, real channel counts) = G^T S G from the summed slab, in double
-__global__ void __launch_bounds__(256)
-wgrad_wino4_finish_kernel(const float* __restrict__ sums, float* __restrict__ dW, int Cin_real, int Cout_real, int coP, int ciP) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void w4g_finish_body(const float* __restrict__ sums, float* __restrict__ dW, int Cin_real, int Cout_real, int coP,
+                                                int ciP, int idx) {
     if (idx >= Cout_real * Cin_real) return;
     const int ci = idx % Cin_real, co = idx / Cin_real;                   // ci fastest: coalesced reads
     const size_t pstride = (size_t)coP * ciP;
@@ -443,6 +440,32 @@ wgrad_wino4_finish_kernel(const float* __restrict__ sums, float* __restrict__ dW
         }
 }
 
+__global__ void __launch_bounds__(256) wgrad_wino4_sum_kernel(float* __restrict__ slabs, int nslab, size_t stride) {
+    w4g_sum_body(slabs, nslab, stride, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256)
+wgrad_wino4_finish_kernel(const float* __restrict__ sums, float* __restrict__ dW, int Cin_real, int Cout_real, int coP, int ciP) {
+    w4g_finish_body(sums, dW, Cin_real, Cout_real, coP, ciP, blockIdx.x * blockDim.x + threadIdx.x);
+}
+#ifndef SCIPNP_DIAG_BUILD
+// the slab reductions / back-transforms of MANY layers in one launch each (blockIdx.y = the layer): a trainer that keeps every
+// layer's slabs until the end of its backward pass finishes them all with two launches instead of two per layer
+constexpr int W4G_MULTI_MAX = 32;
+struct W4gFinishJobs {
+    float* ws[W4G_MULTI_MAX];
+    float* dW[W4G_MULTI_MAX];
+    int nslab[W4G_MULTI_MAX], cin_real[W4G_MULTI_MAX], cout_real[W4G_MULTI_MAX], coP[W4G_MULTI_MAX], ciP[W4G_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256) wgrad_wino4_sum_multi_kernel(const W4gFinishJobs j) {
+    const int q = blockIdx.y;
+    w4g_sum_body(j.ws[q], j.nslab[q], (size_t)W4G_POS * j.coP[q] * j.ciP[q], (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) wgrad_wino4_finish_multi_kernel(const W4gFinishJobs j) {
+    const int q = blockIdx.y;
+    w4g_finish_body(j.ws[q], j.dW[q], j.cin_real[q], j.cout_real[q], j.coP[q], j.ciP[q], blockIdx.x * blockDim.x + threadIdx.x);
+}
+#endif
+
 static inline int w4g_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace scipnp
@@ -451,7 +474,7 @@ using namespace scipnp;
 
 static int w4g_launch(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n, int Cin_real,
                       int Cout_real, int Cin, int Cout, int h, int w, int dbg, scipnp_stream_t s) {
-    SCIPNP_REQUIRE(act_c8 && dz_c8 && dW && workspace, "null pointer");
+    SCIPNP_REQUIRE(act_c8 && dz_c8 && workspace, "null pointer");      // (dW == NULL: the slabs only, see ..._finish_multi)
     SCIPNP_REQUIRE(n > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 &&
                    Cout_real > 0 && Cin_real <= Cin && Cout_real <= Cout && nslab > 0, "bad shape");
     // (the input descriptor spans the tensor plus (w + 1) pixels: masked lanes carry the offset 0x80000000, which must stay
@@ -468,7 +491,7 @@ static int w4g_launch(const float* act_c8, const float* dz_c8, float* dW, float*
     hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, dim3((unsigned)(nslab * ncob * ncib)), dim3(W4G_THREADS), W4G_LDS_BYTES, st,
                        act_c8, dz_c8, workspace, n, Cin / 8, Cout / 8, h, w, nslab, ncob, ncib, dbg);
     int rc = launch_status("conv3x3_wgrad_wino4_kernel");
-    if (rc) return rc;
+    if (rc || dW == nullptr) return rc;
     const size_t per_slab = (size_t)W4G_POS * coP * ciP;
     hipLaunchKernelGGL(wgrad_wino4_sum_kernel, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, st, workspace, nslab,
                        per_slab);
@@ -490,6 +513,32 @@ size_t scipnp_conv3x3_wgrad_wino4_workspace_floats(int Cin, int Cout, int nslab)
 int scipnp_conv3x3_wgrad_wino4(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
                                int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s) {
     return w4g_launch(act_c8, dz_c8, dW, workspace, nslab, n, Cin_real, Cout_real, Cin, Cout, h, w, 0, s);
+}
+
+int scipnp_conv3x3_wgrad_wino4_finish_multi(int n, float* const* workspace, float* const* dW, const int* nslab, const int* Cin_real,
+                                            const int* Cout_real, const int* Cin, const int* Cout, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(n >= 0 && (n == 0 || (workspace && dW && nslab && Cin_real && Cout_real && Cin && Cout)), "bad arguments");
+    for (int base = 0; base < n; base += W4G_MULTI_MAX) {
+        const int m = n - base < W4G_MULTI_MAX ? n - base : W4G_MULTI_MAX;
+        W4gFinishJobs j = {};
+        size_t most_sum = 0;
+        int most_fin = 0;
+        for (int q = 0; q < m; ++q) {
+            const int g = base + q;
+            SCIPNP_REQUIRE(workspace[g] && dW[g] && nslab[g] > 0 && Cin[g] > 0 && Cout[g] > 0 && Cin[g] % 8 == 0 && Cout[g] % 8 == 0 &&
+                           Cin_real[g] > 0 && Cout_real[g] > 0 && Cin_real[g] <= Cin[g] && Cout_real[g] <= Cout[g], "bad arguments in job %d", g);
+            j.ws[q] = workspace[g]; j.dW[q] = dW[g]; j.nslab[q] = nslab[g]; j.cin_real[q] = Cin_real[g]; j.cout_real[q] = Cout_real[g];
+            j.ciP[q] = w4g_round_up(Cin[g], 32); j.coP[q] = w4g_round_up(Cout[g], 32);
+            const size_t per_slab = (size_t)W4G_POS * j.coP[q] * j.ciP[q];
+            most_sum = per_slab > most_sum ? per_slab : most_sum;
+            most_fin = Cout_real[g] * Cin_real[g] > most_fin ? Cout_real[g] * Cin_real[g] : most_fin;
+        }
+        hipLaunchKernelGGL(wgrad_wino4_sum_multi_kernel, dim3((unsigned)((most_sum + 255) / 256), (unsigned)m), dim3(256), 0,
+                           (hipStream_t)s, j);
+        hipLaunchKernelGGL(wgrad_wino4_finish_multi_kernel, dim3((unsigned)((most_fin + 255) / 256), (unsigned)m), dim3(256), 0,
+                           (hipStream_t)s, j);
+    }
+    return launch_status("wgrad_wino4 sum / finish multi kernels");
 }
 
 #else   /* ---- SCIPNP_DIAG_BUILD: the laboratory entry (libscipnp_diag.so, include/scipnp_diag.h) */

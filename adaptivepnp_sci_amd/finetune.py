@@ -62,7 +62,7 @@ def _wino4_slabs(cin, cout):
 
 
 def wgrad_f4_enabled():
-    """the fp32 FFDNet trainer takes the weight gradients of its 32-multiple layers in the Winograd F(4x4) domain
+    """the fp32 FFDNet trainer takes the weight gradients of its layers (since round 5 all of them) in the Winograd F(4x4) domain
     (csrc/wgrad_wino4.hip: 382 us against 441 us of the F(2x2) form at 96 -> 96 on 8 x 256 x 256, rounding 4.9e-6 against
     1.5e-6 of the gradient's norm, gate 1e-4: DESIGN.md section 5); SCIPNP_F32_WGRAD=f2 keeps the F(2x2) form"""
     from . import config
@@ -166,6 +166,8 @@ class _FFDNetTrainer:
         self._synced = None                               # (data_ptr, _version) of every parameter when device == module
         self._host = None                                 # pinned staging buffer of the deferred write-back
         self._wb = None                                   # (stream, event) of a write-back in flight
+        self.losses = []                                  # (device mean, trace list) of the Adam steps not reported yet
+        self._host_loss, self._loss_on_host = None, 0     # pinned copies of their sums (deferred write-back)
         # master parameters, gradients and Adam moments live in four flat buffers: one Adam launch per step
         self.flat_p, self.flat_g = torch.empty(total, dtype=F32, device=dev), torch.empty(total, dtype=F32, device=dev)
         self.flat_m, self.flat_v = torch.zeros(total, dtype=F32, device=dev), torch.zeros(total, dtype=F32, device=dev)
@@ -214,6 +216,14 @@ class _FFDNetTrainer:
                              for ci, co in zip(self.cin, self.cout)])
         self.ws = torch.empty(ws, dtype=F32, device=dev)
         self.bws = torch.empty((nc // 8) * 64 * 8, dtype=F32, device=dev)
+        # F(4x4)-domain weight gradients: every layer keeps its own slabs and bias partials until the end of the backward pass,
+        # where ONE slab-reduction, ONE back-transform and ONE bias-reduction launch finish all of them (round 5: three dependent
+        # launches of 5-9 us per layer and step were 0.45 ms of a 12 ms tile event)
+        self.ws_l = self.bws_l = None
+        if self.wino4 and all(_wino_wgrad_fits(B, ci, co, M, N) for ci, co in zip(self.cin, self.cout)):
+            self.ws_l = [torch.empty(lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(ci, co, _wino4_slabs(ci, co)), dtype=F32, device=dev)
+                         for ci, co in zip(self.cin, self.cout)]
+            self.bws_l = [torch.empty((co // 8) * 64 * 8, dtype=F32, device=dev) for co in self.cout]
         nb_ = C.c_int(0)
         _lib.check(lib.scipnp_ffdnet_loss_grad(None, None, None, None, None, M, N, B, C.byref(nb_), None), 'loss size')
         self.loss_part = torch.empty(nb_.value, dtype=torch.float64, device=dev)
@@ -300,11 +310,14 @@ class _FFDNetTrainer:
         eng = self.eng
         B, M, N = eng.B, eng.M, eng.N
         dz = self.gout
+        if self.ws_l is not None:
+            return self._backward_deferred(dz)
         for l in range(self.nb - 1, -1, -1):
             a_in = eng.in_c8 if l == 0 else self.acts[l - 1]
             ci_r, co_r = self._real(l)
-            if self.wino4 and self.cin[l] % 32 == 0 and self.cout[l] % 32 == 0 and \
-                    _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
+            # (every layer, the 16-channel head and tail included -- the kernel pads the narrow side to its 32-channel block:
+            # 84 / 82 us against 106 / 118 us of the F(2x2)-domain kernel on a tile, profiles/r05zw_wgrad_narrow.txt)
+            if self.wino4 and _wino_wgrad_fits(B, self.cin[l], self.cout[l], M, N):
                 _lib.check(self.lib.scipnp_conv3x3_wgrad_wino4(_ptr(a_in), _ptr(dz), _ptr(self.dw[l]), _ptr(self.ws),
                                                                _wino4_slabs(self.cin[l], self.cout[l]), B, ci_r, co_r,
                                                                self.cin[l], self.cout[l], M, N, _s()), 'wgrad wino4')
@@ -327,6 +340,33 @@ class _FFDNetTrainer:
                     _lib.check(self.lib.scipnp_conv3x3_c8(_ptr(dz), _ptr(self.bwd[l]), _ptr(nxt), _ptr(self.acts[l - 1]), B,
                                                           self.cout[l], self.cin[l], M, N, 16, _s()), 'backward-data conv')
                 dz = nxt
+
+    def _backward_deferred(self, dz):
+        """the same backward pass with the F(4x4)-domain weight gradient of every layer: slabs and bias partials stay in the
+        layer's own workspace, three multi-layer launches at the end turn them into dW / db (same kernels' arithmetic: the
+        gradients are bit-identical to finishing layer by layer)"""
+        eng, lib = self.eng, self.lib
+        B, M, N = eng.B, eng.M, eng.N
+        for l in range(self.nb - 1, -1, -1):
+            a_in = eng.in_c8 if l == 0 else self.acts[l - 1]
+            ci_r, co_r = self._real(l)
+            _lib.check(lib.scipnp_conv3x3_wgrad_wino4(_ptr(a_in), _ptr(dz), None, _ptr(self.ws_l[l]),
+                                                      _wino4_slabs(self.cin[l], self.cout[l]), B, ci_r, co_r, self.cin[l],
+                                                      self.cout[l], M, N, _s()), 'wgrad wino4 slabs')
+            _lib.check(lib.scipnp_conv_bias_grad(_ptr(dz), None, _ptr(self.bws_l[l]), B, co_r, self.cout[l], M, N, _s()), 'bgrad partials')
+            if l > 0:
+                nxt = self.dz[l & 1]
+                ops.conv3x3_c8w(dz.view(B, self.cout[l] // 8, M, N, 8), self.bwd_w[l], self.cin[l], mask_src=self.acts[l - 1], out=nxt)
+                dz = nxt
+        n = self.nb
+        P, I = C.c_void_p * n, C.c_int * n
+        real = [self._real(l) for l in range(n)]
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino4_finish_multi(
+            n, P(*[t.data_ptr() for t in self.ws_l]), P(*[t.data_ptr() for t in self.dw]),
+            I(*[_wino4_slabs(ci, co) for ci, co in zip(self.cin, self.cout)]), I(*[r[0] for r in real]), I(*[r[1] for r in real]),
+            I(*self.cin), I(*self.cout), _s()), 'wgrad wino4 finish')
+        _lib.check(lib.scipnp_conv_bias_grad_reduce_multi(n, P(*[t.data_ptr() for t in self.bws_l]), P(*[t.data_ptr() for t in self.db]),
+                                                          I(*[r[1] for r in real]), _s()), 'bgrad reduce')
 
     def _backward_split(self):
         eng = self.eng
@@ -367,9 +407,11 @@ class _FFDNetTrainer:
         self.finish_write_back()
         if model is not self.model:
             return False
-        cur = ffdnet_layers(model)                        # (state_dict views: new tensor objects over the parameters' storage)
-        if len(cur) != len(self.layers) or any(a.data_ptr() != c.data_ptr() or b.data_ptr() != d.data_ptr() or a.shape != c.shape
-                                               for (a, b), (c, d) in zip(cur, self.layers)):
+        # the module's parameters still live where this trainer reads / writes them (storage identity: state_dict() and
+        # parameters() hand out new tensor objects over the same storage)
+        mine = {t.data_ptr() for t in self._params()}
+        cur = [q for q in model.parameters()]
+        if len(cur) != len(mine) or any(q.data_ptr() not in mine for q in cur):
             return False
         if self._synced is None or self._synced != self._mark():
             _upload_flat(self.flat_p, [t.detach() for t in self._params()])
@@ -400,14 +442,32 @@ class _FFDNetTrainer:
         self._wb_stream.wait_stream(cur)
         with torch.cuda.stream(self._wb_stream):
             self._host.copy_(self.flat_p, non_blocking=True)
+            if self.losses:                          # the steps' losses ride along (an .item() on the solve's stream would wait
+                if self._host_loss is None or self._host_loss.numel() < len(self.losses):     # for the evaluation pass)
+                    self._host_loss = torch.empty(max(8, len(self.losses)), dtype=torch.float64, pin_memory=True)
+                for i, (loss, _) in enumerate(self.losses):
+                    self._host_loss[i:i + 1].copy_(loss.total.reshape(1), non_blocking=True)
+                self._loss_on_host = len(self.losses)
             ev = torch.cuda.Event()
             ev.record(self._wb_stream)
         self._wb = ev
 
+    def report_losses(self):
+        """the reference prints the loss tensor of every Adam step (test_ffdnet_ipol.py:298-299)"""
+        pending, self.losses = self.losses, []
+        on_host, self._loss_on_host = self._loss_on_host, 0
+        for i, (loss, trace) in enumerate(pending):
+            val = float(self._host_loss[i]) / loss.count if i < on_host else float(loss.item())
+            print('loss:', val)
+            if trace is not None:
+                trace.append(val)
+
     def finish_write_back(self):
+        if self._wb is not None:
+            self._wb.synchronize()
+        self.report_losses()
         if self._wb is None:
             return
-        self._wb.synchronize()
         self._wb = None
         host = self._host.numpy()
         off = 0
@@ -443,13 +503,12 @@ def ffdnet_online_finetune(model, eng, y_pm, Phi_pm, sigma, lr_, update_per_iter
                        **{f'model.{2 * l}.bias': tr.db[l].clone() for l in range(tr.nb)}})
         tr.adam(lr_)
         tr.pack(final=(it == update_per_iter - 1))
-        val = float(loss.item())
-        print('loss:', val)                                   # the reference prints the loss tensor (:298-299)
-        if trace is not None:
-            trace.append(val)
-    tr.write_back(defer=defer_write_back)
+        tr.losses.append((loss, trace))                       # read back and printed once the whole event is enqueued (a
+    tr.write_back(defer=defer_write_back)                     # read-back per step stalled the GPU for 0.1 ms each)
     eng.adopt(tr.fwd, tr.fwd_s if tr.split else None,     # the engine continues on the device-packed updated weights
               packed_wino=tr.fwd_w if tr.wino else None)
+    if not defer_write_back:
+        tr.report_losses()
     return tr if defer_write_back else model
 
 

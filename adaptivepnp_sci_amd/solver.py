@@ -322,6 +322,7 @@ class AdmmRun:
             # kernels on -b:  x + 1*(-b) = x - b exactly, and (-b) + (x - theta) = -(b - (x - theta)).
             b_in, inv_rho, inv_tau, w = ops.negate(self.b), 1.0, 0.0, None
         closed = self.close_form and k > 0      # closed-form RGB update (reference :175-182 / :224-230), Malvar at k = 0
+        pending = None
         if self.denoiser == 'ffdnet_color':
             split = self.eng.precision == 'f16x3'
             # the finetune's weight-gradient kernel (fp32 MFMA) needs the fp32 c8 input as well
@@ -335,15 +336,12 @@ class AdmmRun:
                 ops.pm_pre_rgb(w, self.x_rgb, None, c8, inv_tau, nsig, net_in_c8s=c8s)
             else:
                 ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s)
-            pending = None
             if gate:
                 from .finetune import ffdnet_online_finetune
                 pending = ffdnet_online_finetune(self.model, self.eng, self.y, self.Phi, nsig, self.lr_, self.update_per_iter,
                                                  logf=self.logf, defer_write_back=True)
             self.eng.forward(events=self.profile_events)
-            if pending is not None and hasattr(pending, 'finish_write_back'):
-                pending.finish_write_back()             # (the module holds the updated weights when step() returns, as before;
-            src_rgb, src_c8 = None, self.eng.out_c8     # the copy ran beside the evaluation pass)
+            src_rgb, src_c8 = None, self.eng.out_c8
         else:
             net_in = self.rgb_w if self.two_stage else self.x_rgb
             if closed:
@@ -373,6 +371,9 @@ class AdmmRun:
                 ops.sse_partials(self.orig, self.x, self._new_sse(ops.sse_nblocks(self.x.numel())))
         if last:
             self.out_rgb = self.out_store if src_c8 is not None else src_rgb
+        if pending is not None and hasattr(pending, 'finish_write_back'):
+            pending.finish_write_back()         # the event's losses are printed and the module receives the updated weights once
+                                                # everything of this iteration is enqueued: both travelled beside the evaluation pass
 
     def _deep_demosaic(self, b_in, inv_rho):
         """x_rgb = DDnet(mosaic of x + b/rho)  (reference :168-171, :192-194)"""

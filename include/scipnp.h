@@ -327,9 +327,16 @@ int scipnp_conv3x3_wgrad_wino(const float* act_c8, const float* dz_c8, float* dW
 size_t scipnp_conv3x3_wgrad_wino4_workspace_floats(int Cin, int Cout, int nslab);
 int scipnp_conv3x3_wgrad_wino4(const float* act_c8, const float* dz_c8, float* dW, float* workspace, int nslab, int n,
                                int Cin_real, int Cout_real, int Cin, int Cout, int h, int w, scipnp_stream_t s);
+/* dW == NULL: only the kernel that fills the slabs; the slab reductions and back-transforms of n such layers (each with its own
+ * workspace) then take two launches in all -- a trainer finishes every layer at the end of its backward pass */
+int scipnp_conv3x3_wgrad_wino4_finish_multi(int n, float* const* workspace, float* const* dW, const int* nslab, const int* Cin_real,
+                                            const int* Cout_real, const int* Cin, const int* Cout, scipnp_stream_t s);
 /* db[co] = sum dz; workspace >= (Cout/8)*64*8 floats */
 int scipnp_conv_bias_grad(const float* dz_c8, float* db, float* workspace, int n, int Cout_real, int Cout,
                           int h, int w, scipnp_stream_t s);
+/* db == NULL: the partial sums only (workspace keeps them); the reductions of n layers in one launch */
+int scipnp_conv_bias_grad_reduce_multi(int n, const float* const* workspace, float* const* db, const int* Cout_real,
+                                       scipnp_stream_t s);
 /* one torch.optim.Adam step (amsgrad=False, weight_decay=0) on a flat float32 tensor; step counts from 1 */
 int scipnp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                      double beta1, double beta2, double eps, int step, scipnp_stream_t s);

@@ -3,7 +3,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft
-FT_REPS=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft -- python3 $GRAFT_REPO_ROOT/tools/finetune_bench.py > $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft.log 2>&1 || exit 1
+FT_REPS=${FT_REPS:-4} timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft -- python3 $GRAFT_REPO_ROOT/tools/finetune_bench.py > $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft.log 2>&1 || exit 1
 grep "iteration with" $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft.log
 python3 $GRAFT_REPO_ROOT/tools/trace_stats.py $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft 30 | cut -c1-170 | tee $GRAFT_REPO_ROOT/gpurun_out/r05zu_ft_summary.txt
 python3 - <<'PY'
