@@ -608,31 +608,36 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
             const unsigned pbytes = (unsigned)((size_t)H2 * W2 * 32);
             auto r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + plane), 0, pbytes, 0x00020000);
             auto r_res = __builtin_amdgcn_make_buffer_rsrc((void*)((add_res ? a.residual : a.out) + plane), 0, pbytes, 0x00020000);
+            // 16 rows x 32 groups of 4 pixels = 512 lines of 128 bytes, 4096 pieces of 16 bytes: piece s * 256 + tid -> line (piece >> 3),
+            // chunk (tid & 7): the eight lanes of a line write it in ONE store instruction (round 5; until then a thread wrote its own
+            // 128 bytes in eight instructions, each of which touched 64 lines with 16 bytes -- the pattern the LINES epilogue removed
+            // from the plain store)
+            const int chunk = tid & 7;
     #pragma unroll
-            for (int it = 0; it < 2; ++it) {                    // 16 rows x 32 groups of 4 pixels = 512 items, two per thread
-                const int item = tid + it * W4_THREADS, yl = item >> 5, xg = item & 31;
-                const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg;
-                const float* src = tile + yl * ROW + xg * 36;
+            for (int half = 0; half < 2; ++half) {
                 f32x4 px[8];
+                unsigned off[8];
     #pragma unroll
-                for (int k = 0; k < 8; ++k) px[k] = *(const f32x4*)(src + 4 * k);
-                unsigned off[4];
-    #pragma unroll
-                for (int k = 0; k < 4; ++k) off[k] = (y2 < H2 && x2 + k < W2) ? (unsigned)(((size_t)y2 * W2 + x2 + k) * 32) : 0x80000000u;
+                for (int s = 0; s < 8; ++s) {
+                    const int line = (half * 8 + s) * 32 + (tid >> 3), yl = line >> 5, xg = line & 31;
+                    const int y2 = 2 * y0 + yl, x2 = 2 * x0 + 4 * xg + (chunk >> 1);
+                    px[s] = *(const f32x4*)(tile + yl * ROW + xg * 36 + 4 * chunk);
+                    off[s] = (y2 < H2 && x2 < W2) ? (unsigned)(((size_t)y2 * W2 + x2) * 32 + 16 * (chunk & 1)) : 0x80000000u;
+                }
                 if (add_res) {
     #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        px[k] = px[k] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[k >> 1] + 16 * (k & 1), 0, 0));
+                    for (int s = 0; s < 8; ++s)
+                        px[s] = px[s] + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off[s], 0, 0));
                 }
                 if (relu) {
     #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int s = 0; s < 8; ++s)
     #pragma unroll
-                        for (int e = 0; e < 4; ++e) px[k][e] = fmaxf(px[k][e], 0.f);
+                        for (int e = 0; e < 4; ++e) px[s][e] = fmaxf(px[s][e], 0.f);
                 }
     #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[k]), r_out, off[k >> 1] + 16 * (k & 1), 0, 0);
+                for (int s = 0; s < 8; ++s)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[s]), r_out, off[s], 0, 0);
             }
     #endif
             return;
