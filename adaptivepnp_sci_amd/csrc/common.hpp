@@ -180,6 +180,19 @@ int tv_band_candidates(const float* x, const float* b, float coef, int M, int N,
 int tv_stop_test_launch(const TvCandidates& cd, int C, float weight, float eps, hipStream_t st);
 double tv_scalar_as_double(float f);     // weight / eps: the shortest decimal that round-trips the float (tv.hip as_double)
 
+// A/B switches of the laboratory (the round-2 schedules of the TV kernels, the general dual-update + projection kernel, band /
+// batch geometries): the PRODUCT library reads no environment variable -- every choice of form it offers is an argument
+// (scipnp.h) or a field of adaptivepnp_sci_amd.config.Config.  `make tvvariant NAME=lab TVFLAGS=-DSCIPNP_LAB_SWITCHES` builds a
+// library in which lab_switch("SCIPNP_...") looks the variable up (tools/gpu_round5_tv_*.sh run their A/B rows on that build).
+inline const char* lab_switch(const char* name) {
+#ifdef SCIPNP_LAB_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // State handed from one launch of the ADMM-TV iteration to the next (the band kernel's candidates and partial sums; theta / b / x
 // of the fused dual update + projection) is stored NON-TEMPORALLY: the consumer runs on all eight XCDs, whose L2s are not coherent
 // with each other, so these lines have to reach the memory side before the next launch can read them -- written through as they

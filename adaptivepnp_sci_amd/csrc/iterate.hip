@@ -36,7 +36,7 @@ static TvPath tv_path(const scipnp_admm_tv_args* a) {
     // the same launch, no candidates written) fills the chip once there is a plane per CU -- 256 planes of 128 x 128 take 1 x
     // the whole-plane kernel's time where the banded form + fused projection pay per plane (tools/probes/tv_units_probe.py)
     if (banded && U > 1 && tv_plane_dual_fits(M, N, 4 * BU, p.nstd, want_sse)) {
-        static const int force = [] { const char* e = getenv("SCIPNP_TV_PLANE_BATCH"); return e ? atoi(e) : -1; }();
+        static const int force = [] { const char* e = lab_switch("SCIPNP_TV_PLANE_BATCH"); return e ? atoi(e) : -1; }();
         const int cus = device_cu_count();
         const long long planes = 4LL * BU, gens = (planes + cus - 1) / cus;
         const bool fills = planes * 4 >= gens * cus * 3;                    // the last generation leaves at most a quarter idle

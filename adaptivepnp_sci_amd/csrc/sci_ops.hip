@@ -1022,8 +1022,8 @@ int pm_dual_project_sel(const float* theta_raw, const TvCandidates* cdp, double 
     // the candidate form keeps the stop iteration of at most 4 planes per workgroup (always true for one unit)
     SCIPNP_REQUIRE(!use_cd || units == 1 || ((long long)CH * threads * VECs - 1) / MN + 2 <= 4,
                    "unit-batched candidate form: planes of %lld pixels are too small for this launch shape", MN);
-    // small states in the candidate form: the one-round-trip kernel (SCIPNP_DUAL_PROJECT_GENERAL=1 keeps the general one, for A/B)
-    static const bool general_only = [] { const char* e = getenv("SCIPNP_DUAL_PROJECT_GENERAL"); return e && e[0] == '1'; }();
+    // small states in the candidate form: the one-round-trip kernel (laboratory builds: SCIPNP_DUAL_PROJECT_GENERAL=1 keeps the general one, for A/B)
+    static const bool general_only = [] { const char* e = lab_switch("SCIPNP_DUAL_PROJECT_GENERAL"); return e && e[0] == '1'; }();
     if (use_cd && !general_only && VECs == 1 && CH == 1 && B <= 8 && cd.nbands <= 8 && MN % 256 == 0 && Q % 256 == 0) {
         const double inv_mn = (MN & (MN - 1)) == 0 ? 1.0 / (double)MN : 0.0;
 #if defined(SCIPNP_TV_STAMPS)

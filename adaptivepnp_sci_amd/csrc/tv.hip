@@ -910,17 +910,17 @@ tv_band_kernel(const float* __restrict__ x, const float* __restrict__ b, float c
 // band height for N <= 256: 16-row bands when 32-row bands would leave the chip short of workgroups
 bool tv_band_fits(int M, int N, int n_iter) { return N <= 256 && n_iter >= 1 && n_iter - 1 <= TVB_HALO; }
 
-// experiment switch (SCIPNP_TV_TINY_BANDS=1): 8-row bands for problems that leave the chip short of workgroups even with 16-row
+// laboratory switch (lab_switch; SCIPNP_TV_TINY_BANDS=1): 8-row bands for problems that leave the chip short of workgroups even with 16-row
 // bands (twice the workgroups, 16 computed rows per 8 useful ones)
 static bool tv_tiny_bands() {
-    static const bool on = [] { const char* e = getenv("SCIPNP_TV_TINY_BANDS"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char* e = lab_switch("SCIPNP_TV_TINY_BANDS"); return e && e[0] == '1'; }();
     return on;
 }
 
-// experiment switch (SCIPNP_TV_BAND_V1=1): the round-2 schedule of the band computation (tv_band_run) instead of round 5's
+// laboratory switch (lab_switch, -DSCIPNP_LAB_SWITCHES builds only; SCIPNP_TV_BAND_V1=1): the round-2 schedule of the band computation (tv_band_run) instead of round 5's
 // (tv_band_run2) -- same results, for A/B timing
 static bool tv_band_v1() {
-    static const bool on = [] { const char* e = getenv("SCIPNP_TV_BAND_V1"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char* e = lab_switch("SCIPNP_TV_BAND_V1"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -1010,7 +1010,7 @@ static int tv_plane_launch(const float* x, const float* b, float coef, float* th
                            hipStream_t st) {
     // rows per thread: ceil(M / strips), strips = 1024 / columns
     const TvDual d = dual ? *dual : TvDual{};
-    static const bool plane_v1 = [] { const char* e = getenv("SCIPNP_TV_PLANE_V1"); return e && e[0] == '1'; }();
+    static const bool plane_v1 = [] { const char* e = lab_switch("SCIPNP_TV_PLANE_V1"); return e && e[0] == '1'; }();
 #define SCIPNP_TVP_(COLS, R, V2)                                                                                        \
     do {                                                                                                                \
         if (dual)                                                                                                       \

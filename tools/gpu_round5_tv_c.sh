@@ -2,6 +2,8 @@
 # round 5: band kernel v2 + one-round-trip dual-update/projection kernel -- parity tests touching the TV step, then the ADMM-TV
 # iteration's kernel durations (rocprofv3 kernel trace) for: new kernels, old band kernel, old dual-project kernel
 set -u
+# (the SCIPNP_TV_BAND_V1 / SCIPNP_DUAL_PROJECT_GENERAL rows need the laboratory build: make -C adaptivepnp_sci_amd/csrc tvvariant NAME=lab TVFLAGS=-DSCIPNP_LAB_SWITCHES)
+export SCIPNP_LIB=${SCIPNP_LIB:-$GRAFT_REPO_ROOT/build/variants/libscipnp_tvlab.so}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 TAG=${1:-r05z}

@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: ADMM-TV iteration -- clock stamps of the band kernel, kernel durations of the iteration (new / old band / old projection)
 set -u
+# (the SCIPNP_TV_BAND_V1 / SCIPNP_DUAL_PROJECT_GENERAL rows need the laboratory build: make -C adaptivepnp_sci_amd/csrc tvvariant NAME=lab TVFLAGS=-DSCIPNP_LAB_SWITCHES)
+export SCIPNP_LIB=${SCIPNP_LIB:-$GRAFT_REPO_ROOT/build/variants/libscipnp_tvlab.so}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 TAG=${1:-r05z}
