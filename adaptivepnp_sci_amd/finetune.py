@@ -436,8 +436,13 @@ class _FFDNetTrainer:
             if pool is None:
                 pool = _WB_TLS.pool = {}
             if key not in pool:
-                pool[key] = (torch.empty(self.flat_p.numel(), dtype=F32, pin_memory=True), torch.cuda.Stream(self.flat_p.device))
-            self._host, self._wb_stream = pool[key]
+                pool[key] = [torch.empty(self.flat_p.numel(), dtype=F32, pin_memory=True), torch.cuda.Stream(self.flat_p.device), None]
+            self._pool = pool[key]
+            self._host, self._wb_stream = self._pool[0], self._pool[1]
+        owner = self._pool[2]                    # the staging buffer is shared: whoever used it last has to be done with it
+        if owner is not None and owner is not self:
+            owner.finish_write_back()
+        self._pool[2] = self
         cur = torch.cuda.current_stream(self.flat_p.device)
         self._wb_stream.wait_stream(cur)
         with torch.cuda.stream(self._wb_stream):
