@@ -853,6 +853,67 @@ def test_winograd_f4_wgrad_vs_autograd(ops):
     assert lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), p(dW), p(ws), 0, n, ci_r, co_r, ci, co, h, w, s) != 0
 
 
+def test_multi_layer_entries_equal_their_single_layer_calls(ops):
+    """round 5: the trainer's many tiny per-layer launches as ONE launch per kind -- scipnp_pack_conv3x3_device_multi,
+    scipnp_pack_conv3x3_wino4_multi, scipnp_conv3x3_wgrad_wino4 with dW = NULL + scipnp_conv3x3_wgrad_wino4_finish_multi,
+    scipnp_conv_bias_grad with db = NULL + scipnp_conv_bias_grad_reduce_multi: bit-identical to the per-layer calls, for layers of
+    different shapes in one table (narrow head / tail, padded channels, transposed packs), more jobs than one table holds, n = 0"""
+    import ctypes as C
+    from adaptivepnp_sci_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(515)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    layers = [(13, 96, 16, 96), (96, 96, 96, 96), (96, 12, 96, 16), (24, 40, 24, 40)] * 10          # 40 layers > 32 per table
+    ws_ = [torch.randn(co_r, ci_r, 3, 3, generator=g).cuda() for ci_r, co_r, _, _ in layers]
+    bs_ = [torch.randn(co_r, generator=g).cuda() for _, co_r, _, _ in layers]
+    jobs, single = [], []
+    for (ci_r, co_r, ci, co), w, b in zip(layers, ws_, bs_):
+        for tr in (0, 1):
+            n = lib.scipnp_conv3x3_packed_floats(co, ci) if tr else lib.scipnp_conv3x3_packed_floats(ci, co)
+            a, b_ = torch.full((n,), float('nan'), device='cuda'), torch.full((n,), float('nan'), device='cuda')
+            jobs.append((w, None if tr else b, a, ci_r, co_r, ci, co, tr))
+            _lib.check(lib.scipnp_pack_conv3x3_device(p(w), None if tr else p(b), p(b_), ci_r, co_r, ci, co, tr, s), 'pack')
+            single.append(b_)
+    ops.pack_conv3x3_device_multi(jobs)
+    assert all(torch.equal(j[2], r) for j, r in zip(jobs, single))
+    ops.pack_conv3x3_device_multi([])                                            # nothing to do
+    # F(4x4) packs from the forward packs
+    fw = [(j[2], j[5], j[6]) for j in jobs if not j[7]]
+    outs = [torch.full((lib.scipnp_conv3x3_wino4_packed_floats(ci, co),), float('nan'), device='cuda') for _, ci, co in fw]
+    ops.pack_conv3x3_wino4_multi([(pk, o, ci, co) for (pk, ci, co), o in zip(fw, outs)])
+    for (pk, ci, co), o in zip(fw, outs):
+        assert torch.equal(o, ops.pack_conv3x3_wino4(pk, ci, co))
+    # weight / bias gradients: slabs and partials first, one finish for all layers
+    n, h, w = 2, 13, 37
+    four = layers[:4]
+    xs = [ops.to_c8(torch.relu(torch.randn(n, ci_r, h, w, generator=g)).cuda()) for ci_r, _, _, _ in four]
+    dzs = [ops.to_c8(torch.randn(n, co_r, h, w, generator=g).cuda()) for _, co_r, _, _ in four]
+    nsl = [5, 3, 7, 64]
+    wss = [torch.full((lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(ci, co, k),), float('nan'), device='cuda')
+           for (_, _, ci, co), k in zip(four, nsl)]
+    bws = [torch.full(((co // 8) * 64 * 8,), float('nan'), device='cuda') for _, _, _, co in four]
+    dW = [torch.full((co_r, ci_r, 3, 3), float('nan'), device='cuda') for ci_r, co_r, _, _ in four]
+    db = [torch.full((co_r,), float('nan'), device='cuda') for _, co_r, _, _ in four]
+    for (ci_r, co_r, ci, co), x8, dz8, ws, bw, k in zip(four, xs, dzs, wss, bws, nsl):
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), None, p(ws), k, n, ci_r, co_r, ci, co, h, w, s), 'slabs')
+        _lib.check(lib.scipnp_conv_bias_grad(p(dz8), None, p(bw), n, co_r, co, h, w, s), 'partials')
+    P, I = C.c_void_p * 4, C.c_int * 4
+    _lib.check(lib.scipnp_conv3x3_wgrad_wino4_finish_multi(4, P(*[t.data_ptr() for t in wss]), P(*[t.data_ptr() for t in dW]), I(*nsl),
+                                                           I(*[l[0] for l in four]), I(*[l[1] for l in four]), I(*[l[2] for l in four]),
+                                                           I(*[l[3] for l in four]), s), 'finish')
+    _lib.check(lib.scipnp_conv_bias_grad_reduce_multi(4, P(*[t.data_ptr() for t in bws]), P(*[t.data_ptr() for t in db]),
+                                                      I(*[l[1] for l in four]), s), 'reduce')
+    for (ci_r, co_r, ci, co), x8, dz8, k, dw_m, db_m in zip(four, xs, dzs, nsl, dW, db):
+        ws1 = torch.empty(lib.scipnp_conv3x3_wgrad_wino4_workspace_floats(ci, co, k), device='cuda')
+        dw1, db1, bw1 = torch.empty_like(dw_m), torch.empty_like(db_m), torch.empty((co // 8) * 64 * 8, device='cuda')
+        _lib.check(lib.scipnp_conv3x3_wgrad_wino4(p(x8), p(dz8), p(dw1), p(ws1), k, n, ci_r, co_r, ci, co, h, w, s), 'wgrad')
+        _lib.check(lib.scipnp_conv_bias_grad(p(dz8), p(db1), p(bw1), n, co_r, co, h, w, s), 'bgrad')
+        assert torch.equal(dw_m, dw1) and torch.equal(db_m, db1), (ci_r, co_r)
+    assert lib.scipnp_conv3x3_wgrad_wino4_finish_multi(1, P(None, None, None, None), P(*[t.data_ptr() for t in dW]), I(*nsl), I(1, 1, 1, 1),
+                                                       I(1, 1, 1, 1), I(8, 8, 8, 8), I(8, 8, 8, 8), s) != 0      # null workspace refused
+
+
 def test_split_wgrad_bgrad_backward_data_vs_autograd(ops):
     """the finetune's split-fp16 kernels: weight / bias gradients from c8s operands (transposing LDS reads, pre-scaled
     dZ) and the backward-data conv with the ReLU-mask epilogue, against PyTorch autograd in float64"""
