@@ -515,15 +515,27 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                             for (int e = 0; e < 4; ++e) v[it][e] = (fw[e] > 0.f) ? v[it][e] : 0.f;
                         }
                     }
-                    // Cache hints on the stores (DIAG bits 10 / 11, laboratory only): with the nt hint the ISOLATED layer -- the same input
-                    // tensor every launch -- takes 227 - 230 us instead of 246 - 249 (sc1: 241 - 247; profiles/r05d_wino4_store_hints.txt),
-                    // but inside the network pass, where every launch reads what the previous one wrote, the body launch stays at
-                    // 240 us and the 256x256x16 tile iteration gets SLOWER (1.37 -> 1.43 ms: its 100 MB tensors are served from the
-                    // Infinity Cache when the stores allocate there) -- plain stores are the product
+                    // Cache hints on the stores.  With the nt hint the ISOLATED body layer takes 227 - 230 us instead of 246 - 249
+                    // (profiles/r05d_wino4_store_hints.txt), but inside a network pass, where every launch reads what the previous
+                    // one wrote, it depends on the size: outputs that the 256 MB Infinity Cache can hold next to the layer's input are
+                    // served from there when the stores allocate (256x256x16 tile, 50 MB per launch: 1.31 -> 1.36 ms per iteration
+                    // with nt), at 100 MB per launch it is even, larger outputs leave faster without allocating (1024x1024x8: 10.53
+                    // -> 10.34 ms; DDnet 13.81 -> 13.56 ms, FastDVDnet 5.50 -> 5.43 ms; profiles/r05zz_w4nt_*).  The entry point
+                    // sets W4_FLAG_NT for launches whose output is 128 MB or more; DIAG bits 10 / 11 force nt / sc1 (laboratory).
+#ifdef W4_STORE_NT                                   /* variant build: every whole-line store with the nt hint */
+                    constexpr int AUX = 2;
+#else
                     constexpr int AUX = (DIAG & 1024) ? 2 : (DIAG & 2048) ? 16 : 0;
+#endif
+                    if (AUX == 0 && (a.flags & W4_FLAG_NT)) {            // (workgroup-uniform)
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, AUX);
+                        for (int it = 0; it < 4; ++it)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, 2);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, AUX);
+                    }
                 }
 #endif
             }
@@ -635,9 +647,15 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
     #pragma unroll
                         for (int e = 0; e < 4; ++e) px[s][e] = fmaxf(px[s][e], 0.f);
                 }
+                if (a.flags & W4_FLAG_NT) {                      // (outputs of 128 MB or more: see the whole-line epilogue)
     #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[s]), r_out, off[s], 0, 0);
+                    for (int s = 0; s < 8; ++s)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[s]), r_out, off[s], 0, 2);
+                } else {
+    #pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, px[s]), r_out, off[s], 0, 0);
+                }
             }
     #endif
             return;
@@ -855,6 +873,7 @@ int scipnp_conv3x3_c8w4(const float* in, const float* packed_wino4, float* out, 
     a.ntx = (w + W4_TW - 1) / W4_TW; a.nty = (h + W4_TH - 1) / W4_TH;
     a.m_ncb = w4_magic(a.NCB); a.m_ntx = w4_magic(a.ntx); a.m_nty = w4_magic(a.nty);
     a.flags = flags;
+    if ((long long)n * Cout * h * w * 4 >= W4_NT_BYTES) a.flags |= W4_FLAG_NT;      // (see the store epilogue)
     const long long total = (long long)a.ntx * a.nty * n * a.NCB;
     SCIPNP_REQUIRE(total < (1ll << 31), "grid too large");
     a.total_units = (unsigned)total;

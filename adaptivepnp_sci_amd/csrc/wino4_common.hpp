@@ -18,6 +18,8 @@ constexpr int W4_PIECES = W4_SLAB / 256;              // 1 KiB LDS-DMA pieces pe
 constexpr int W4_TW = 64, W4_TH = 8;                  // output pixels per workgroup
 constexpr int W4_TWP = W4_TW + 2, W4_THP = W4_TH + 2; // halo tile
 constexpr int W4_THREADS = 256;
+constexpr int W4_FLAG_NT = 1 << 20;                          // Wino4Args.flags, set by the entry point: whole-line stores with the nt hint
+constexpr long long W4_NT_BYTES = 128ll << 20;              // ... for launches that write at least this much
 constexpr int W4_RSL = W4_TWP + W4_TWP / 16;          // slots per halo row: pixel x sits in slot x + (x >> 4) (one padding slot per 16)
 constexpr int W4_UNITS = W4_THP * W4_RSL * 2;         // 16-byte units (4 channels of a pixel) of the halo tile: [hf][row][slot]
 constexpr int W4_RAW_PIECES = (W4_UNITS + 63) / 64;   // 1 KiB LDS-DMA pieces per raw tile (21; the last one partly padding)
