@@ -94,6 +94,7 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
         auto r_in = __builtin_amdgcn_make_buffer_rsrc((void*)in_g, 0, plane_bytes, 0x00020000);
         int pc = wvu + 4 * k;
         if (pc >= W4_RAW_PIECES) pc -= 4;
+        // (requested with the nt hint the tiles' halo rows are no longer served from L2: DDnet 13.6 -> 14.8 ms, profiles/r05zz_w4_load_nt.txt)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)((char*)dst + 1024 * pc), 16, in_off[k], 0, 0, 0);
 #endif
     };

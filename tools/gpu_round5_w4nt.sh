@@ -3,7 +3,7 @@
 # network iterations (one python process per row: DDnet, FastDVDnet, the headline FFDNet pass, the 256x256x16 tile)
 set -u
 cd $GRAFT_REPO_ROOT
-for v in product w4nt; do
+for v in ${VARIANTS:-product w4nt}; do
   unset SCIPNP_LIB
   [ $v != product ] && export SCIPNP_LIB=$GRAFT_REPO_ROOT/build/variants/libscipnp_$v.so
   echo "== $v"
