@@ -130,7 +130,12 @@ __device__ __forceinline__ void split_store16(float v0, float v1, float v2, floa
     const auto r0 = __builtin_amdgcn_permlane32_swap(hu.u[0], lu.u[0], false, false);
     const auto r1 = __builtin_amdgcn_permlane32_swap(hu.u[1], lu.u[1], false, false);
     // lanes < 32: (r[0], r[1]) = (own hi, partner's hi);  lanes >= 32: (partner's lo', own lo')
+#ifdef CS_STORE_NT                                    /* variant build (make csvariant): the c8s stores with the nt hint */
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((u4v){r0[0], r1[0], r0[1], r1[1]}, (u4v*)dst);
+#else
     *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+#endif
 #endif
 }
 
