@@ -523,12 +523,18 @@ conv3x3_c8w4_kernel(const Wino4Args a) {
                     // with nt), at 100 MB per launch it is even, larger outputs leave faster without allocating (1024x1024x8: 10.53
                     // -> 10.34 ms; DDnet 13.81 -> 13.56 ms, FastDVDnet 5.50 -> 5.43 ms; profiles/r05zz_w4nt_*).  The entry point
                     // sets W4_FLAG_NT for launches whose output is 128 MB or more; DIAG bits 10 / 11 force nt / sc1 (laboratory).
-#ifdef W4_STORE_NT                                   /* variant build: every whole-line store with the nt hint */
+#if defined(W4_STORE_AUX)                            /* variant build (make w4variant W4FLAGS=-DW4_STORE_AUX=n): cache-policy bits of every whole-line store */
+                    constexpr int AUX = W4_STORE_AUX;
+#elif defined(W4_STORE_NT)                           /* variant build: every whole-line store with the nt hint */
                     constexpr int AUX = 2;
 #else
                     constexpr int AUX = (DIAG & 1024) ? 2 : (DIAG & 2048) ? 16 : 0;
 #endif
+#if defined(W4_STORE_AUX)
+                    if (false) {
+#else
                     if (AUX == 0 && (a.flags & W4_FLAG_NT)) {            // (workgroup-uniform)
+#endif
 #pragma unroll
                         for (int it = 0; it < 4; ++it)
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), r_out, off[it], 0, 2);
