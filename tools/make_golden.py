@@ -534,6 +534,39 @@ def g_fastdvdlong():
          psnr_all=np.array(res[4]), psnr_frames=np.array(res[2]), noise=noise.astype(np.float64), losses=np.array(trace), **dn)
 
 
+def _full512(name, seed, denoiser, its, sig, net, **kw):
+    """One of the two long driver schedules at BASELINE's full size (512 x 512 x 8), run by the REFERENCE on this container's CPU
+    (tens of minutes with the online finetune event under the reference's global anomaly mode): what is kept is what a free-running
+    solver has to reproduce -- the PSNR of every iteration and the final mosaic -- not the iterates (8 MiB each)."""
+    import time
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=seed)
+    warm = _tv_warm(y, Phi, 40)
+    logf = io.StringIO()
+    seed_all()
+    t0 = time.time()
+    res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, denoiser, its, False, sig, x0_bayer=torch.from_numpy(warm), X_orig=orig,
+                                       model_denoise=net, show_iqa=True, demosaic_method='malvar2004', logf=logf, **kw)
+    print(f'   reference {denoiser} {its} at 512x512x8: {time.time() - t0:.0f} s on {torch.get_num_threads()} threads')
+    assert len(res[4]) == sum(its)
+    save(name, final=np.asarray(res[1], np.float32), psnr_all=np.asarray(res[4], np.float64), psnr_frames=np.asarray(res[2], np.float64),
+         warm_sha=np.frombuffer(__import__('hashlib').sha256(np.ascontiguousarray(warm).tobytes()).digest(), np.uint8),
+         seed=np.array(seed), its=np.array(its), sig=np.array(sig))
+
+
+def g_full512ffd():
+    """configs[1](ii): two_stage_ADMM_Online_FFD_Warm.py:62-76,260-269 -- sigma [25,12,6]/255 x [15,6,4], one finetune event at k = 15"""
+    net, _ = load_ref_ffdnet()
+    _full512('full512_ffdnet_schedule', 2, 'ffdnet_color', [15, 6, 4], [25 / 255, 12 / 255, 6 / 255], net,
+             lr_=2e-6, inital_iter=1, interval_iter=15, update_=True, update_per_iter=2)
+
+
+def g_full512fastdvd():
+    """configs[2]: two_stage_ADMM_Online_FastDVD_Warm.py:68-75,295-304 -- sigma [8/255] x 18, one finetune event at k = 9 (synthetic weights, seed 0)"""
+    rnet, _, _ = _ref_fastdvd(0)
+    _full512('full512_fastdvd_schedule', 9, 'fastdvd_color', [18], [8 / 255], rnet,
+             lr_=2e-6, inital_iter=1, interval_iter=9, update_=True, update_per_iter=2, update_times=1)
+
+
 def g_closedform():
     """close_form_demosaic=True (reference :112-118, :175-182, :224-230): tau = 10, rho = 0.55, closed-form RGB update
     for k > 0 (Malvar only at k = 0); clipped on the FFDNet branch, not on the FastDVDnet branch."""
@@ -713,13 +746,14 @@ def g_logs():
     save('log_text_16x16x4', y=y, Phi=Phi, orig=orig, **out)
 
 
-GROUPS = dict(ddnettune=g_ddnettune, fastdvdlong=g_fastdvdlong, ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
+GROUPS = dict(full512ffd=g_full512ffd, full512fastdvd=g_full512fastdvd, ddnettune=g_ddnettune, fastdvdlong=g_fastdvdlong, ffdgray=g_ffdgray, logs=g_logs, ddnet=g_ddnet, closedform=g_closedform, weights=g_weights, ops=g_ops, bayer=g_bayer, malvar=g_malvar, tv=g_tv, tvadmm=g_tvadmm,
               ffdnet=g_ffdnet, ffdadmm=g_ffdadmm, ffdtune=g_ffdtune, fastdvd=g_fastdvd)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(8)
-    todo = sys.argv[1:] or list(GROUPS)
+    torch.set_num_threads(int(os.environ.get('GOLDEN_THREADS', '8')))
+    # (the two full512* groups take tens of minutes each: by name only)
+    todo = sys.argv[1:] or [g for g in GROUPS if not g.startswith('full512')]
     for g in todo:
         print(f'== {g}')
         GROUPS[g]()
