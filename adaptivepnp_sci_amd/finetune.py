@@ -430,16 +430,20 @@ class _FFDNetTrainer:
             _download_flat(self.flat_p, dsts)
             self._synced = self._mark()
             return
-        if self._host is None:                  # pinned staging + side stream: one per host thread, shared by its trainers
-            key = (self.flat_p.device.index, self.flat_p.numel())
-            pool = getattr(_WB_TLS, 'pool', None)
-            if pool is None:
-                pool = _WB_TLS.pool = {}
-            if key not in pool:
-                pool[key] = [torch.empty(self.flat_p.numel(), dtype=F32, pin_memory=True), torch.cuda.Stream(self.flat_p.device), None]
-            self._pool = pool[key]
-            self._host, self._wb_stream = self._pool[0], self._pool[1]
-        owner = self._pool[2]                    # the staging buffer is shared: whoever used it last has to be done with it
+        # pinned staging + side stream: one per HOST THREAD, shared by the trainers that thread steps.  Looked up on every call (never
+        # cached on the trainer): a trainer first stepped by one lane thread and later by another must not carry the first thread's
+        # buffer along -- two threads would then fill and read one pinned buffer at the same time.
+        if self._wb is not None:                 # (a pending write-back of this trainer, possibly staged in another thread's buffer)
+            self.finish_write_back()
+        key = (self.flat_p.device.index, self.flat_p.numel())
+        pool = getattr(_WB_TLS, 'pool', None)
+        if pool is None:
+            pool = _WB_TLS.pool = {}
+        if key not in pool:
+            pool[key] = [torch.empty(self.flat_p.numel(), dtype=F32, pin_memory=True), torch.cuda.Stream(self.flat_p.device), None]
+        self._pool = pool[key]
+        self._host, self._wb_stream = self._pool[0], self._pool[1]
+        owner = self._pool[2]                    # the staging buffer is shared within the thread: whoever used it last has to be done with it
         if owner is not None and owner is not self:
             owner.finish_write_back()
         self._pool[2] = self

@@ -34,7 +34,10 @@ The record carries
                  micro-benchmarks in the same invocation; `traffic` from rocprofv3
                  --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes) run as child processes of this
                  invocation when rocprofv3 is available, else from the committed profile it names;
-  phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch;
+  phi_step     : HBM roofline of the Phi / Phi^T Phi projection launch on an HBM-RESIDENT state (2048x2048x8, 570 MB per
+                 launch): `frac` is an HBM fraction; the bench's own 36 MB state replays out of the Infinity Cache and is
+                 reported apart (`cache_resident`, `cache_resident_frac`); `frac_rocprof` (here and in `roofline`) = the
+                 same work over the kernel's rocprofv3 --kernel-trace average of a child pass of this run;
   configs      : the other single-GPU BASELINE configurations (ADMM-TV 256x256x8, FastDVDnet 512x512x8,
                  a 256x256x16 tile with the online finetune): ms/iteration, a per-layer-class table of the
                  convolution launches (kernel, launches, us, executed FLOPs, frac) and parity against the CPU
@@ -268,7 +271,7 @@ def compact_line(full, detail_path=None):
     rf = full.get('roofline')
     if rf:
         out['roofline'] = _pick_keys(rf, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch',
-                                          'flop_per_launch', 'avg_launch_ms', 'rocprof_kernel_us', 'launch_shape',
+                                          'flop_per_launch', 'avg_launch_ms', 'rocprof_kernel_us', 'frac_rocprof', 'launch_shape',
                                           'direct_form_equivalent_TFLOPs', 'peak_measured'))
         out['roofline']['traffic'] = rf.get('traffic')
         out['roofline']['kernel'] = str(rf.get('kernel', '')).split(' (')[0]
@@ -276,14 +279,12 @@ def compact_line(full, detail_path=None):
         out['roofline'] = None
     ph = full.get('phi_step')
     if ph:
-        out['phi_step'] = _pick_keys(ph, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch',
-                                          'launch_us', 'host_loop_us', 'rocprof_kernel_us'))
+        out['phi_step'] = _pick_keys(ph, ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_rocprof', 'traffic', 'algorithmic_bytes_per_launch',
+                                          'launch_us', 'rocprof_kernel_us', 'cube', 'cache_resident_frac'))
         out['phi_step']['timing'] = 'hipGraph replay'
         out['phi_step']['kernel'] = str(ph.get('kernel', '')).split(' (')[0]
         if ph.get('non_denoiser_chain'):
             out['phi_step']['chain'] = _pick_keys(ph['non_denoiser_chain'], ('algorithmic_bytes', 'us', 'frac'))
-        if ph.get('large_state'):
-            out['phi_step']['large_state_frac'] = ph['large_state'].get('frac')
     cb = full.get('cpu_baseline')
     if cb:
         out['cpu_baseline'] = _pick_keys(cb, ('value', 'unit', 'cores', 'kind', 'cpu_model', 'value_1_thread'))
@@ -407,7 +408,7 @@ def pmc_traffic(timeout_s=150):
             d = os.path.join(tmp, name)
             r = subprocess.run([exe, '--kernel-trace', '--pmc', name, '--output-format', 'csv', '-d', d, '--',
                                 sys.executable, os.path.join(ROOT, 'tools', 'pmc_probe.py')],
-                               cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE,
+                               cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp', SCIPNP_PMC_PASS='1'), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f'rocprofv3 --pmc {name} exited {r.returncode}: {r.stdout[-300:]}'
@@ -426,8 +427,8 @@ def pmc_traffic(timeout_s=150):
             for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
                 for row in csv.DictReader(open(f)):
                     dur.setdefault(row['Kernel_Name'], []).append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-3)
-            # (the first launch of a kernel includes its code-object load: median, not mean)
-            kernel_us = {k.replace('scipnp::', '').replace('void ', ''): float(np.median(v)) for k, v in dur.items()}
+            # average of the kernel's launches of the measured block (pmc_probe.py: the LAST 60 of each kernel; everything before is preheat)
+            kernel_us = {k.replace('scipnp::', '').replace('void ', ''): float(np.mean(v[-60:] if len(v) > 60 else v[len(v) // 2:])) for k, v in dur.items()}
     except Exception as e:                                  # noqa: BLE001 -- best effort, the bench line says what happened
         return None, f'{type(e).__name__}: {e}'
     finally:
@@ -691,9 +692,13 @@ def roofline_record(prec, body_launch_s, traffic, traffic_src, measured, f32_for
             src = f'committed profile profiles/pmc_traffic.json (live PMC pass unavailable: {traffic_src})'
     flop = body_flop * min(1.0, exec_ratio)                  # the algorithm run: never more than the pipes execute
     achieved = flop / body_launch_s
+    # the same kernel's average duration under rocprofv3 --kernel-trace in a child pass of THIS run (tools/pmc_probe.py: the clocks
+    # preheated with 30+ ms of body launches, then 60 back-to-back launches) -- what profiles/ holds; `frac_rocprof` = executed FLOPs over it
+    rp_us = (_pick(ROCPROF_KERNEL_US, kname.split('<')[0] + '<' + {'conv3x3_c8w4_kernel': '0, 0', 'conv3x3_c8w_kernel': '0, 4', 'conv3x3_c8_kernel': '3, 0', 'conv3x3_c8s_kernel': '3, 0'}.get(kname.split('<')[0], '')) if shape is None else None)
     return {'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+            'frac_rocprof': (flop / (rp_us * 1e-6) / peak) if rp_us else None,
             'traffic': tr, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
-            'rocprof_kernel_us': (_pick(ROCPROF_KERNEL_US, kname.split('<')[0] + '<' + {'conv3x3_c8w4_kernel': '0, 0', 'conv3x3_c8w_kernel': '0, 4', 'conv3x3_c8_kernel': '3, 0', 'conv3x3_c8s_kernel': '3, 0'}.get(kname.split('<')[0], '')) if shape is None else None),
+            'rocprof_kernel_us': rp_us,
             'algorithmic_bytes_per_launch': body_bytes, 'kernel': kname, 'launch_shape': [hs, ws, bs],
             'flop_per_launch': flop, 'avg_launch_ms': body_launch_s * 1e3,
             'direct_form_flop_per_launch': body_flop, 'direct_form_equivalent_TFLOPs': direct_rate / 1e12,
@@ -749,8 +754,6 @@ def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
     xo = torch.empty_like(th)
     ls, ls_host = graph_timed(lambda: ops.pm_project(th, bb, ph, yy, ps, 0, 1.0, 1.0, out=xo), 20)
     lb = 16.0 * Hl * Hl * Bl + 8.0 * Hl * Hl
-    phi_large = {'cube': [Hl, Hl, Bl], 'kernel': 'pm_project_kernel<4,8,0>', 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'host_loop_us': ls_host * 1e6, 'achieved': lb / ls / 1e9,
-                 'unit': 'GB/s', 'frac': lb / ls / PEAK_HBM}
     del th, bb, ph, yy, ps, xo
     # and on the bench's own 512 x 512 x 8 state: 50 launches captured into one hipGraph, the replay between one event pair
     xs = torch.empty_like(run.x)
@@ -777,24 +780,26 @@ def phi_record(run, phi_s, traffic, traffic_src, measured, dev):
     del st, part
     # (the 512x512x8 state is 65536 four-pixel chunks: below the kernel's 4-pixels-per-thread threshold, so it runs one pixel per
     # thread, <VEC=1,MAXB=8,MODE=0>; the 2048x2048x8 state of `large_state` runs <4,8,0> -- the names rocprofv3 shows)
-    return {'bound': 'hbm', 'kernel': 'pm_project_kernel<1,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum)))',
-            'non_denoiser_chain': chain_rec,
-            # primary figure: 50 launches captured into one hipGraph, the replay between one event pair (independent of the host's
-            # launch rate; agrees with the rocprofv3 kernel time in profiles/); `host_loop_us` = the same 50 launches issued by the
-            # host; `in_step` = the event pair around the single launch inside the timed steps
-            'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': b2b * 1e6, 'host_loop_us': b2b_host * 1e6,
-            'timing': 'hipGraph replay of 50 launches',
-            'achieved': phi_bytes / b2b / 1e9, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': phi_bytes / b2b / PEAK_HBM,
-            'in_step': {'launch_us': phi_s * 1e6, 'achieved': phi_bytes / phi_s / 1e9, 'frac': phi_bytes / phi_s / PEAK_HBM,
-                        'note': 'event pair around one ~8 us launch: includes ~2-3 us of event / launch overhead'},
-            'traffic': _pick(traffic, 'pm_project_kernel'), 'traffic_source': traffic_src,
-            # the same kernel's duration in a rocprofv3 --kernel-trace child pass of THIS run (one isolated launch, dispatch ramp and
-            # drain included: what profiles/ shows); `launch_us` is the sustained back-to-back rate, where they overlap
-            'rocprof_kernel_us': _pick(ROCPROF_KERNEL_US, 'pm_project_kernel'),
-            'state_note': 'the 36 MB state of a 512x512x8 cube stays in the 256 MB Infinity Cache between launches: `frac` above the '
-                          'HBM stream rate is cache bandwidth; `large_state` (570 MB per launch) is the HBM figure',
-            'peak_measured': measured.get('hbm_read_GBs'), 'large_state': phi_large,
-            'frac_of_measured_hbm_read_peak': (phi_bytes / b2b / 1e9 / measured['hbm_read_GBs']) if measured.get('hbm_read_GBs') else None}
+    # `frac`, `achieved`, `launch_us`, `algorithmic_bytes_per_launch`: the kernel on an HBM-RESIDENT state (2048x2048x8, 570 MB per launch:
+    # twice the Infinity Cache) -- the figure north_star names; the bench's own 512x512x8 state (36 MB) stays in the Infinity Cache
+    # between launches, its replay rate is cache bandwidth and is reported apart, as `cache_resident`
+    cache_res = {'cube': [H, W, B], 'kernel': 'pm_project_kernel<1,8,0>', 'algorithmic_bytes_per_launch': phi_bytes, 'launch_us': b2b * 1e6,
+                 'host_loop_us': b2b_host * 1e6, 'timing': 'hipGraph replay of 50 launches', 'achieved': phi_bytes / b2b / 1e9, 'unit': 'GB/s',
+                 'frac_of_hbm_peak': phi_bytes / b2b / PEAK_HBM,
+                 'note': 'the 36 MB state of a 512x512x8 cube stays in the 256 MB Infinity Cache between launches: cache bandwidth, not an HBM fraction',
+                 'rocprof_kernel_us': _pick(ROCPROF_KERNEL_US, 'pm_project_kernel<1'),
+                 'in_step': {'launch_us': phi_s * 1e6, 'achieved': phi_bytes / phi_s / 1e9,
+                             'note': 'event pair around one ~8 us launch: includes ~2-3 us of event / launch overhead'}}
+    rp_large = _pick(ROCPROF_KERNEL_US, 'pm_project_kernel<4')
+    return {'bound': 'hbm', 'kernel': 'pm_project_kernel<4,8,0> (p = theta - b/rho; x = p + Phi^T((y - Phi p)/(alpha rho + Phi_sum))) on a 2048x2048x8 state',
+            'cube': [Hl, Hl, Bl], 'algorithmic_bytes_per_launch': lb, 'launch_us': ls * 1e6, 'host_loop_us': ls_host * 1e6,
+            'timing': 'hipGraph replay of 20 launches', 'achieved': lb / ls / 1e9, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': lb / ls / PEAK_HBM,
+            'rocprof_kernel_us': rp_large, 'frac_rocprof': (lb / (rp_large * 1e-6) / PEAK_HBM) if rp_large else None,
+            'traffic': _pick(traffic, 'pm_project_kernel<4'), 'traffic_source': traffic_src,
+            'peak_measured': measured.get('hbm_read_GBs'),
+            'frac_of_measured_hbm_read_peak': (lb / ls / 1e9 / measured['hbm_read_GBs']) if measured.get('hbm_read_GBs') else None,
+            'cache_resident': cache_res, 'cache_resident_frac': phi_bytes / b2b / PEAK_HBM,
+            'non_denoiser_chain': chain_rec}
 
 
 # ------------------------------------------------------------------------------------------------ the other BASELINE configs
@@ -854,9 +859,17 @@ def config_records(ffd_sd, budget_s=60.0):
     run = AdmmRun(y, Phi, 'tv', False, X_orig=orig)
     ms_host = _ms_per_iter(run, 0, 50, 5)
     ms, tv_timing = ms_host, 'host loop of 50 steps between two synchronisations'
+    ms_graph = None
     try:                                                # like phi_step: 50 iterations (100 launches) captured into ONE hipGraph --
-        g_s, _ = graph_timed(lambda: run.step(0), 50)   # the rate the GPU sustains whatever the host's launch rate is
-        ms, tv_timing = g_s * 1e3, 'hipGraph replay of 50 captured iterations, event-timed (host_loop_ms: the same steps issued by the host)'
+        # the rate the GPU sustains whatever the host's launch rate is.  Captured on a THROW-AWAY run (a captured step advances the
+        # run's host-side state without executing: the run object is not usable afterwards)
+        run_t = AdmmRun(y, Phi, 'tv', False, X_orig=orig)
+        for _ in range(5):
+            run_t.step(0)
+        g_s, _ = graph_timed(lambda: run_t.step(0), 50)
+        del run_t
+        ms_graph = g_s * 1e3
+        ms, tv_timing = ms_graph, 'hipGraph replay of 50 captured iterations, event-timed (host_loop_ms: the same steps issued by the host)'
     except Exception as e:                              # (capture refused: keep the host loop's figure)
         tv_timing += f'; hipGraph capture failed: {type(e).__name__}'
     E = 256 * 256 * 8
@@ -866,7 +879,10 @@ def config_records(ffd_sd, budget_s=60.0):
     o = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [3], [0], X_orig=orig)
     out['admm_tv_256'] = {
         'workload': 'configs[0]: ADMM-TV (one-stage, Chambolle 5 inner iterations), 256x256x8, per-iteration PSNR on device',
-        'dtype': 'f32', 'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'host_loop_ms': ms_host, 'timing': tv_timing,
+        # (keys since round 5: `ms_per_iteration` = the hipGraph-replay figure when a capture succeeded, else the host loop's; both are
+        # always present under their own names)
+        'dtype': 'f32', 'ms_per_iteration': ms, 'iterations_per_s': 1e3 / ms, 'host_loop_ms': ms_host, 'graph_replay_ms': ms_graph,
+        'timing': tv_timing,
         'dominant_kernel': 'tv_band_kernel (all 5 Chambolle iterations of a 128x128 plane in one launch of 8 workgroups per plane: 16-row bands with a 4-row halo)',
         'bound': 'hbm (launch/VALU-latency limited at this size)', 'algorithmic_bytes_per_iteration': tv_bytes,
         'achieved_GBs': tv_bytes / (ms * 1e-3) / 1e9, 'frac': tv_bytes / (ms * 1e-3) / PEAK_HBM,

@@ -13,7 +13,7 @@
 // BIT-IDENTICAL results (tests/test_gpu_ops.py).  Weights: scipnp_repack_wino4n re-lays the F(4x4) packing into 16-channel slabs.
 #include "wino4_common.hpp"
 #ifdef SCIPNP_DIAG_BUILD
-#include "../../include/scipnp_diag.h"
+#include "../scipnp_lab.h"
 
 namespace scipnp {
 

@@ -433,7 +433,7 @@ static int wp_fill_args(Wino4Args& a, const float* in, const float* packed_wino4
 extern "C" {
 
 #ifdef SCIPNP_DIAG_BUILD   /* LABORATORY only (libscipnp_diag.so): measured at parity with conv_wino4.hip inside a network pass */
-#include "../../include/scipnp_diag.h"
+#include "../scipnp_lab.h"
 /* stamped instantiation: slots in the header comment of the kernel's WP_STAMP uses -- wave 0 (a consumer): [0] entry,
  * [1] P2 passed, [8 + 2s] MFMAs of k-step s issued, [9 + 2s] its barrier passed, [3] loop left, [4] first image written, [5] stores
  * issued, [6] acknowledged, [7] XCC_ID << 32 | HW_ID; wave 8 (a producer): [56] P1 passed, [57] P2 passed, [64 + 2s] work of k-step

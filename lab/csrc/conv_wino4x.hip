@@ -27,7 +27,7 @@
 // thirds A and B leave their (s, d) in LDS; A finishes output row 1, B row 2, C rows 0 and 3.
 #include "wino4_common.hpp"
 #ifdef SCIPNP_DIAG_BUILD
-#include "../../include/scipnp_diag.h"
+#include "../scipnp_lab.h"
 #endif
 
 namespace scipnp {

@@ -30,7 +30,7 @@
 // accumulator comes back after 1, 2 or 4 instructions and at 0.98 from 8 on, whatever the number of waves per SIMD
 // (tools/probes/mfma_dep_probe.py, profiles/r03_mfma_dep.txt).
 #include "common.hpp"
-#include "../../include/scipnp_diag.h"
+#include "../scipnp_lab.h"
 
 namespace scipnp {
 

@@ -6,8 +6,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import ops
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
-import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'lab'))
+import lablib as diaglib  # noqa: E402  (lab/libscipnp_lab.so)
 
 g = torch.Generator().manual_seed(2)
 ok = True

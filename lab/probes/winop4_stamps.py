@@ -7,8 +7,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from adaptivepnp_sci_amd import _lib, ops
-sys.path.insert(0, os.path.join(ROOT, 'tools'))
-import diaglib  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'lab'))
+import lablib as diaglib  # noqa: E402  (lab/libscipnp_lab.so)
 lib = diaglib.load()
 n, c, h, w = (int(v) for v in os.environ.get('WP_SHAPE', '8,64,256,256').split(','))
 g = torch.Generator().manual_seed(0)

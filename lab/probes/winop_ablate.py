@@ -6,8 +6,8 @@ import torch
 os.environ['SCIPNP_WINO_F4'] = '0'                              # classic = the F(2x2) kernel here
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adaptivepnp_sci_amd import _lib, ops
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools'))
-import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'lab'))
+import lablib as diaglib  # noqa: E402  (lab/libscipnp_lab.so)
 lib = diaglib.load()
 n, c, h, w = 8, 96, 256, 256
 g = torch.Generator().manual_seed(0)

@@ -367,6 +367,57 @@ def test_config1_full_reference_schedule_with_online_finetune(solver, ffdnet_sta
     assert np.abs(d_ref).max() > 0 and rel_l2(d_got, d_ref) < 2e-2
 
 
+def _full512_case(name):
+    """inputs of a tests/golden/full512_*.npz run: the synthetic problem of its seed and the oracle's 40-iteration ADMM-TV warm start
+    (what tools/make_golden.py handed the reference; checked against the digest the fixture carries)"""
+    import hashlib
+    from adaptivepnp_sci_amd import synth
+    from oracle import solver as OS
+    g = load_gold(name)
+    y, Phi, orig = synth.make_problem(512, 512, 8, seed=int(g['seed']))
+    warm = OS.one_stage_admm(y, Phi, 1, 0.01, 'tv', [40], [0])['x_bayer']
+    assert hashlib.sha256(np.ascontiguousarray(warm).tobytes()).digest() == bytes(g['warm_sha']), 'warm start differs from the one the reference was given'
+    return g, y, Phi, orig, warm
+
+
+def test_config1_full_schedule_vs_reference_capture(solver, ffdnet_state_dict):
+    """configs[1](ii) at BASELINE's size against THE REFERENCE ITSELF (tests/golden/full512_ffdnet_schedule.npz: captured by
+    tools/make_golden.py full512ffd from the imported reference on CPU): 512x512x8, sigma [25,12,6]/255 x [15,6,4], online
+    finetune lr 2e-6 x 2 steps firing once at k = 15 (two_stage_ADMM_Online_FFD_Warm.py:62-76,260-269) -- the final mosaic
+    within 1e-5 relative L2, the PSNR of every one of the 25 free-running iterations and of every frame within 1e-4 dB"""
+    from adaptivepnp_sci_amd.nets import FFDNet
+    g, y, Phi, orig, warm = _full512_case('full512_ffdnet_schedule')
+    net = FFDNet()
+    net.load_state_dict(ffdnet_state_dict)
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'ffdnet_color', [int(v) for v in g['its']], False, [float(v) for v in g['sig']],
+                                            x0_bayer=warm, X_orig=orig, model_denoise=net, logf=io.StringIO(), lr_=2e-6, inital_iter=1,
+                                            interval_iter=15, update_=True, update_per_iter=2)
+    assert len(res[4]) == 25
+    assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL, np.abs(np.array(res[4]) - g['psnr_all']).max()
+    assert rel_l2(res[1], g['final']) <= REL_TOL, rel_l2(res[1], g['final'])
+    assert np.abs(np.array(res[2]) - g['psnr_frames']).max() <= PSNR_TOL
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_config2_full_schedule_vs_reference_capture(solver, precision, monkeypatch):
+    """configs[2] at BASELINE's size against THE REFERENCE ITSELF (tests/golden/full512_fastdvd_schedule.npz, tools/make_golden.py
+    full512fastdvd): 512x512x8, sigma 8/255 x 18 iterations, rho 0.55, online finetune lr 2e-6 x 2 Adam steps firing once at
+    k = 9, update_times 1 (two_stage_ADMM_Online_FastDVD_Warm.py:68-75,295-304), seeded synthetic weights (model.pth is not in the
+    snapshot) -- final mosaic within 1e-5 relative L2, all 18 PSNR values and the per-frame PSNR within 1e-4 dB"""
+    monkeypatch.setenv('SCIPNP_CONV_PRECISION', precision)
+    from oracle.nets import cpu_data_parallel, synth_fastdvdnet_weights
+    g, y, Phi, orig, warm = _full512_case('full512_fastdvd_schedule')
+    net = cpu_data_parallel(synth_fastdvdnet_weights(0))
+    np.random.seed(42)                                           # worker_init_fn(0) of the reference (utilspy.py:22-25)
+    res = solver.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, 'fastdvd_color', [18], False, [8 / 255], x0_bayer=warm, X_orig=orig,
+                                            model_denoise=net, logf=io.StringIO(), lr_=2e-6, inital_iter=1, interval_iter=9,
+                                            update_=True, update_per_iter=2, update_times=1)
+    assert len(res[4]) == 18
+    assert np.abs(np.array(res[4]) - g['psnr_all']).max() <= PSNR_TOL, np.abs(np.array(res[4]) - g['psnr_all']).max()
+    assert rel_l2(res[1], g['final']) <= REL_TOL, rel_l2(res[1], g['final'])
+    assert np.abs(np.array(res[2]) - g['psnr_frames']).max() <= PSNR_TOL
+
+
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_deep_demosaicking_256x256x8(solver, ffdnet_state_dict, precision, monkeypatch):
     """the reference drivers' default mode (deep_demosaicking=True) at a size with many tiles per layer: DDnet + FFDNet,

@@ -1,6 +1,6 @@
 """ctypes binding of libscipnp_diag.so -- the laboratory beside the product library (include/scipnp_diag.h): MFMA / HBM
-micro-benchmarks, stamped and ablated instantiations of the Winograd kernels, the persistent F(2x2) kernel that was measured and
-not adopted.  Used by bench.py (`measured_peaks`), tools/peaks_bench.py, tools/probes/* and two -m gpu tests; nothing under
+micro-benchmarks, stamped and ablated instantiations of the product's Winograd kernels.  Used by bench.py (`measured_peaks`),
+tools/peaks_bench.py and tools/probes/*; nothing under
 adaptivepnp_sci_amd/ imports this module."""
 import ctypes as C
 import os
@@ -23,21 +23,6 @@ SIGNATURES = {
     'scipnp_bench_stream': (_int, [_vp, _vp, _sz, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_conv3x3_c8w4_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8w6': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_wino4n_packed_floats': (_sz, [_int, _int]),
-    'scipnp_repack_wino4n': (_int, [_vp, _vp, _int, _int, _vp]),
-    'scipnp_conv3x3_c8wn': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8wn_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    'scipnp_conv3x3_c8wn_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8wp': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8wp_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    'scipnp_conv3x3_c8w6_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    'scipnp_conv3x3_c8w6_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p_supported': (_int, [_int, _int]),
-    'scipnp_conv3x3_winop_packed_floats': (_sz, [_int, _int]),
-    'scipnp_pack_conv3x3_winop': (_int, [_vp, _vp, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    'scipnp_conv3x3_c8p_diag': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     'scipnp_conv3x3_c8w_stamped': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     'scipnp_diag_conv3x3_wgrad_wino4': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
 }
@@ -67,81 +52,3 @@ def load():
 
 def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
-
-
-def pack_winop(packed_f32, Cin, Cout):
-    """slab layout of the persistent F(2x2,3x3) kernel from the fp32 direct packing (device buffers); None if unsupported"""
-    import torch
-    lib = load()
-    if not lib.scipnp_conv3x3_c8p_supported(Cin, Cout):
-        return None
-    p = torch.empty(lib.scipnp_conv3x3_winop_packed_floats(Cin, Cout), dtype=torch.float32, device=packed_f32.device)
-    _lib.check(lib.scipnp_pack_conv3x3_winop(_p(packed_f32), _p(p), Cin, Cout, _lib.stream_ptr()), 'scipnp_pack_conv3x3_winop')
-    return p
-
-
-def conv3x3_c8p(x, packed_winop, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
-    """the persistent 96-output-channel F(2x2,3x3) kernel (csrc/conv_winop.hip); arguments as ops.conv3x3_c8w"""
-    import torch
-    n, cg, h, w, _ = x.shape
-    if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
-    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0)
-    _lib.check(load().scipnp_conv3x3_c8p(_p(x), _p(packed_winop), _p(out), _p(residual), _p(mask_src), n, cg * 8, Cout, h, w, flags,
-                                         _lib.stream_ptr()), 'scipnp_conv3x3_c8p')
-    return out
-
-
-def conv3x3_c8w6(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None, head=False):
-    """scipnp_conv3x3_c8w4's convolution on the three-waves-per-SIMD laboratory kernel (csrc/conv_wino4x.hip): same packing,
-    bit-identical results, no PixelShuffle store"""
-    import torch
-    from adaptivepnp_sci_amd import _lib
-    n, cg, h, w, _ = x.shape
-    if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
-    flags = ((1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0) | (0x100 if head else 0))
-    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    _lib.check(load().scipnp_conv3x3_c8w6(P(x), P(packed_wino4), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
-                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8w6')
-    return out
-
-
-def repack_wino4n(packed_wino4, Cin, Cout):
-    """the F(4x4) packing of ops.pack_conv3x3_wino4 re-laid into the 16-channel slabs of scipnp_conv3x3_c8wn"""
-    import torch
-    from adaptivepnp_sci_amd import _lib
-    out = torch.empty(load().scipnp_conv3x3_wino4n_packed_floats(Cin, Cout), dtype=torch.float32, device=packed_wino4.device)
-    _lib.check(load().scipnp_repack_wino4n(C.c_void_p(packed_wino4.data_ptr()), C.c_void_p(out.data_ptr()), Cin, Cout, _lib.stream_ptr()),
-               'scipnp_repack_wino4n')
-    return out
-
-
-def conv3x3_c8wn(x, packed_wino4n, Cout, relu=False, residual=None, mask_src=None, out=None):
-    """scipnp_conv3x3_c8w4's convolution on the 16-channel-workgroup laboratory kernel (csrc/conv_wino4n.hip: three workgroups
-    per CU), weights from repack_wino4n: bit-identical results, no PixelShuffle store"""
-    import torch
-    from adaptivepnp_sci_amd import _lib
-    n, cg, h, w, _ = x.shape
-    if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
-    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0)
-    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    _lib.check(load().scipnp_conv3x3_c8wn(P(x), P(packed_wino4n), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
-                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8wn')
-    return out
-
-
-def conv3x3_c8wp(x, packed_wino4, Cout, relu=False, residual=None, mask_src=None, out=None):
-    """scipnp_conv3x3_c8w4's convolution for Cout % 64 == 0 on the producer / consumer laboratory kernel (csrc/conv_wino4p.hip):
-    same packing, bit-identical results; stride 1, plain store"""
-    import torch
-    from adaptivepnp_sci_amd import _lib
-    n, cg, h, w, _ = x.shape
-    if out is None:
-        out = torch.empty(n, Cout // 8, h, w, 8, device=x.device, dtype=torch.float32)
-    flags = (1 if relu else 0) | (2 if residual is not None else 0) | (16 if mask_src is not None else 0)
-    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    _lib.check(load().scipnp_conv3x3_c8wp(P(x), P(packed_wino4), P(out), P(residual), P(mask_src), n, cg * 8, Cout, h, w, flags,
-                                          _lib.stream_ptr()), 'scipnp_conv3x3_c8wp')
-    return out

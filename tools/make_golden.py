@@ -534,7 +534,7 @@ def g_fastdvdlong():
          psnr_all=np.array(res[4]), psnr_frames=np.array(res[2]), noise=noise.astype(np.float64), losses=np.array(trace), **dn)
 
 
-def _full512(name, seed, denoiser, its, sig, net, **kw):
+def _full512(name, seed, denoiser, its, sig, net, onet, **kw):
     """One of the two long driver schedules at BASELINE's full size (512 x 512 x 8), run by the REFERENCE on this container's CPU
     (tens of minutes with the online finetune event under the reference's global anomaly mode): what is kept is what a free-running
     solver has to reproduce -- the PSNR of every iteration and the final mosaic -- not the iterates (8 MiB each)."""
@@ -543,11 +543,22 @@ def _full512(name, seed, denoiser, its, sig, net, **kw):
     warm = _tv_warm(y, Phi, 40)
     logf = io.StringIO()
     seed_all()
+    st = np.random.get_state()
     t0 = time.time()
     res = R.twoStageAdmm_denoise_bayer(y, Phi, 1, 0.01, denoiser, its, False, sig, x0_bayer=torch.from_numpy(warm), X_orig=orig,
                                        model_denoise=net, show_iqa=True, demosaic_method='malvar2004', logf=logf, **kw)
     print(f'   reference {denoiser} {its} at 512x512x8: {time.time() - t0:.0f} s on {torch.get_num_threads()} threads')
     assert len(res[4]) == sum(its)
+    # the oracle restatement, free-running over the same schedule from the same RNG state: final mosaic and every PSNR
+    np.random.set_state(st)
+    t0 = time.time()
+    okw = dict(lr=kw['lr_'], inital_iter=kw['inital_iter'], interval_iter=kw['interval_iter'], update=True, update_per_iter=kw['update_per_iter'])
+    if 'update_times' in kw:
+        okw['update_times'] = kw['update_times']
+    o = OS.two_stage_admm(y, Phi, denoiser, its, sig, x0_bayer=warm, X_orig=orig, model_denoise=onet, **okw)
+    print(f'   oracle {denoiser} {its} at 512x512x8: {time.time() - t0:.0f} s')
+    check(f'{name}: final mosaic', o['x_bayer'], res[1], tol=float(os.environ.get('FULL512_TOL', '0')))
+    check(f'{name}: PSNR of every iteration', np.array(o['psnr_all']), np.array(res[4]), tol=float(os.environ.get('FULL512_TOL', '0')))
     save(name, final=np.asarray(res[1], np.float32), psnr_all=np.asarray(res[4], np.float64), psnr_frames=np.asarray(res[2], np.float64),
          warm_sha=np.frombuffer(__import__('hashlib').sha256(np.ascontiguousarray(warm).tobytes()).digest(), np.uint8),
          seed=np.array(seed), its=np.array(its), sig=np.array(sig))
@@ -555,15 +566,15 @@ def _full512(name, seed, denoiser, its, sig, net, **kw):
 
 def g_full512ffd():
     """configs[1](ii): two_stage_ADMM_Online_FFD_Warm.py:62-76,260-269 -- sigma [25,12,6]/255 x [15,6,4], one finetune event at k = 15"""
-    net, _ = load_ref_ffdnet()
-    _full512('full512_ffdnet_schedule', 2, 'ffdnet_color', [15, 6, 4], [25 / 255, 12 / 255, 6 / 255], net,
+    net, sd = load_ref_ffdnet()
+    _full512('full512_ffdnet_schedule', 2, 'ffdnet_color', [15, 6, 4], [25 / 255, 12 / 255, 6 / 255], net, oracle_ffdnet(sd),
              lr_=2e-6, inital_iter=1, interval_iter=15, update_=True, update_per_iter=2)
 
 
 def g_full512fastdvd():
     """configs[2]: two_stage_ADMM_Online_FastDVD_Warm.py:68-75,295-304 -- sigma [8/255] x 18, one finetune event at k = 9 (synthetic weights, seed 0)"""
-    rnet, _, _ = _ref_fastdvd(0)
-    _full512('full512_fastdvd_schedule', 9, 'fastdvd_color', [18], [8 / 255], rnet,
+    rnet, onet, _ = _ref_fastdvd(0)
+    _full512('full512_fastdvd_schedule', 9, 'fastdvd_color', [18], [8 / 255], rnet, onet,
              lr_=2e-6, inital_iter=1, interval_iter=9, update_=True, update_per_iter=2, update_times=1)
 
 
