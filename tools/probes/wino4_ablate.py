@@ -19,10 +19,14 @@ NAMES = {1: 'no transform', 2: 'no raw staging', 4: 'no U LDS-DMA', 8: 'no barri
          128: 'matrix work as v_mfma_f32_32x32x2_f32 on the same registers', 256: 'raw requests of 1 KB contiguous memory', 512: 'output stores of 1 KB contiguous memory', 1024: 'stores with the nt hint (isolated layer only: see conv_wino4.hip)', 2048: 'stores with the sc1 hint', 4096: 'classic per-lane store epilogue (correct results)'}
 
 
-KER = os.environ.get('W4_KERNEL', '4')     # '6': scipnp_conv3x3_c8w6_diag (masks 1, 2, 4, 8, 16, 6, 7, 15, 48, 49)
-diag_fn = lib.scipnp_conv3x3_c8w6_diag if KER == '6' else lib.scipnp_conv3x3_c8wn_diag if KER == 'n' else lib.scipnp_conv3x3_c8w4_diag
+KER = os.environ.get('W4_KERNEL', '4')     # '6' / 'n': the not-adopted kernels of lab/ (needs `make -C lab`; masks 1, 2, 4, 8, 16, 6, 7, 15, 48, 49)
+lablib = None
+if KER in ('6', 'n') or os.environ.get('W4_WITH_LAB') == '1':
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'lab'))
+    import lablib  # noqa: E402
+diag_fn = lablib.load().scipnp_conv3x3_c8w6_diag if KER == '6' else lablib.load().scipnp_conv3x3_c8wn_diag if KER == 'n' else lib.scipnp_conv3x3_c8w4_diag
 if KER == 'n':
-    p4 = diaglib.repack_wino4n(p4, c, c)
+    p4 = lablib.repack_wino4n(p4, c, c)
 
 
 def run(diag):
@@ -47,9 +51,10 @@ def timed(fn, reps=5, inner=20):
 print(f'F(2x2) kernel               {timed(lambda: ops.conv3x3_c8w(x8, p2, c, relu=True, out=out)):7.1f} us')
 p4_32 = ops.pack_conv3x3_wino4(pk, c, c)
 print(f'F(4x4) kernel (product)     {timed(lambda: ops.conv3x3_c8w4(x8, p4_32, c, relu=True, out=out)):7.1f} us')
-print(f'F(4x4) 12-wave workgroups   {timed(lambda: diaglib.conv3x3_c8w6(x8, p4_32, c, relu=True, out=out)):7.1f} us')
-pn_ = diaglib.repack_wino4n(p4_32, c, c)
-print(f'F(4x4) 16-co, 3 WGs per CU  {timed(lambda: diaglib.conv3x3_c8wn(x8, pn_, c, relu=True, out=out)):7.1f} us')
+if lablib is not None:
+    print(f'F(4x4) 12-wave workgroups   {timed(lambda: lablib.conv3x3_c8w6(x8, p4_32, c, relu=True, out=out)):7.1f} us')
+    pn_ = lablib.repack_wino4n(p4_32, c, c)
+    print(f'F(4x4) 16-co, 3 WGs per CU  {timed(lambda: lablib.conv3x3_c8wn(x8, pn_, c, relu=True, out=out)):7.1f} us')
 print('ablations of scipnp_conv3x3_c8w' + KER)
 MASKS = [int(v) for v in os.environ['W4_MASKS'].split(',')] if os.environ.get('W4_MASKS') else \
     (1, 2, 4, 8, 16, 32, 3, 5, 9, 10, 12, 14, 6, 7, 15, 39, 47, 48, 49, 55, 63, 128)

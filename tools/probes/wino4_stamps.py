@@ -19,10 +19,16 @@ out, ref = torch.empty_like(x8), torch.empty_like(x8)
 nwg = (w // 64) * (h // (16 if os.environ.get('W4_KERNEL', '4') == '6' else 8)) * n * (c // 32)
 st = torch.zeros(nwg * 128, dtype=torch.int64, device='cuda')
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KER = os.environ.get('W4_KERNEL', '4')            # '6': the three-waves-per-SIMD kernel (scipnp_conv3x3_c8w6_stamped; masks 0, 1, 6, 7)
-stamped = lib.scipnp_conv3x3_c8w6_stamped if KER == '6' else lib.scipnp_conv3x3_c8wn_stamped if KER == 'n' else lib.scipnp_conv3x3_c8w4_stamped
+if KER in ('6', 'n'):                                        # the not-adopted kernels of lab/ (needs `make -C lab`)
+    sys.path.insert(0, os.path.join(ROOT, 'lab'))
+    import lablib  # noqa: E402
+    stamped = lablib.load().scipnp_conv3x3_c8w6_stamped if KER == '6' else lablib.load().scipnp_conv3x3_c8wn_stamped
+else:
+    stamped = lib.scipnp_conv3x3_c8w4_stamped
 if KER == 'n':                                          # 16-channel workgroups: re-laid weights, twice the workgroups
-    p4w = diaglib.repack_wino4n(p4, c, c)
+    p4w = lablib.repack_wino4n(p4, c, c)
     st = torch.zeros(2 * nwg * 128, dtype=torch.int64, device='cuda')
     nwg *= 2
 else:

@@ -5,7 +5,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptivepnp_sci_amd import ops
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import diaglib  # noqa: E402  (the persistent F(2x2) kernel lives in libscipnp_diag.so)
 
 n, c, h, w = 8, 96, 256, 256
 flop = 2.0 * 9 * c * c * h * w * n
@@ -16,14 +15,12 @@ b = torch.randn(c, generator=g)
 x8 = ops.to_c8(x)
 pk = ops.pack_conv3x3(wt, b, Cin=c, Cout=c, device='cuda')
 pw = ops.pack_conv3x3_wino(pk, c, c)
-pwinop = diaglib.pack_winop(pk, c, c)
 p4 = ops.pack_conv3x3_wino4(pk, c, c)
 o84 = torch.empty_like(x8)
 o8, o8w, o8v, o8p = torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8), torch.empty_like(x8)
 variants = {'fp32 direct': lambda: ops.conv3x3_c8(x8, pk, c, relu=True, out=o8),
             'fp32 winograd': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8w),
             'fp32 wino 16row': lambda: ops.conv3x3_c8w(x8, pw, c, relu=True, out=o8v, rows16=True),
-            'fp32 wino persist': lambda: diaglib.conv3x3_c8p(x8, pwinop, c, relu=True, out=o8p),
             'fp32 wino F(4x4)': lambda: ops.conv3x3_c8w4(x8, p4, c, relu=True, out=o84)}
 for f in variants.values():
     for _ in range(3):
