@@ -11,12 +11,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
 import diaglib  # noqa: E402  (libscipnp_diag.so: the laboratory entries)
 lib = diaglib.load()
 n, c, h, w = 8, 96, 256, 256
+if os.environ.get('W4_SHAPE'):                      # 'n,cin,cout,h,w' -- e.g. the narrow layers: 8,16,96,512,512 (FastDVDnet inc conv 1)
+    n, c, co_, h, w = (int(v) for v in os.environ['W4_SHAPE'].split(','))
+else:
+    co_ = c
 g = torch.Generator().manual_seed(0)
 x8 = ops.to_c8(torch.randn(n, c, h, w, generator=g).cuda())
-pk = ops.pack_conv3x3(torch.randn(c, c, 3, 3, generator=g) * 0.05, torch.randn(c, generator=g), Cin=c, Cout=c, device='cuda')
-p4 = ops.pack_conv3x3_wino4(pk, c, c)
-out, ref = torch.empty_like(x8), torch.empty_like(x8)
-nwg = (w // 64) * (h // (16 if os.environ.get('W4_KERNEL', '4') == '6' else 8)) * n * (c // 32)
+pk = ops.pack_conv3x3(torch.randn(co_, c, 3, 3, generator=g) * 0.05, torch.randn(co_, generator=g), Cin=c, Cout=co_, device='cuda')
+p4 = ops.pack_conv3x3_wino4(pk, c, co_)
+out = torch.empty(n, (co_ + 7) // 8, h, w, 8, device='cuda')
+ref = torch.empty_like(out)
+nwg = (w // 64) * (h // (16 if os.environ.get('W4_KERNEL', '4') == '6' else 8)) * n * ((co_ + 31) // 32)
 st = torch.zeros(nwg * 128, dtype=torch.int64, device='cuda')
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +33,7 @@ if KER in ('6', 'n'):                                        # the not-adopted k
 else:
     stamped = lib.scipnp_conv3x3_c8w4_stamped
 if KER == 'n':                                          # 16-channel workgroups: re-laid weights, twice the workgroups
-    p4w = lablib.repack_wino4n(p4, c, c)
+    p4w = lablib.repack_wino4n(p4, c, co_)
     st = torch.zeros(2 * nwg * 128, dtype=torch.int64, device='cuda')
     nwg *= 2
 else:
@@ -38,13 +43,13 @@ OFF = int(os.environ.get('W4_STAMP_OFF', '0'))       # diag bits 0..2 (no transf
 FL = 1 | (OFF << 12)
 print('parts switched off (diag mask):', OFF)
 for _ in range(3):
-    _lib.check(stamped(P(x8), P(p4w), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
+    _lib.check(stamped(P(x8), P(p4w), P(out), n, c, co_, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-_lib.check(stamped(P(x8), P(p4w), P(out), n, c, c, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
+_lib.check(stamped(P(x8), P(p4w), P(out), n, c, co_, h, w, FL, P(st), _lib.stream_ptr()), 'stamped')
 e1.record()
 torch.cuda.synchronize()
-ops.conv3x3_c8w4(x8, p4, c, relu=True, out=ref)
+ops.conv3x3_c8w4(x8, p4, co_, relu=True, out=ref)
 print('stamped launch', round(e0.elapsed_time(e1) * 1e3, 1), 'us; equals the product kernel:', bool(torch.equal(out, ref)))
 s = st.cpu().numpy().reshape(nwg, 128).astype(np.float64)
 CG = c // 8
