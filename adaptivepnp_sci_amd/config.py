@@ -25,6 +25,9 @@ f32_wgrad      SCIPNP_F32_WGRAD                             'f4' (default: FFDNe
 streams        SCIPNP_STREAMS                               1..8 (default 2): half-batches of a network pass on side streams
 hipgraph       SCIPNP_HIPGRAPH                              False (default) | True: ADMM-TV schedules replayed as a hipGraph
 tv_defer       SCIPNP_TV_DEFER                              True (default: two-launch ADMM-TV iteration) | False
+resident_trainer SCIPNP_RESIDENT_TRAINER                    True (default: an update_=True FFDNet solve builds its finetune trainer with the engine and
+                                                            keeps it -- activation stash, F(4x4) slab workspaces, Adam state: ~1.8 GB per 256x256x16
+                                                            tile, > 3 GB at 512x512x8 -- for the solve's lifetime) | False: built at the event, freed after it
 wgrad_slabs    SCIPNP_WGRAD_SLABS                           None (default: one persistent workgroup per CU) | int
 (SCIPNP_LIB -- another libscipnp.so -- and SCIPNP_KEEP_TORCH_THREADS are process-level switches of _lib.py, not forms.)
 """
@@ -35,7 +38,7 @@ import threading
 from typing import Optional
 
 _ENV = ('SCIPNP_CONV_PRECISION', 'SCIPNP_FFDNET_PRECISION', 'SCIPNP_F32_CONV', 'SCIPNP_WINO_F4', 'SCIPNP_F32_WGRAD', 'SCIPNP_STREAMS',
-        'SCIPNP_HIPGRAPH', 'SCIPNP_TV_DEFER', 'SCIPNP_WGRAD_SLABS')
+        'SCIPNP_HIPGRAPH', 'SCIPNP_TV_DEFER', 'SCIPNP_WGRAD_SLABS', 'SCIPNP_RESIDENT_TRAINER')
 
 
 @dataclasses.dataclass(frozen=True)
@@ -48,6 +51,7 @@ class Config:
     hipgraph: bool = False
     tv_defer: bool = True
     wgrad_slabs: Optional[int] = None
+    resident_trainer: bool = True
 
     def __post_init__(self):
         if self.precision not in ('f32', 'f16x3'):
@@ -75,7 +79,8 @@ class Config:
                    streams=int(e.get('SCIPNP_STREAMS', '2')),
                    hipgraph=e.get('SCIPNP_HIPGRAPH', '0') == '1',
                    tv_defer=e.get('SCIPNP_TV_DEFER', '1') != '0',
-                   wgrad_slabs=int(slabs) if slabs else None)
+                   wgrad_slabs=int(slabs) if slabs else None,
+                   resident_trainer=e.get('SCIPNP_RESIDENT_TRAINER', '1') != '0')
 
 
 _lock = threading.Lock()
@@ -127,7 +132,9 @@ def use(cfg=None, **fields):
     """In force for this thread inside the block: `cfg` (default: what is in force now) with `fields` replaced.  Field overrides
     given WITHOUT a cfg also reach into the solves stepped inside the block (`with config.use(streams=1): run.step(...)` runs that
     step on one stream although the run keeps its own configuration): explicit field overrides > a solve's configuration > a
-    full configuration of an outer block > the process default."""
+    full configuration of an outer block > the process default.  Exception: a field the solve's constructor was given explicitly
+    (AdmmRun(config=...) pins every field, conv_precision= the precision) stays what the solve was built with -- its buffers and
+    packed weights exist in that form -- unless it is one of SCHEDULING_FIELDS (`streams`), which never change a result."""
     st = getattr(_tls, 'stack', None)
     if cfg is not None:
         base, over = cfg, dict(fields)
@@ -146,9 +153,11 @@ def use(cfg=None, **fields):
 def solve_scope(cfg, pinned=()):
     """the configuration a solve (solver.AdmmRun) was constructed with, for one of its calls: replaces whatever full configuration
     is in force and keeps the field overrides of enclosing use(**fields) blocks -- except for the fields in `pinned`, which the
-    solve's constructor was given explicitly (config= pins all of them, conv_precision= the precision)"""
+    solve's constructor was given explicitly (config= pins all of them, conv_precision= the precision).  SCHEDULING_FIELDS are
+    never pinned: they say how the launches are issued, not what is computed (`with config.use(streams=1):` around a step of a
+    `config=` run keeps that step on one stream -- solver.PartLanes and bench.single_stream_launch_log rely on it)"""
     st = getattr(_tls, 'stack', None)
-    over = {k: v for k, v in st[-1][1].items() if k not in pinned} if st else {}
+    over = {k: v for k, v in st[-1][1].items() if k not in pinned or k in SCHEDULING_FIELDS} if st else {}
     st = _push(cfg, over)
     try:
         yield st[-1][2]
@@ -157,6 +166,7 @@ def solve_scope(cfg, pinned=()):
 
 
 FIELDS = tuple(f.name for f in dataclasses.fields(Config))
+SCHEDULING_FIELDS = ('streams',)
 
 
 # the value of scipnp_twostage_ffdnet_args.conv_form (include/scipnp.h) that names a configuration's arithmetic

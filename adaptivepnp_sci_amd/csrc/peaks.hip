@@ -580,11 +580,22 @@ SCIPNP_BANK_BODY(mfma_bank_kernel_2, SCIPNP_BANK_2)
         "v_add_f32 %0, v0, v63\n"
 SCIPNP_BANK_BODY(mfma_bank_kernel_3, SCIPNP_BANK_3)
 
-// HBM stream: mode 0 read-only (sum into one value per thread), mode 1 copy; grid-stride over float4
+// HBM stream: mode 0 read-only (sum into one value per thread), mode 1 copy, mode 2 write-only (a value made from the index: what a
+// layer that writes many more bytes than it reads is bounded by), mode 3 write-only with the nt hint; grid-stride over float4
 __global__ void __launch_bounds__(256)
 stream_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n4, int mode, float* __restrict__ sink) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     float acc = 0.f;
+    if (mode >= 2) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float f = (float)(unsigned)i;
+            const float4 v = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            if (mode == 3) __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)(out + i));
+            else out[i] = v;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = in[i];
         if (mode) out[i] = v;
@@ -661,7 +672,8 @@ int scipnp_bench_mfma_bank(float* out, unsigned long long* cycles, int blocks, i
     return launch_status("mfma_bank_kernel");
 }
 
-/* mode 0: read n floats of `in` (sink: blocks*256 floats); mode 1: copy n floats in -> out.  n % 4 == 0. */
+/* mode 0: read n floats of `in` (sink: blocks*256 floats); mode 1: copy n floats in -> out; mode 2 / 3: write n floats of `out`
+ * (plain / nt stores; `in` is not read but must be a valid pointer).  n % 4 == 0. */
 int scipnp_bench_stream(const float* in, float* out, size_t n, int mode, int blocks, float* sink, scipnp_stream_t s) {
     SCIPNP_REQUIRE(in && n > 0 && n % 4 == 0 && blocks > 0 && (mode ? out != nullptr : sink != nullptr), "bad arguments");
     SCIPNP_ALIGNED(in);

@@ -205,6 +205,7 @@ __device__ __forceinline__ float tv_lane_next(float v) {      // lane l <- lane 
 // (0, 2^-60) below TVB_GUARD
 constexpr unsigned TVB_GUARD = (0x21800000u << 1) - 1u;      // bits(2^-60) = 0x21800000
 __device__ __forceinline__ unsigned tv_guard_word(float f) { return (__builtin_bit_cast(unsigned, f) << 1) - 1u; }
+constexpr unsigned TVB_BIG = 0x71800000u + TVB_GUARD;     // bits(2^100) = 0x71800000; big <= 0x7FFFFFFF: no wrap-around
 
 // the p-update of R pixels of one thread: g[k] = (g0, g1), pz[k] = (p0, p1) in, pz out; nrm[k] out; returns the guard word
 template <int R>
@@ -221,11 +222,17 @@ __device__ __forceinline__ unsigned tv_p_update_fast(const tv_f2 (&g)[R], tv_f2 
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) s[k] = __builtin_amdgcn_sqrtf(x[k]);
+    unsigned big = 0u;                       // largest gradient energy of the thread's pixels (x >= 0: the bit pattern is monotonic)
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const unsigned a = tv_guard_word(x[k]), b = tv_guard_word(num[k].x), c = tv_guard_word(num[k].y);
         guard = min(guard, min(a, min(b, c)));
+        big = max(big, __builtin_bit_cast(unsigned, x[k]));
     }
+    // upper side: an energy above 2^100 (unnormalised input of ~1e15 and more; infinities and NaNs of an overflowed g*g included)
+    // would put the denominator where v_rcp_f32 returns a denormal or zero and the refinement makes NaNs of what the IEEE division
+    // rounds to zero -- such a wave takes the general path too: TVB_BIG - big drops below TVB_GUARD exactly when big > bits(2^100)
+    guard = min(guard, TVB_BIG - big);
 #pragma unroll
     for (int k = 0; k < R; ++k) {            // v_sqrt_f32 is within 1 ulp: pick among s - 1 ulp, s, s + 1 ulp by the sign of the residuals
         const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s[k]) - 1);

@@ -240,7 +240,8 @@ class AdmmRun:
             with ops.overflow_scope(self.ovf_word):
                 if denoiser == 'ffdnet_color':
                     self.eng = FFDNetEngine(model, B, M, N, self.device, precision=conv_precision)
-                    if getattr(self, 'update_', False) and getattr(self, 'U', 1) == 1 and getattr(self, 'update_per_iter', 0) > 0:
+                    if (getattr(self, 'update_', False) and getattr(self, 'U', 1) == 1 and getattr(self, 'update_per_iter', 0) > 0
+                            and config.current().resident_trainer):
                         # the online finetune's trainer (device master weights, activation stash, workspaces) is built with the
                         # engine, like every other buffer of the solve; an event reuses it (finetune._FFDNetTrainer.reuse)
                         from .finetune import _FFDNetTrainer
@@ -373,6 +374,8 @@ class AdmmRun:
             self.out_rgb = self.out_store if src_c8 is not None else src_rgb
         if pending is not None and hasattr(pending, 'finish_write_back'):
             pending.finish_write_back()         # the event's losses are printed and the module receives the updated weights once
+            if not config.current().resident_trainer and getattr(self.eng, '_ft_trainer', None) is pending:
+                self.eng._ft_trainer = None         # (opt-out: the trainer's ~GBs live for the event only; the engine keeps its own packs)
                                                 # everything of this iteration is enqueued: both travelled beside the evaluation pass
 
     def _deep_demosaic(self, b_in, inv_rho):
@@ -827,7 +830,7 @@ def _run_schedule(run, sigma, iter_max, log=None):
     """the iterations of one solver call; `log`: _LogStream (lines stream out during the loop) or None"""
     total = sum(iter_max)
     if (run.denoiser == 'tv' and total >= 4 and ITERATE_HOOK is None and run.phi_events is None
-            and config.current().hipgraph):
+            and (run.config.hipgraph if 'hipgraph' in getattr(run, '_pinned', ()) else config.current().hipgraph)):
         _run_tv_graphed(run, total)
         if log is not None:                              # graph replay: the values exist only after the replays
             k = 0

@@ -59,7 +59,10 @@ def test_a_solves_configuration_field_overrides_and_pins():
         with config.solve_scope(run_cfg, pinned=('precision',)):
             assert (config.current().precision, config.current().streams) == ('f16x3', 1)
         with config.solve_scope(run_cfg, pinned=config.FIELDS):
-            assert config.current() == run_cfg
+            # config= pins every field that says WHAT is computed; the scheduling fields (streams) stay overridable: PartLanes and
+            # bench.single_stream_launch_log wrap steps of such runs in use(streams=1)
+            assert config.current() == run_cfg.replace(streams=1)
+            assert config.current().precision == 'f16x3'
         with config.use(config.Config(hipgraph=True)):                # a full configuration resets the field overrides
             assert config.current().streams == 2 and config.current().hipgraph
     assert config.conv_form(config.Config(precision='f16x3')) == 1 and config.conv_form(config.Config(wino_f4=False)) == 2 \

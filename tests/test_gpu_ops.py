@@ -1275,7 +1275,9 @@ def test_tv_banded_kernel_tiny_operands_take_the_general_path(ops):
     which only uses sqrtf and '/'"""
     rng = np.random.default_rng(2025)
     M, N = 70, 128
-    scales = [1.0, 1e-9, 1e-15, 1e-20, 1e-25, 1e-32, 1e-38, 3e-42, 0.0]
+    # (... and on the upper side, round 6: gradient energies above 2^100 -- amplitudes of 1e16 and more --
+    # take the general path as well: the hand-expanded division would make NaNs where the IEEE one rounds to zero)
+    scales = [1.0, 1e-9, 1e-15, 1e-20, 1e-25, 1e-32, 1e-38, 3e-42, 0.0, 1e12, 1e16, 1e18]
     base = rng.uniform(0, 1, (len(scales) + 3, M, N)).astype(np.float32)
     for c, sc in enumerate(scales):
         base[c] *= np.float32(sc)

@@ -41,5 +41,9 @@ t = timed(lambda: _lib.check(lib.scipnp_bench_stream(p(a), None, n, 0, blocks, p
 res['hbm_read_GBs'] = 4 * n / t / 1e9
 t = timed(lambda: _lib.check(lib.scipnp_bench_stream(p(a), p(b), n, 1, blocks, None, st()), 'stream'))
 res['hbm_copy_GBs_read_plus_write'] = 8 * n / t / 1e9
+t = timed(lambda: _lib.check(lib.scipnp_bench_stream(p(a), p(b), n, 2, blocks, None, st()), 'stream'))
+res['hbm_write_GBs'] = 4 * n / t / 1e9
+t = timed(lambda: _lib.check(lib.scipnp_bench_stream(p(a), p(b), n, 3, blocks, None, st()), 'stream'))
+res['hbm_write_nt_GBs'] = 4 * n / t / 1e9
 res['device'] = torch.cuda.get_device_name(0)
 print(json.dumps(res, indent=1))
