@@ -996,6 +996,16 @@ int scipnp_conv3x3_c8w4_diag(const float* in, const float* packed_wino4, float* 
         hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 0, false, false, false>), grid, block, W4_LDS_BYTES, (hipStream_t)s, a);
         return launch_status("conv3x3_c8w4_kernel<classic stores>");
     }
+    if (diag == 8192 || diag == 8193) {                     // the persistent form (PERSIST = true; results unchanged): 2 (8192) or 1 (8193) workgroups per CU walk the units
+        static LdsAttrOnce attr;
+        if (int rc = attr.ensure((const void*)conv3x3_c8w4_kernel<0, 0, false, true>, (size_t)160 * 1024, "conv3x3_c8w4 persistent")) return rc;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned per = diag == 8192 ? 2u : 1u;
+        const unsigned g = (unsigned)std::min<long long>(total, (long long)per * cus);
+        hipLaunchKernelGGL((conv3x3_c8w4_kernel<0, 0, false, true>), dim3(g), block, per == 1 ? (size_t)160 * 1024 : W4_LDS_BYTES, (hipStream_t)s, a);
+        return launch_status("conv3x3_c8w4_kernel<persistent>");
+    }
     switch (diag) {
         W4_DIAG_CASE(1) W4_DIAG_CASE(2) W4_DIAG_CASE(4) W4_DIAG_CASE(8) W4_DIAG_CASE(16) W4_DIAG_CASE(32) W4_DIAG_CASE(6)
         W4_DIAG_CASE(7) W4_DIAG_CASE(15) W4_DIAG_CASE(39) W4_DIAG_CASE(47) W4_DIAG_CASE(48) W4_DIAG_CASE(49) W4_DIAG_CASE(55)
