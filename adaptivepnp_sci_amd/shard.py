@@ -167,6 +167,10 @@ def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=
             dist.barrier(group)
         sync()
 
+    import gc
+    gc.collect()                    # (no generation-2 collector pass inside the timed region: a host pause of tens of ms idles the GPU)
+    gc_was = gc.isenabled()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     if batched:
@@ -185,6 +189,8 @@ def timed_job(n_units, prepare, iterate, finish, unit_shape, device, steps, dst=
     t_gather = time.perf_counter() - t0 - t_solve
     barrier()
     total = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     mine_t = torch.tensor([total, t_solve, t_gather, float(len(mine))], dtype=torch.float64, device=device)
     if inited:
         allt = [torch.empty_like(mine_t) for _ in range(world)]

@@ -48,6 +48,7 @@ The record carries
 """
 import argparse
 import contextlib
+import gc
 import io
 import json
 import os
@@ -600,6 +601,11 @@ def time_precision(prec, args, ctx):
     from adaptivepnp_sci_amd import ops as _ops
     side = run.eng.precision == 'f16x3' and _ops.side_stream_count() > 1
     run.profile_events, run.phi_events = (None if side else events), phi_events
+    # the host runs only a few launches ahead of the GPU: one long host pause inside the timed region (a generation-2 pass of the cyclic
+    # garbage collector over everything torch / numpy have imported takes tens of ms) would drain the queue and idle the GPU for as long.
+    # The collector is run NOW and held off until the region ends -- nothing the steps allocate is cyclic.
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -612,6 +618,7 @@ def time_precision(prec, args, ctx):
         n_gathered = len(gathered) if rank == 0 else 0
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
