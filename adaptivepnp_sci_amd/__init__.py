@@ -14,4 +14,4 @@ from .ddnet import DDnet  # noqa: F401
 from .fastdvd import FastDVDnet  # noqa: F401
 from .nets import FFDNet  # noqa: F401
 
-__version__ = '0.5.0'
+__version__ = '0.6.0'

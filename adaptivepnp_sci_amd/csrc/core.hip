@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace scipnp
 
 extern "C" {
-const char* scipnp_version(void) { return "scipnp 0.5.0 (round 5)"; }
+const char* scipnp_version(void) { return "scipnp 0.6.0 (round 6)"; }
 const char* scipnp_last_error(void) { return scipnp::g_err; }
 const char* scipnp_arch(void) { return "gfx950"; }
 }

@@ -309,7 +309,23 @@ template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<4> { using type = float4; };
 
-template <int VEC, int MAXB, int MODE>  // MODE 0 two-stage, 1 one-stage, 2 setup (Phi_sum, x0 = y*Phi)
+// the projection's streamed operands (theta, b, Phi: read once per launch).  NT: non-temporal loads -- on a state far larger than the 256 MB
+// Infinity Cache (2048 x 2048 x 8: 570 MB per launch) the launch takes 94-96 us instead of 119 (6.0 against 4.8 TB/s,
+// profiles/r06k_proj_stream.txt); on states the cache holds (<= 285 MB per launch, launches back to back) plain loads are 4-25 % faster,
+// and non-temporal STORES of x lose at every size -- so the entry point asks for NT only above PROJ_NT_BYTES per launch.
+constexpr double PROJ_NT_BYTES = 384e6;
+template <typename V, bool NT>
+__device__ __forceinline__ V proj_ld(const float* p) {
+    if constexpr (NT && sizeof(V) == 16) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t v = __builtin_nontemporal_load((const f4_t*)p);
+        return __builtin_bit_cast(V, v);
+    } else {
+        return *(const V*)p;
+    }
+}
+
+template <int VEC, int MAXB, int MODE, bool NT = false>  // MODE 0 two-stage, 1 one-stage, 2 setup (Phi_sum, x0 = y*Phi)
 __global__ void __launch_bounds__(256)
 pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
                   const float* __restrict__ Phi, const float* __restrict__ y,
@@ -323,14 +339,14 @@ pm_project_kernel(const float* __restrict__ theta, const float* __restrict__ bb,
     for (int t = 0; t < MAXB; ++t) {
         if (t < B) {
             const size_t o = (size_t)t * Q + q;
-            V phv = *(const V*)(Phi + o);
+            V phv = proj_ld<V, NT>(Phi + o);
             const float* php = (const float*)&phv;
             if (MODE == 2) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) { ph[t][v] = php[v]; p[t][v] = php[v]; }
             } else {
-                V thv = *(const V*)(theta + o);
-                V bv = *(const V*)(bb + o);
+                V thv = proj_ld<V, NT>(theta + o);
+                V bv = proj_ld<V, NT>(bb + o);
                 const float* thp = (const float*)&thv;
                 const float* bp = (const float*)&bv;
 #pragma unroll
@@ -476,13 +492,22 @@ static int launch_pm_project(const float* theta, const float* b, const float* Ph
     // small states (a 256 x 256 mosaic is 64 workgroups of 4-pixel threads on 256 CUs): one pixel per thread -- the loads of
     // a wave stay contiguous, the launch gets four times the workgroups (ADMM-TV 256x256x8: 6.7 -> see profiles/r03d_*)
     const bool wide = Q / 4 >= 512LL * threads;
-    if (vec && wide && B <= 8) SCIPNP_GO(4, 8);
+    // states beyond the Infinity Cache: theta, b, Phi are read once per launch and nothing of them is found again -- non-temporal loads
+    const bool nt = vec && wide && MODE != 2 && 16.0 * (double)Q * B >= PROJ_NT_BYTES;
+#define SCIPNP_GO_NT(VEC, MAXB)                                                                     \
+    hipLaunchKernelGGL((pm_project_kernel<VEC, MAXB, MODE, true>),                                   \
+                       dim3((unsigned)((Q / VEC + threads - 1) / threads)), dim3(threads), 0, st,    \
+                       theta, b, Phi, y, Phisum_in, Phisum_out, x, Q, B, c0, c1)
+    if (nt && B <= 8) SCIPNP_GO_NT(4, 8);
+    else if (nt && B <= 16) SCIPNP_GO_NT(4, 16);
+    else if (vec && wide && B <= 8) SCIPNP_GO(4, 8);
     else if (vec && wide && B <= 16) SCIPNP_GO(4, 16);
     else if (vec && wide) SCIPNP_GO(2, 32);      // 17..32 frames: 2 pixels per thread keep p and Phi in 128 registers
     else if (B <= 8) SCIPNP_GO(1, 8);
     else if (B <= 16) SCIPNP_GO(1, 16);
     else SCIPNP_GO(1, 32);
 #undef SCIPNP_GO
+#undef SCIPNP_GO_NT
     return launch_status("pm_project_kernel");
 }
 

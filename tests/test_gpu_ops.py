@@ -1267,6 +1267,27 @@ def test_tv_banded_kernel_random_shapes(ops):
         assert torch.equal(o1, o3), (M, N, C_, n_iter)
 
 
+def test_projection_on_a_state_beyond_the_infinity_cache_equals_the_small_state_kernel(ops):
+    """round 6: above 384 MB per launch scipnp_pm_project reads theta, b, Phi with non-temporal loads (pm_project_kernel<4, 8, MODE, true>:
+    6.0 instead of 4.8 TB/s on a 2048 x 2048 x 8 state, profiles/r06k_proj_stream.txt) -- the same per-pixel expressions: a unit batch of
+    16 cubes of 512 x 512 x 8 (570 MB per launch, the large-state kernel) gives bit for bit what 16 single-cube launches (one pixel per
+    thread, plain loads) give, in both conventions"""
+    g = torch.Generator().manual_seed(61)
+    U, B, M, N = 16, 8, 256, 256
+    th = torch.rand(B * U, 4, M, N, generator=g).cuda()
+    b = (torch.rand(B * U, 4, M, N, generator=g) - 0.5).cuda()
+    Phi = (torch.rand(B * U, 4, M, N, generator=g) > 0.5).float().cuda()
+    y = (torch.rand(U * 4, M, N, generator=g) * B / 2).cuda()
+    Ps, _ = ops.pm_setup_units(Phi, y, U, want_x0=False)
+    for mode, c0, c1 in ((0, 1 / 0.55, 0.55), (1, 1.0, 0.01)):
+        big = ops.pm_project(th, b, Phi, y, Ps, mode, c0, c1, torch.empty_like(th), units=U)
+        fr = lambda t, u: t.view(B, U, 4, M, N)[:, u].contiguous()       # noqa: E731  (frame f = t * U + u)
+        for u in (0, 7, 15):
+            one = ops.pm_project(fr(th, u), fr(b, u), fr(Phi, u), y.view(U, 4, M, N)[u].contiguous(), Ps.view(U, 4, M, N)[u].contiguous(),
+                                 mode, c0, c1, torch.empty(B, 4, M, N, device='cuda'))
+            assert torch.equal(fr(big, u), one), (mode, u)
+
+
 def test_tv_banded_kernel_tiny_operands_take_the_general_path(ops):
     """round 5: the banded kernel writes out sqrt and the two divisions of the dual update itself (csrc/tv.hip tv_p_update_fast:
     v_sqrt + 1-ulp fix-up, one shared reciprocal refinement, no operand scaling) and a wave falls back to the compiler's
