@@ -47,8 +47,10 @@ SIGNATURES = {
                                      C.POINTER(_int), _vp]),
     'scipnp_pm_pre_denoise': (_int, [_vp] * 6 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
     'scipnp_pm_pre_denoise_ex': (_int, [_vp] * 7 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
+    'scipnp_pm_pre_denoise_mosaic': (_int, [_vp] * 7 + [_int, _int, _int, _flt, _flt, _flt, _vp]),
     'scipnp_pm_pre_closed_form': (_int, [_vp] * 8 + [_int, _int, _int, _flt, _flt, _flt, _int, _flt, _vp]),
     'scipnp_pm_post_denoise': (_int, [_vp] * 10 + [_int, _int, _int, _int, C.POINTER(_int), _vp]),
+    'scipnp_pm_post_denoise_mosaic': (_int, [_vp] * 10 + [_int, _int, _int, _int, C.POINTER(_int), _vp]),
     'scipnp_sse_partials': (_int, [_vp, _vp, _sz, _vp, C.POINTER(_int), _vp]),
     'scipnp_conv3x3_packed_floats': (_sz, [_int, _int]),
     'scipnp_pack_conv3x3_weights': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),

@@ -4,6 +4,10 @@
 //       ->  x_rgb, x_rgb - w/tau  ->  planar and/or pixel-unshuffled c8 denoiser input.
 // post: denoised RGB (planar, or FFDNet tail in c8 before pixel-shuffle) -> theta at the CFA sites,
 //       clip, dual updates b and w, optional SSE partials.
+// Round 6: between the two kernels only the MOSAIC has to travel (scipnp_pm_pre_denoise_mosaic / scipnp_pm_post_denoise_mosaic: 4 E bytes
+// written + read instead of the 12 E of x_rgb): the post kernel demosaicks its quad again from the stored mosaic with the same
+// operations (malvar_quad), so w += x_rgb - out sees bit for bit the x_rgb the pre kernel fed to the denoiser.  (It cannot take the
+// mosaic from x and b themselves: it updates b -- and x in the first iteration -- in place, under its neighbours' 5x5 windows.)
 // One thread = one Bayer quad (2x2 mosaic pixels) of one frame; consecutive lanes = consecutive n,
 // so every plane access is a coalesced row segment.  Built with -ffp-contract=off; the 5x5
 // correlations use explicit fmaf chains in row-major tap order.
@@ -44,6 +48,45 @@ __device__ __forceinline__ int reflect_plane(int mm, int d, int M) {
     return r >> 1;  // r keeps parity d
 }
 
+// Malvar-2004 on the quad whose (dy=0,dx=0) pixel is v[2][2]: rgb[c][dy][dx] (malvar2004.py:213-240)
+__device__ __forceinline__ void malvar_quad(const float (&v)[6][6], float (&rgb)[3][2][2]) {
+    // R site (0,0)
+    rgb[0][0][0] = v[2][2];
+    rgb[1][0][0] = corr5<0, 0, false>(v, K_G);
+    rgb[2][0][0] = corr5<0, 0, false>(v, K_DIAG);
+    // G1 site (0,1): red row, blue column
+    rgb[0][0][1] = corr5<0, 1, false>(v, K_ROW);
+    rgb[1][0][1] = v[2][3];
+    rgb[2][0][1] = corr5<0, 1, true>(v, K_ROW);
+    // G2 site (1,0): blue row, red column
+    rgb[0][1][0] = corr5<1, 0, true>(v, K_ROW);
+    rgb[1][1][0] = v[3][2];
+    rgb[2][1][0] = corr5<1, 0, false>(v, K_ROW);
+    // B site (1,1)
+    rgb[0][1][1] = corr5<1, 1, false>(v, K_DIAG);
+    rgb[1][1][1] = corr5<1, 1, false>(v, K_G);
+    rgb[2][1][1] = v[3][3];
+}
+
+// the 6x6 mosaic window of quad (m, n) of one frame from its four planes (plane-major, reflect-101 border); bt != nullptr: the mosaic
+// is x + inv_rho * b, formed here
+__device__ __forceinline__ void load_window(const float* __restrict__ xt, const float* __restrict__ bt, float inv_rho, int M, int N,
+                                            int m, int n, float (&v)[6][6]) {
+    const size_t plane = (size_t)M * N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d_y = i & 1;                 // window row i <-> mosaic row 2m-2+i: parity = i&1
+        const int mm = reflect_plane(m - 1 + (i >> 1), d_y, M);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int d_x = j & 1;
+            const int nn = reflect_plane(n - 1 + (j >> 1), d_x, N);
+            const size_t o = (size_t)(d_y * 2 + d_x) * plane + (size_t)mm * N + nn;
+            v[i][j] = bt ? (xt[o] + inv_rho * bt[o]) : xt[o];
+        }
+    }
+}
+
 // shared tail of the two pre-denoiser kernels: store x_rgb, form x_rgb - inv_tau*w and emit it in the requested
 // layouts (planar rgb_w, fp32 c8 with the pixel-unshuffle + sigma map, split-fp16 c8s)
 __device__ __forceinline__ void emit_pre_outputs(const float (&rgb)[3][2][2], const float* __restrict__ w,
@@ -59,7 +102,7 @@ __device__ __forceinline__ void emit_pre_outputs(const float (&rgb)[3][2][2], co
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const size_t o = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
-            *(float2*)(x_rgb + o) = make_float2(rgb[c][dy][0], rgb[c][dy][1]);
+            if (x_rgb) *(float2*)(x_rgb + o) = make_float2(rgb[c][dy][0], rgb[c][dy][1]);
             float2 wv = make_float2(0.f, 0.f);
             if (w) wv = *(const float2*)(w + o);
             in[c][dy][0] = w ? (rgb[c][dy][0] - inv_tau * wv.x) : rgb[c][dy][0];
@@ -88,7 +131,7 @@ __device__ __forceinline__ void emit_pre_outputs(const float (&rgb)[3][2][2], co
 
 __global__ void __launch_bounds__(256)
 pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
-                      const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ rgb_w,
+                      const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ mosaic_out, float* __restrict__ rgb_w,
                       float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N, int B, float inv_rho,
                       float inv_tau, float sigma) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,40 +139,14 @@ pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
     const int t = blockIdx.z;
     if (n >= N) return;
     const size_t plane = (size_t)M * N;
-    const float* xt = x + (size_t)t * 4 * plane;
-    const float* bt = b ? b + (size_t)t * 4 * plane : nullptr;
     float v[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int d_y = i & 1;                 // window row i <-> mosaic row 2m-2+i: parity = i&1
-        const int mm = reflect_plane(m - 1 + (i >> 1), d_y, M);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int d_x = j & 1;
-            const int nn = reflect_plane(n - 1 + (j >> 1), d_x, N);
-            const size_t o = (size_t)(d_y * 2 + d_x) * plane + (size_t)mm * N + nn;
-            v[i][j] = bt ? (xt[o] + inv_rho * bt[o]) : xt[o];
-        }
+    load_window(x + (size_t)t * 4 * plane, b ? b + (size_t)t * 4 * plane : nullptr, inv_rho, M, N, m, n, v);
+    if (mosaic_out) {                          // the quad's own four mosaic values, plane-major like x
+        float* mo = mosaic_out + (size_t)t * 4 * plane + (size_t)m * N + n;
+        mo[0] = v[2][2]; mo[plane] = v[2][3]; mo[2 * plane] = v[3][2]; mo[3 * plane] = v[3][3];
     }
-    // rgb[c][dy][dx]
     float rgb[3][2][2];
-    // R site (0,0)
-    rgb[0][0][0] = v[2][2];
-    rgb[1][0][0] = corr5<0, 0, false>(v, K_G);
-    rgb[2][0][0] = corr5<0, 0, false>(v, K_DIAG);
-    // G1 site (0,1): red row, blue column
-    rgb[0][0][1] = corr5<0, 1, false>(v, K_ROW);
-    rgb[1][0][1] = v[2][3];
-    rgb[2][0][1] = corr5<0, 1, true>(v, K_ROW);
-    // G2 site (1,0): blue row, red column
-    rgb[0][1][0] = corr5<1, 0, true>(v, K_ROW);
-    rgb[1][1][0] = v[3][2];
-    rgb[2][1][0] = corr5<1, 0, false>(v, K_ROW);
-    // B site (1,1)
-    rgb[0][1][1] = corr5<1, 1, false>(v, K_DIAG);
-    rgb[1][1][1] = corr5<1, 1, false>(v, K_G);
-    rgb[2][1][1] = v[3][3];
-
+    malvar_quad(v, rgb);
     emit_pre_outputs(rgb, w, x_rgb, rgb_w, net_in, net_in_s, M, N, m, n, t, inv_tau, sigma);
 }
 
@@ -198,7 +215,7 @@ constexpr int POST_THREADS = 256;
 __global__ void __launch_bounds__(POST_THREADS)
 pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restrict__ out_c8,
                        float* __restrict__ out_store, float* __restrict__ x,
-                       const float* __restrict__ x_rgb, float* __restrict__ theta, float* __restrict__ b,
+                       const float* __restrict__ x_rgb, const float* __restrict__ mosaic, float* __restrict__ theta, float* __restrict__ b,
                        float* __restrict__ w, const float* __restrict__ orig, double* sse_part,
                        int first_iter_alias, int M, int N, int B) {
     __shared__ double red[16];
@@ -227,6 +244,12 @@ pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restric
                     o[c][dy][0] = q.x; o[c][dy][1] = q.y;
                 }
         }
+        float xm[3][2][2];
+        if (w && mosaic) {                     // x_rgb of this quad again, from the mosaic the pre kernel stored (same operations)
+            float v[6][6];
+            load_window(mosaic + (size_t)t * 4 * plane, nullptr, 0.f, M, N, m, n, v);
+            malvar_quad(v, xm);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -234,7 +257,7 @@ pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restric
                 const size_t off = ((size_t)t * 3 + c) * HW + (size_t)(2 * m + dy) * W + 2 * n;
                 if (out_store) *(float2*)(out_store + off) = make_float2(o[c][dy][0], o[c][dy][1]);
                 if (w) {
-                    const float2 xr = *(const float2*)(x_rgb + off);
+                    const float2 xr = mosaic ? make_float2(xm[c][dy][0], xm[c][dy][1]) : *(const float2*)(x_rgb + off);
                     float2 wv = *(float2*)(w + off);
                     wv.x = wv.x + (xr.x - o[c][dy][0]);
                     wv.y = wv.y + (xr.y - o[c][dy][1]);
@@ -293,7 +316,25 @@ int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, flo
     if (net_in_c8s) SCIPNP_ALIGNED(net_in_c8s);
     const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
     const dim3 grid((N + threads - 1) / threads, M, B);
-    hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, x_rgb, rgb_w,
+    hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, x_rgb, (float*)nullptr, rgb_w,
+                       net_in_c8, (char*)net_in_c8s, M, N, B, inv_rho, inv_tau, sigma);
+    return launch_status("pm_pre_denoise_kernel");
+}
+
+int scipnp_pm_pre_denoise_mosaic(const float* x, const float* b, const float* w, float* mosaic, float* rgb_w,
+                                 float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho, float inv_tau,
+                                 float sigma, scipnp_stream_t s) {
+    SCIPNP_REQUIRE(x && mosaic, "null pointer");
+    SCIPNP_REQUIRE(mosaic != x && mosaic != b, "the mosaic buffer must not alias x or b (its neighbours are still being read)");
+    SCIPNP_REQUIRE(rgb_w || net_in_c8 || net_in_c8s, "no denoiser-input layout requested");
+    SCIPNP_REQUIRE(M >= 2 && N >= 2 && B > 0 && B <= 65535 && M <= 65535, "bad shape M=%d N=%d B=%d", M, N, B);
+    if (w) SCIPNP_ALIGNED(w);
+    if (rgb_w) SCIPNP_ALIGNED(rgb_w);
+    if (net_in_c8) SCIPNP_ALIGNED(net_in_c8);
+    if (net_in_c8s) SCIPNP_ALIGNED(net_in_c8s);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    hipLaunchKernelGGL(pm_pre_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, x, b, w, (float*)nullptr, mosaic, rgb_w,
                        net_in_c8, (char*)net_in_c8s, M, N, B, inv_rho, inv_tau, sigma);
     return launch_status("pm_pre_denoise_kernel");
 }
@@ -344,7 +385,25 @@ int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out
     const dim3 grid((N + threads - 1) / threads, M, B);
     if (nblocks) *nblocks = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(pm_post_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, out_rgb, out_c8,
-                       out_rgb_store, x, x_rgb, theta, b, w, orig, sse_part, first_iter_alias, M, N, B);
+                       out_rgb_store, x, x_rgb, (const float*)nullptr, theta, b, w, orig, sse_part, first_iter_alias, M, N, B);
+    return launch_status("pm_post_denoise_kernel");
+}
+
+int scipnp_pm_post_denoise_mosaic(const float* out_rgb, const float* out_c8, float* out_rgb_store, float* x,
+                                  const float* mosaic, float* theta, float* b, float* w, const float* orig,
+                                  double* sse_part, int first_iter_alias, int M, int N, int B, int* nblocks,
+                                  scipnp_stream_t s) {
+    SCIPNP_REQUIRE((out_rgb != nullptr) != (out_c8 != nullptr), "exactly one of out_rgb / out_c8 must be given");
+    SCIPNP_REQUIRE(x && theta && b && w && mosaic, "null pointer");
+    SCIPNP_REQUIRE(mosaic != x && mosaic != b && mosaic != theta, "the mosaic buffer must not alias the state it helps to update");
+    SCIPNP_REQUIRE((sse_part == nullptr) || (orig != nullptr), "sse_part needs orig");
+    SCIPNP_REQUIRE(M >= 2 && N >= 2 && B > 0 && B <= 65535 && M <= 65535, "bad shape");
+    if (out_c8) SCIPNP_ALIGNED(out_c8);
+    const int threads = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const dim3 grid((N + threads - 1) / threads, M, B);
+    if (nblocks) *nblocks = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(pm_post_denoise_kernel, grid, dim3(threads), 0, (hipStream_t)s, out_rgb, out_c8,
+                       out_rgb_store, x, (const float*)nullptr, mosaic, theta, b, w, orig, sse_part, first_iter_alias, M, N, B);
     return launch_status("pm_post_denoise_kernel");
 }
 

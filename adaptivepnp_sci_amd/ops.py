@@ -206,8 +206,17 @@ def pm_dual_update(theta_raw, x, theta, b, sign, orig=None, sse_part=None, which
     return nb.value
 
 
-def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma, net_in_c8s=None):
+def pm_pre_denoise(x, b, w, x_rgb, rgb_w, net_in_c8, inv_rho, inv_tau, sigma, net_in_c8s=None, mosaic=None):
+    """mosaic (B,4,M,N) given: x_rgb is not stored (pass None) -- the kernel keeps the mosaic x + b/rho it demosaicked instead, for
+    pm_post_denoise(..., mosaic=) to rebuild x_rgb from (a third of the bytes; bit-identical w update)"""
     B, _, M, N = x.shape
+    if mosaic is not None:
+        if x_rgb is not None:
+            raise ValueError('pm_pre_denoise: give x_rgb or mosaic, not both')
+        _call('scipnp_pm_pre_denoise_mosaic', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(mosaic, 'mosaic'), _p(rgb_w, 'rgb_w'),
+              _p(net_in_c8, 'net_in_c8'), _p(net_in_c8s, 'net_in_c8s', torch.float16), M, N, B,
+              float(np.float32(inv_rho)), float(np.float32(inv_tau)), float(np.float32(sigma)), _stream())
+        return
     _call('scipnp_pm_pre_denoise_ex', _p(x, 'x'), _p(b, 'b'), _p(w, 'w'), _p(x_rgb, 'x_rgb'), _p(rgb_w, 'rgb_w'),
           _p(net_in_c8, 'net_in_c8'), _p(net_in_c8s, 'net_in_c8s', torch.float16), M, N, B,
           float(np.float32(inv_rho)), float(np.float32(inv_tau)), float(np.float32(sigma)), _stream())
@@ -230,9 +239,18 @@ def pm_pre_rgb(w, x_rgb, rgb_w, net_in_c8, inv_tau, sigma, net_in_c8s=None):
 
 
 def pm_post_denoise(out_rgb, out_c8, out_rgb_store, x, x_rgb, theta, b, w, first_iter_alias, orig=None,
-                    sse_part=None):
+                    sse_part=None, mosaic=None):
     B, _, M, N = x.shape
     nb = C.c_int(0)
+    if mosaic is not None:                   # x_rgb rebuilt from the mosaic pm_pre_denoise(..., mosaic=) stored
+        if x_rgb is not None:
+            raise ValueError('pm_post_denoise: give x_rgb or mosaic, not both')
+        _call('scipnp_pm_post_denoise_mosaic', _p(out_rgb, 'out_rgb'), _p(out_c8, 'out_c8'), _p(out_rgb_store, 'out_rgb_store'),
+              _p(x, 'x'), _p(mosaic, 'mosaic'), _p(theta, 'theta'), _p(b, 'b'), _p(w, 'w'), _p(orig, 'orig'),
+              _p(sse_part, 'sse_part', torch.float64), int(bool(first_iter_alias)), M, N, B, C.byref(nb), _stream())
+        if sse_part is not None and nb.value != sse_part.numel():
+            raise _lib.ScipnpError(f'SSE partial count mismatch: kernel wrote {nb.value}, buffer has {sse_part.numel()}')
+        return nb.value
     _call('scipnp_pm_post_denoise', _p(out_rgb, 'out_rgb'), _p(out_c8, 'out_c8'), _p(out_rgb_store, 'out_rgb_store'),
           _p(x, 'x'), _p(x_rgb, 'x_rgb'), _p(theta, 'theta'), _p(b, 'b'), _p(w, 'w'), _p(orig, 'orig'),
           _p(sse_part, 'sse_part', torch.float64), int(bool(first_iter_alias)), M, N, B, C.byref(nb), _stream())

@@ -232,6 +232,9 @@ class AdmmRun:
             self.x_rgb = torch.empty(B, 3, H, W, dtype=F32, device=self.device)
             self.w = torch.zeros_like(self.x_rgb) if two_stage else None
             self.out_store = torch.empty_like(self.x_rgb)
+            # two-stage + Malvar: only the mosaic x + b/rho travels from the pre- to the post-denoiser kernel (4 E bytes each way instead of
+            # x_rgb's 12 E; ops.pm_pre_denoise / pm_post_denoise mosaic=).  x_rgb itself stays for the closed-form and DDnet branches.
+            self.mosaic = torch.empty_like(self.x) if two_stage else None
             # the range-guard word exists BEFORE the engines do: their constructors pack the split-fp16 weights, and a weight
             # outside the representable range (|w| >= 31.9, e.g. after a BatchNorm fold) must raise THIS solve's word
             from .nets import default_precision
@@ -324,6 +327,7 @@ class AdmmRun:
             b_in, inv_rho, inv_tau, w = ops.negate(self.b), 1.0, 0.0, None
         closed = self.close_form and k > 0      # closed-form RGB update (reference :175-182 / :224-230), Malvar at k = 0
         pending = None
+        via_mosaic = False                      # this iteration's pre kernel stored the mosaic instead of x_rgb
         if self.denoiser == 'ffdnet_color':
             split = self.eng.precision == 'f16x3'
             # the finetune's weight-gradient kernel (fp32 MFMA) needs the fp32 c8 input as well
@@ -335,6 +339,9 @@ class AdmmRun:
             elif self.dd is not None:
                 self._deep_demosaic(b_in, inv_rho)
                 ops.pm_pre_rgb(w, self.x_rgb, None, c8, inv_tau, nsig, net_in_c8s=c8s)
+            elif self.two_stage:
+                ops.pm_pre_denoise(self.x, b_in, w, None, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s, mosaic=self.mosaic)
+                via_mosaic = True
             else:
                 ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, c8, inv_rho, inv_tau, nsig, net_in_c8s=c8s)
             if gate:
@@ -351,9 +358,11 @@ class AdmmRun:
             elif self.dd is not None:
                 self._deep_demosaic(b_in, inv_rho)
                 ops.pm_pre_rgb(w, self.x_rgb, self.rgb_w, None, inv_tau, nsig)
+            elif self.two_stage:
+                ops.pm_pre_denoise(self.x, b_in, w, None, self.rgb_w, None, inv_rho, inv_tau, nsig, mosaic=self.mosaic)
+                via_mosaic = True
             else:
-                ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, self.rgb_w if self.two_stage else None, None,
-                                   inv_rho, inv_tau, nsig)
+                ops.pm_pre_denoise(self.x, b_in, w, self.x_rgb, None, None, inv_rho, inv_tau, nsig)
             if gate and self.two_stage and (self.update_i < self.update_times or self.update_times < 0):
                 from .finetune import fastdvdnet_online_finetune
                 fastdvdnet_online_finetune(self.model, self.eng, net_in, self.y, self.Phi, nsig, self.lr_,
@@ -364,8 +373,8 @@ class AdmmRun:
         iqa_here = self.iqa and self.two_stage
         part = self._new_sse(ops.post_nblocks(M, N, B)) if iqa_here else None
         ops.pm_post_denoise(src_rgb, src_c8, self.out_store if ((last or self.close_form) and src_c8 is not None) else None,
-                            self.x, self.x_rgb if self.two_stage else None, self.theta, b_in, w, k == 0,
-                            self.orig if iqa_here else None, part)
+                            self.x, self.x_rgb if (self.two_stage and not via_mosaic) else None, self.theta, b_in, w, k == 0,
+                            self.orig if iqa_here else None, part, mosaic=self.mosaic if via_mosaic else None)
         if not self.two_stage:
             ops.negate(b_in, out=self.b)
             if self.iqa:
@@ -462,7 +471,7 @@ class AdmmRun:
                 getattr(r, name).copy_(getattr(self, name).view(B, U, 4, self.M, self.N)[:, u])
             r.sse_rows = list(rows[u])
             if self.denoiser != 'tv':
-                for name in ('x_rgb', 'w', 'out_store'):
+                for name in ('x_rgb', 'w', 'out_store'):            # (mosaic: written and read inside one step)
                     src = getattr(self, name)
                     if src is not None:
                         getattr(r, name).copy_(src.view(B, U, 3, H, W)[:, u])

@@ -146,6 +146,15 @@ int scipnp_pm_pre_denoise_ex(const float* x, const float* b, const float* w, flo
                              float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho,
                              float inv_tau, float sigma, scipnp_stream_t s);
 
+/* the same fusion with only the MOSAIC handed on to the post-denoiser kernel (round 6): instead of x_rgb ([B][3][H][W], 12 bytes per
+ * state element written here and read back by scipnp_pm_post_denoise for w += x_rgb - out) the kernel stores the mosaic x + inv_rho*b
+ * it demosaicked, plane-major [B][4][M][N] like x (4 bytes per element), and scipnp_pm_post_denoise_mosaic demosaicks its pixels
+ * again from it -- the same operations in the same order, so w receives bit for bit what it receives through x_rgb.  `mosaic` must
+ * not alias x or b; at least one of rgb_w / net_in_c8 / net_in_c8s is required.  -- the same reference lines as above. */
+int scipnp_pm_pre_denoise_mosaic(const float* x, const float* b, const float* w, float* mosaic, float* rgb_w,
+                                 float* net_in_c8, void* net_in_c8s, int M, int N, int B, float inv_rho,
+                                 float inv_tau, float sigma, scipnp_stream_t s);
+
 /* closed-form RGB update of the reference's `close_form_demosaic=True` branch for iterations k > 0:
  *   x_rgb = (rho*x3 + b3 + tau*out_prev + w) / (rho*cfa_mask + tau), clipped to [0,1] if clip != 0,
  * x3/b3 = Bayer planes scattered to their CFA sites; then x_rgb - inv_tau*w in the same layouts as above.
@@ -171,6 +180,14 @@ int scipnp_pm_post_denoise(const float* out_rgb, const float* out_c8, float* out
                            float* x, const float* x_rgb, float* theta, float* b, float* w,
                            const float* orig, double* sse_part, int first_iter_alias,
                            int M, int N, int B, int* nblocks, scipnp_stream_t s);
+
+/* the same with x_rgb recomputed from the mosaic scipnp_pm_pre_denoise_mosaic stored (Malvar-2004 on the 6x6 window of every Bayer
+ * quad, reflect-101 border: the pre kernel's own operations); w is required (without a w update nothing needs x_rgb: use
+ * scipnp_pm_post_denoise with x_rgb = NULL).  -- dvp...:206-209 / :256-259, :265, :267, :271, :274-279, malvar2004.py:169-246. */
+int scipnp_pm_post_denoise_mosaic(const float* out_rgb, const float* out_c8, float* out_rgb_store,
+                                  float* x, const float* mosaic, float* theta, float* b, float* w,
+                                  const float* orig, double* sse_part, int first_iter_alias,
+                                  int M, int N, int B, int* nblocks, scipnp_stream_t s);
 
 /* sum of squared differences, per-block fp64 partials (deterministic two-level reduction; the
  * host adds the nblocks doubles)  -- skimage peak_signal_noise_ratio at dvp...:279,:320 */

@@ -1267,6 +1267,44 @@ def test_tv_banded_kernel_random_shapes(ops):
         assert torch.equal(o1, o3), (M, N, C_, n_iter)
 
 
+@pytest.mark.parametrize('shape', [(3, 8, 8), (8, 37, 70), (2, 128, 256)])
+def test_mosaic_hand_off_between_the_pre_and_post_denoiser_kernels_is_bit_identical(ops, shape):
+    """round 6: scipnp_pm_pre_denoise_mosaic stores the mosaic x + b/rho (4 bytes per state element) instead of x_rgb (12) and
+    scipnp_pm_post_denoise_mosaic demosaicks it again for w += x_rgb - out -- every output of the pair (both denoiser-input layouts,
+    theta, b, w, the out_store copy, the squared-error partials) equals the x_rgb pair's bit for bit, borders (reflect-101) included,
+    with a planar and with a c8 denoiser output, in the first-iteration alias mode too"""
+    B, M, N = shape
+    g = torch.Generator().manual_seed(7 * M + N)
+    x = torch.rand(B, 4, M, N, generator=g).cuda()
+    b = ((torch.rand(B, 4, M, N, generator=g) - 0.5) * 0.2).cuda()
+    w0 = ((torch.rand(B, 3, 2 * M, 2 * N, generator=g) - 0.5) * 0.1).cuda()
+    orig = torch.rand(B, 4, M, N, generator=g).cuda()
+    out_rgb = torch.rand(B, 3, 2 * M, 2 * N, generator=g).cuda() * 1.2 - 0.1
+    out_c8 = torch.rand(B, 2, M, N, 8, generator=g).cuda() * 1.2 - 0.1
+    for alias in (False, True):
+        for planar in (True, False):
+            res = []
+            for mode in ('x_rgb', 'mosaic'):
+                xs, bs, ws, th = x.clone(), b.clone(), w0.clone(), torch.empty_like(x)
+                x_rgb, mos = torch.empty_like(w0), torch.full_like(x, -3.0)
+                rgb_w, c8 = torch.empty_like(w0), torch.empty(B, 2, M, N, 8, device='cuda')
+                part = torch.empty(ops.post_nblocks(M, N, B), dtype=torch.float64, device='cuda')
+                store = torch.empty_like(w0) if not planar else None
+                if mode == 'x_rgb':
+                    ops.pm_pre_denoise(xs, bs, ws, x_rgb, rgb_w, c8, 1 / 0.55, 0.01, 25 / 255)
+                    ops.pm_post_denoise(out_rgb if planar else None, None if planar else out_c8, store, xs, x_rgb, th, bs, ws, alias, orig, part)
+                else:
+                    ops.pm_pre_denoise(xs, bs, ws, None, rgb_w, c8, 1 / 0.55, 0.01, 25 / 255, mosaic=mos)
+                    assert torch.equal(mos, x + np.float32(1 / 0.55) * b)
+                    ops.pm_post_denoise(out_rgb if planar else None, None if planar else out_c8, store, xs, None, th, bs, ws, alias, orig, part,
+                                        mosaic=mos)
+                res.append((rgb_w, c8, xs, bs, ws, th, part, store))
+            for a_, b_ in zip(*res):
+                assert (a_ is None and b_ is None) or torch.equal(a_, b_), (shape, alias, planar)
+    with pytest.raises(ValueError):
+        ops.pm_pre_denoise(x, b, w0, torch.empty_like(w0), None, None, 1.0, 0.01, 0.1, mosaic=torch.empty_like(x))
+
+
 def test_projection_on_a_state_beyond_the_infinity_cache_equals_the_small_state_kernel(ops):
     """round 6: above 384 MB per launch scipnp_pm_project reads theta, b, Phi with non-temporal loads (pm_project_kernel<4, 8, MODE, true>:
     6.0 instead of 4.8 TB/s on a 2048 x 2048 x 8 state, profiles/r06k_proj_stream.txt) -- the same per-pixel expressions: a unit batch of

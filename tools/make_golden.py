@@ -559,7 +559,9 @@ def _full512(name, seed, denoiser, its, sig, net, onet, **kw):
     print(f'   oracle {denoiser} {its} at 512x512x8: {time.time() - t0:.0f} s')
     check(f'{name}: final mosaic', o['x_bayer'], res[1], tol=float(os.environ.get('FULL512_TOL', '0')))
     check(f'{name}: PSNR of every iteration', np.array(o['psnr_all']), np.array(res[4]), tol=float(os.environ.get('FULL512_TOL', '0')))
-    save(name, final=np.asarray(res[1], np.float32), psnr_all=np.asarray(res[4], np.float64), psnr_frames=np.asarray(res[2], np.float64),
+    # (PyTorch's CPU convolutions sum in an order that depends on the thread count: the files are bit-reproducible at the script's
+    # default of 8 threads, which `threads` records; other counts move the final mosaic by ~1e-7 relative)
+    save(name, threads=np.array(torch.get_num_threads()), final=np.asarray(res[1], np.float32), psnr_all=np.asarray(res[4], np.float64), psnr_frames=np.asarray(res[2], np.float64),
          warm_sha=np.frombuffer(__import__('hashlib').sha256(np.ascontiguousarray(warm).tobytes()).digest(), np.uint8),
          seed=np.array(seed), its=np.array(its), sig=np.array(sig))
 
