@@ -87,6 +87,21 @@ __device__ __forceinline__ void load_window(const float* __restrict__ xt, const 
     }
 }
 
+// Which (column block, quad row m, frame t) this workgroup computes.  Workgroups are dealt round-robin over the 8 XCDs in dispatch
+// order, so with the plain (blockIdx.x, y, z) mapping the quad rows m - 1, m, m + 1 a workgroup's 6x6 windows read belong to three
+// different XCDs and every L2 fetches every row of x, b (or the mosaic) three times (PMC: 134 MB per pre-denoiser launch against
+// 98 algorithmic).  Remapped, XCD k works through a CONTIGUOUS eighth of the (t, m, column block) order and finds its neighbours'
+// rows in its own L2.  The logical indices are what everything below uses (the squared-error partials keep their order).
+__device__ __forceinline__ void quad_block(int& bx, int& m, int& t) {
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    unsigned lin = (blockIdx.z * ny + blockIdx.y) * nx + blockIdx.x;
+    if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+    bx = (int)(lin % nx);
+    const unsigned r = lin / nx;
+    m = (int)(r % ny);
+    t = (int)(r / ny);
+}
+
 // shared tail of the two pre-denoiser kernels: store x_rgb, form x_rgb - inv_tau*w and emit it in the requested
 // layouts (planar rgb_w, fp32 c8 with the pixel-unshuffle + sigma map, split-fp16 c8s)
 __device__ __forceinline__ void emit_pre_outputs(const float (&rgb)[3][2][2], const float* __restrict__ w,
@@ -134,9 +149,9 @@ pm_pre_denoise_kernel(const float* __restrict__ x, const float* __restrict__ b,
                       const float* __restrict__ w, float* __restrict__ x_rgb, float* __restrict__ mosaic_out, float* __restrict__ rgb_w,
                       float* __restrict__ net_in, char* __restrict__ net_in_s, int M, int N, int B, float inv_rho,
                       float inv_tau, float sigma) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = blockIdx.y;
-    const int t = blockIdx.z;
+    int bx, m, t;
+    quad_block(bx, m, t);
+    const int n = bx * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const size_t plane = (size_t)M * N;
     float v[6][6];
@@ -219,9 +234,9 @@ pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restric
                        float* __restrict__ w, const float* __restrict__ orig, double* sse_part,
                        int first_iter_alias, int M, int N, int B) {
     __shared__ double red[16];
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = blockIdx.y;
-    const int t = blockIdx.z;
+    int bx, m, t;
+    quad_block(bx, m, t);
+    const int n = bx * blockDim.x + threadIdx.x;
     double acc = 0.0;
     if (n < N) {
         const size_t plane = (size_t)M * N;
@@ -284,7 +299,7 @@ pm_post_denoise_kernel(const float* __restrict__ out_rgb, const float* __restric
     if (sse_part) {
         const double s = block_sum_double(acc, red, threadIdx.x, blockDim.x);
         if (threadIdx.x == 0)
-            sse_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+            sse_part[((size_t)t * gridDim.y + m) * gridDim.x + bx] = s;
     }
 }
 
