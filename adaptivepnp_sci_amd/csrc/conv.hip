@@ -72,8 +72,22 @@ conv3x3_c8_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
-    const int n = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+    // XCD-aware order (round 6, as the Winograd kernels): workgroups are dealt round-robin to the 8 XCDs in dispatch order; remapped, one
+    // XCD works through a contiguous run of (tile, output-channel split) pairs -- the splits of a tile adjacent, tiles row by row -- so
+    // the input tile a split re-reads and the halo rows of the tile below are found in that XCD's L2
+    int x0, y0, n, split;
+    {
+        const unsigned ntx = gridDim.x, nty = gridDim.y, nz = gridDim.z, total = ntx * nty * nz;
+        unsigned lin = (blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
+        if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+        const unsigned ns = (unsigned)a.nsplit;
+        split = (int)(lin % ns);
+        unsigned t = lin / ns;
+        x0 = (int)(t % ntx) * CV_TW;
+        t /= ntx;
+        y0 = (int)(t % nty) * CV_TH;
+        n = (int)(t / nty);
+    }
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
 
