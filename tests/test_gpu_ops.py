@@ -1303,6 +1303,14 @@ def test_mosaic_hand_off_between_the_pre_and_post_denoiser_kernels_is_bit_identi
                 assert (a_ is None and b_ is None) or torch.equal(a_, b_), (shape, alias, planar)
     with pytest.raises(ValueError):
         ops.pm_pre_denoise(x, b, w0, torch.empty_like(w0), None, None, 1.0, 0.01, 0.1, mosaic=torch.empty_like(x))
+    c8 = torch.empty(B, 2, M, N, 8, device='cuda')
+    with pytest.raises(ValueError, match='alias'):            # the mosaic may not be x or b: their neighbours are still being read
+        ops.pm_pre_denoise(x, b, w0, None, None, c8, 1.0, 0.01, 0.1, mosaic=x)
+    with pytest.raises(ValueError, match='layout'):           # ... and some denoiser-input layout has to be asked for
+        ops.pm_pre_denoise(x, b, w0, None, None, None, 1.0, 0.01, 0.1, mosaic=torch.empty_like(x))
+    th = torch.empty_like(x)
+    with pytest.raises(ValueError, match='alias'):
+        ops.pm_post_denoise(out_rgb, None, None, x.clone(), None, th, b.clone(), w0.clone(), False, mosaic=th)
 
 
 def test_projection_on_a_state_beyond_the_infinity_cache_equals_the_small_state_kernel(ops):
